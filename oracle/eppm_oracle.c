@@ -1,0 +1,1000 @@
+/*
+ * eppm_oracle.c -- CPU restatement of the EPPM optical-flow hot path (TEST INFRASTRUCTURE ONLY).
+ * See eppm_oracle.h for the parity status ("parity unpinned" against the CUDA original)
+ * and the determinism rules.  Citations are file:line under /root/reference.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -fPIC -shared (oracle/Makefile).
+ * -ffp-contract=off is part of the specification: the only fused operations are the
+ * explicit fmaf() calls in orc_fast_exp.
+ */
+#include "eppm_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * constants: defs.h:31-76 and the file-local #defines
+ * ---------------------------------------------------------------------------------------- */
+#define PYR_RATIO 0.5f                    /* defs.h:33 */
+#define PM_SIG_R 0.1f                     /* defs.h:48 */
+#define LAMBDA_AD 0.1f                    /* defs.h:51 */
+#define LAMBDA_CENSUS 0.3f                /* defs.h:52 */
+#define CENSUS_MAX_DIFF 8                 /* bao_pmflow_kernel.cu:32 */
+#define WMF_RADIUS 4                      /* defs.h:58 */
+#define WMF_SIG_S (WMF_RADIUS * 1.0f)     /* defs.h:59 */
+#define WMF_SIG_R 0.02f                   /* defs.h:60 */
+#define POSTPROC_BLF_SIG_S 5              /* defs.h:64 */
+#define POSTPROC_BLF_SIG_R 0.02f          /* refine :752 */
+#define POSTPROC_BLF_RADIUS (2 * POSTPROC_BLF_SIG_S) /* refine :753 */
+#define STAT_RADIUS 6                     /* defs.h:68 */
+#define STAT_COUNT_THRESH ((2 * STAT_RADIUS + 1) * (2 * STAT_RADIUS + 1) / 2) /* refine :146 */
+#define STAT_SIM_THRESH 2                 /* refine :147 */
+#define INVALID_LOCATION (-10000)         /* refine :46 */
+#define DIFF_THRESH 0                     /* refine :51 */
+#define UNKNOWN_FLOW_THRESH 1e9           /* defs.h:85 */
+#define UNKNOWN_FLOW 1e10                 /* defs.h:90 */
+#define BLOCK_DIM 16                      /* bao_pmflow_kernel.cu:42-43 */
+
+/* plane-fitting coefficients, bao_pmflow_kernel.cu:319-332 */
+static const float kPlaneCoef[4][4] = {
+    /* u_x,    u_y,     v_x,     v_y */
+    {0.0f,    0.0f,    0.0f,    0.0f},
+    {0.177f, -0.011f, -0.003f,  0.301f},   /* COEF_FL_*    */
+    {0.125f, -0.357f,  0.009f,  0.308f},   /* COEF_LEFT_*  */
+    {0.205f,  0.370f,  0.011f,  0.296f},   /* COEF_RIGHT_* */
+};
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline float fmax2(float a, float b) { return a > b ? a : b; }
+
+void orc_default_params(orc_params* p)
+{
+    p->patch_r = 9; p->num_iter = 10; p->search_range = 30; p->num_guess = 6;
+    p->seg_len = 10; p->wmf_iters = 20; p->seed = 1234ULL; p->dump_stages = 0;
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------
+ * __expf restated.  CUDA's __expf(x) is ex2.approx.ftz(x * log2(e)) (CUDA C Programming
+ * Guide, intrinsic table).  The SFU's ex2.approx is not specified bit for bit, so both the
+ * oracle and the HIP kernels use this one float32 formula (max rel. error 1.7e-7, i.e. the
+ * same 2-ulp class as ex2.approx):
+ *     y = x * log2e;  y < -125 -> 0 (the ".ftz" flush);  n = rint(y);  f = y - n in [-.5,.5];
+ *     2^f by a degree-5 polynomial evaluated with fmaf (Horner);  result = ldexp(p, n).
+ * Used at: bao_pmflow_kernel.cu:285,291; refine :201,759; bao_basic_cuda.cuh:453.
+ * ---------------------------------------------------------------------------------------- */
+float orc_fast_exp(float x)
+{
+    float y = x * 0x1.715476p+0f;
+    if (y < -125.0f) return 0.0f;
+    if (y > 127.0f) y = 127.0f;      /* never reached on this path (all arguments are <= 0) */
+    const float n = rintf(y);
+    const float f = y - n;
+    float p = fmaf(0x1.5bba14p-10f, f, 0x1.3cea88p-7f);
+    p = fmaf(p, f, 0x1.c6b752p-5f);
+    p = fmaf(p, f, 0x1.ebf9bcp-3f);
+    p = fmaf(p, f, 0x1.62e42ap-1f);
+    p = fmaf(p, f, 1.0f);
+    /* ldexpf(p, n): p in [0.70,1.42] and n >= -125, so the product is a normal float and the
+     * multiplication by the exactly representable 2^n is exact */
+    union { uint32_t u; float f; } two_n;
+    two_n.u = (uint32_t)((int)n + 127) << 23;
+    return p * two_n.f;
+}
+
+/* unorm8 -> float of cudaReadModeNormalizedFloat: c/255 rounded to nearest */
+static float g_unorm[256];
+static int g_unorm_ready = 0;
+static void init_unorm(void)
+{
+    if (g_unorm_ready) return;
+    for (int i = 0; i < 256; i++) g_unorm[i] = (float)i / 255.0f;
+    g_unorm_ready = 1;
+}
+
+/* LUTs: bao_pmflow_kernel.cu:670-687 */
+void orc_pm_luts(int patch_r, float* gs, float* cn)
+{
+    const float sig_s = 0.5f * patch_r;                 /* PM_SIG_S, defs.h:47 */
+    for (int i = 0; i <= patch_r; i++) gs[i] = expf(-(i * i) / (sig_s * sig_s));
+    for (int i = 0; i <= CENSUS_MAX_DIFF; i++)
+        cn[i] = 1 - expf(-(float)(i * i) / (LAMBDA_CENSUS * CENSUS_MAX_DIFF * LAMBDA_CENSUS * CENSUS_MAX_DIFF));
+}
+/* refine :270-275 */
+void orc_wmf_lut(float* g)
+{
+    for (int i = 0; i <= WMF_RADIUS; i++) g[i] = expf(-(float)(i * i) / (WMF_SIG_S * WMF_SIG_S));
+}
+/* refine :811-816 */
+void orc_blf_lut(float* g)
+{
+    for (int i = 0; i <= POSTPROC_BLF_RADIUS; i++)
+        g[i] = expf(-(float)(i * i) / (float)(POSTPROC_BLF_SIG_S * POSTPROC_BLF_SIG_S));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * XORWOW.  cuRAND's default generator (curandState = curandStateXORWOW), used by the
+ * reference at bao_pmflow_kernel.cu:68,94-95,1546-1547.  cuRAND is not part of
+ * /root/reference (CUDA toolkit "> 5.0", README.md:19, no pinned version); this restates
+ * the published algorithm: Marsaglia's xorwow (G. Marsaglia, "Xorshift RNGs", JSS 8(14),
+ * 2003, p.5) with cuRAND's documented seeding (seed scrambling, then a skip of
+ * subsequence * 2^67 draws, offset 0), cf. curand_kernel.h _curand_init_scratch/curand().
+ * The 2^67 skip is done with the GF(2) transition matrix of the xorshift part raised to the
+ * 2^67-th power (the Weyl counter d advances by 362437 * 2^67 = 0 mod 2^32).
+ * No reference test pins any value of this stream: "RNG stream: parity unpinned".
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { uint32_t r[160][5]; } mat160;
+
+static inline void xorwow_step_v(uint32_t v[5])
+{
+    uint32_t t = v[0] ^ (v[0] >> 2);
+    v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = v[4];
+    v[4] = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+}
+
+uint32_t orc_xorwow_next(orc_xorwow* s)
+{
+    xorwow_step_v(s->v);
+    s->d += 362437u;
+    return s->v[4] + s->d;
+}
+
+static void vecmat(const uint32_t v[5], const mat160* m, uint32_t out[5])
+{
+    uint32_t a[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 5; i++)
+        for (int j = 0; j < 32; j++)
+            if (v[i] & (1u << j)) {
+                const uint32_t* row = m->r[i * 32 + j];
+                for (int k = 0; k < 5; k++) a[k] ^= row[k];
+            }
+    memcpy(out, a, sizeof(a));
+}
+static void matmul(const mat160* a, const mat160* b, mat160* out)
+{
+    mat160* t = (mat160*)malloc(sizeof(mat160));
+    for (int i = 0; i < 160; i++) vecmat(a->r[i], b, t->r[i]);
+    memcpy(out, t, sizeof(mat160));
+    free(t);
+}
+static void mat_step(mat160* m) /* the one-draw transition matrix */
+{
+    for (int i = 0; i < 160; i++) {
+        uint32_t v[5] = {0, 0, 0, 0, 0};
+        v[i / 32] = 1u << (i % 32);
+        xorwow_step_v(v);
+        memcpy(m->r[i], v, sizeof(v));
+    }
+}
+
+#define SEQ_POW_MAX 40
+static mat160* g_seq_pow = NULL;   /* g_seq_pow[k] = M^(2^(67+k)) */
+static mat160* g_one_pow = NULL;   /* g_one_pow[k] = M^(2^k), k < 64 */
+static void init_jump(void)
+{
+#pragma omp critical(orc_jump)
+    {
+        if (!g_seq_pow) {
+            mat160* one = (mat160*)malloc(sizeof(mat160) * 64);
+            mat160* seq = (mat160*)malloc(sizeof(mat160) * SEQ_POW_MAX);
+            mat_step(&one[0]);
+            for (int k = 1; k < 64; k++) matmul(&one[k - 1], &one[k - 1], &one[k]);
+            mat160 cur;
+            matmul(&one[63], &one[63], &cur);                                  /* 2^64 */
+            for (int k = 64; k < 67; k++) matmul(&cur, &cur, &cur);            /* 2^67 */
+            seq[0] = cur;
+            for (int k = 1; k < SEQ_POW_MAX; k++) matmul(&seq[k - 1], &seq[k - 1], &seq[k]);
+            g_one_pow = one;
+            g_seq_pow = seq;
+        }
+    }
+}
+
+void orc_xorwow_skip(orc_xorwow* s, unsigned long long n)
+{
+    init_jump();
+    s->d += 362437u * (uint32_t)n;
+    for (int k = 0; k < 64; k++)
+        if (n & (1ULL << k)) vecmat(s->v, &g_one_pow[k], s->v);
+}
+
+void orc_xorwow_init(orc_xorwow* s, unsigned long long seed, unsigned long long subsequence)
+{
+    init_jump();
+    /* seed scrambling (curand_kernel.h, _curand_init_scratch) */
+    uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
+    uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0;
+    uint32_t t1 = 2591861531u * s1;
+    s->d = 6615241u + t1 + t0;
+    s->v[0] = 123456789u + t0;
+    s->v[1] = 362436069u ^ t0;
+    s->v[2] = 521288629u + t1;
+    s->v[3] = 88675123u ^ t1;
+    s->v[4] = 5783321u + t0;
+    /* skipahead_sequence(subsequence): subsequence * 2^67 draws */
+    for (int k = 0; k < SEQ_POW_MAX; k++)
+        if (subsequence & (1ULL << k)) vecmat(s->v, &g_seq_pow[k], s->v);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * pyramid geometry: basic/bao_basic.h:196-211 (maxDepth overload)
+ * ---------------------------------------------------------------------------------------- */
+int orc_pyr_init_dim(int* arrH, int* arrW, int h, int w, int max_depth, float ratio)
+{
+    if (max_depth == 0) max_depth = 1;
+    int n = max_depth;
+    if (n <= 0) n = 1;
+    arrH[0] = h; arrW[0] = w;
+    for (int i = 1; i < n; i++) {
+        arrH[i] = (int)((double)h * pow(ratio, i));   /* BAO_FLOAT is double, bao_basic.h:56 */
+        arrW[i] = (int)((double)w * pow(ratio, i));
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * prepare
+ * ---------------------------------------------------------------------------------------- */
+/* bao_basic_cuda.h:258-267 */
+void orc_rgb2rgba(orc_uchar4* out, const uint8_t* rgb, int h, int w)
+{
+    for (int i = 0; i < h * w; i++) {
+        out[i].x = rgb[3 * i]; out[i].y = rgb[3 * i + 1]; out[i].z = rgb[3 * i + 2]; out[i].w = 0;
+    }
+}
+
+/* basic/bao_basic_cuda.cuh:437-467.  Dense (2r+1)^2 Gaussian, clamp-to-edge, weight
+ * recomputed per tap with __expf, float accumulation in tap order (dy outer, dx inner),
+ * one division per channel, float->u8 by truncation. */
+void orc_gauss_filter_rgba(orc_uchar4* out, const orc_uchar4* in, int h, int w, float sigma, int radius_i)
+{
+    const float radius = (float)radius_i;
+    sigma = sigma * sigma * 2;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float vx = 0, vy = 0, vz = 0, vw = 0, sum = 0;
+            for (int dy = (int)-radius; dy <= radius; dy++)
+                for (int dx = (int)-radius; dx <= radius; dx++) {
+                    int cy = imax(0, imin(h - 1, y + dy));
+                    int cx = imax(0, imin(w - 1, x + dx));
+                    float weight = orc_fast_exp(-(float)(dy * dy + dx * dx) / sigma);
+                    orc_uchar4 t = in[(size_t)cy * w + cx];
+                    vx += t.x * weight; vy += t.y * weight; vz += t.z * weight; vw += t.w * weight;
+                    sum += weight;
+                }
+            vx /= sum; vy /= sum; vz /= sum; vw /= sum;
+            orc_uchar4 r;
+            r.x = (uint8_t)vx; r.y = (uint8_t)vy; r.z = (uint8_t)vz; r.w = (uint8_t)vw;
+            out[(size_t)y * w + x] = r;
+        }
+}
+
+/* basic/bao_basic_cuda.cuh:565-601 (uchar4 specialisation) */
+void orc_resize_rgba(orc_uchar4* out, int outH, int outW, const orc_uchar4* in, int h, int w, float ratio)
+{
+    const float div_scale = 1.f / ratio;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < outH; y++)
+        for (int x = 0; x < outW; x++) {
+            float fx = (float)(x + 1) * div_scale - 1;
+            float fy = (float)(y + 1) * div_scale - 1;
+            int xx = (int)fx, yy = (int)fy;
+            float dx = fmax2(fminf(fx - xx, 1), 0);
+            float dy = fmax2(fminf(fy - yy, 1), 0);
+            float rx = 0, ry = 0, rz = 0, rw = 0;
+            for (int m = 0; m <= 1; m++)
+                for (int n = 0; n <= 1; n++) {
+                    int u = imax(0, imin(w - 1, xx + m));
+                    int v = imax(0, imin(h - 1, yy + n));
+                    float s = fabsf(1 - m - dx) * fabsf(1 - n - dy);
+                    orc_uchar4 t = in[(size_t)v * w + u];
+                    rx += (t.x * s); ry += (t.y * s); rz += (t.z * s); rw += (t.w * s);
+                }
+            orc_uchar4 r;
+            r.x = (uint8_t)rx; r.y = (uint8_t)ry; r.z = (uint8_t)rz; r.w = (uint8_t)rw;
+            out[(size_t)y * outW + x] = r;
+        }
+}
+
+/* bao_pmflow_census_kernel.cu:39-90: bit k = lum(neigh_k) > lum(centre), clamp addressing */
+static inline float lum_of(orc_uchar4 p)
+{
+    return 0.3f * g_unorm[p.x] + 0.6f * g_unorm[p.y] + 0.1f * g_unorm[p.z];
+}
+void orc_census(uint8_t* census, const orc_uchar4* img, int h, int w)
+{
+    init_unorm();
+    static const int ox[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+    static const int oy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float c = lum_of(img[(size_t)y * w + x]);
+            unsigned r = 0;
+            for (int k = 0; k < 8; k++) {
+                int cx = iclamp(x + ox[k], 0, w - 1), cy = iclamp(y + oy[k], 0, h - 1);
+                if (lum_of(img[(size_t)cy * w + cx]) > c) r += (1u << k);
+            }
+            census[(size_t)y * w + x] = (uint8_t)r;
+        }
+}
+
+/* refine :1060-1071 + basic/bao_basic_cuda.cuh:642-664 */
+void orc_prepare(orc_uchar4** img_pyr, uint8_t** census_pyr, const orc_uchar4* raw, const int* arrH, const int* arrW, int n_levels)
+{
+    const float ratio = PYR_RATIO;
+    orc_gauss_filter_rgba(img_pyr[0], raw, arrH[0], arrW[0], .5f, 2);        /* refine :1063 */
+    /* construct_gauss_pyramid_pitched: pPyr[0] == d_img so no copy (.cuh:646) */
+    float baseSigma = (1 / ratio - 1);
+    int n = (int)(log(0.25) / log(ratio));
+    float nSigma = baseSigma * n;
+    orc_uchar4** tmp = (orc_uchar4**)calloc(n_levels, sizeof(orc_uchar4*));
+    for (int i = 0; i < n_levels; i++) tmp[i] = (orc_uchar4*)malloc(sizeof(orc_uchar4) * arrH[i] * arrW[i]);
+    for (int i = 1; i < n_levels; i++) {
+        if (i <= n) {
+            float sigma = baseSigma * i;
+            orc_gauss_filter_rgba(tmp[0], img_pyr[0], arrH[0], arrW[0], sigma, (int)(sigma * 3));
+            orc_resize_rgba(img_pyr[i], arrH[i], arrW[i], tmp[0], arrH[0], arrW[0], (float)pow(ratio, i));
+        } else {
+            orc_gauss_filter_rgba(tmp[i - n], img_pyr[i - n], arrH[i - n], arrW[i - n], nSigma, (int)(nSigma * 3));
+            orc_resize_rgba(img_pyr[i], arrH[i], arrW[i], tmp[i - n], arrH[i - n], arrW[i - n],
+                            (float)pow(ratio, i) * arrW[0] / arrW[i - n]);
+        }
+    }
+    for (int i = 0; i < n_levels; i++) free(tmp[i]);
+    free(tmp);
+    for (int i = 0; i < n_levels; i++) orc_census(census_pyr[i], img_pyr[i], arrH[i], arrW[i]);  /* refine :1067-1070 */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * patch cost: bao_pmflow_kernel.cu:255-301.  tex2D = point sample, clamp, u8/255 (A.2).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { float x, y, z; } rgbf;
+static inline rgbf tex_rgb(const orc_uchar4* img, int w, int h, int x, int y)
+{
+    x = iclamp(x, 0, w - 1); y = iclamp(y, 0, h - 1);
+    orc_uchar4 p = img[(size_t)y * w + x];
+    rgbf r = {g_unorm[p.x], g_unorm[p.y], g_unorm[p.z]};
+    return r;
+}
+static inline unsigned tex_u8(const uint8_t* c, int w, int h, int x, int y)
+{
+    x = iclamp(x, 0, w - 1); y = iclamp(y, 0, h - 1);
+    return c[(size_t)y * w + x];
+}
+static inline float max_abs_diff(rgbf a, rgbf b)
+{
+    return fmax2(fmax2(fabsf(a.x - b.x), fabsf(a.y - b.y)), fabsf(a.z - b.z));
+}
+static inline int popcount8(unsigned v) { int n = 0; while (v) { n++; v &= v - 1; } return n; }
+
+/* one sample of the inner loop, :275-295; (sx1,sy1) / (sx2,sy2) are the texel coordinates */
+static inline void patch_sample(const orc_uchar4* img1, const orc_uchar4* img2, const uint8_t* c1, const uint8_t* c2,
+                                int w, int h, rgbf center1, rgbf center2, int sx1, int sy1, int sx2, int sy2,
+                                float gs_j, float gs_i, const float* cn, float* cost_sum, float* weight_sum)
+{
+    rgbf p1 = tex_rgb(img1, w, h, sx1, sy1);
+    rgbf p2 = tex_rgb(img2, w, h, sx2, sy2);
+    unsigned k1 = tex_u8(c1, w, h, sx1, sy1);
+    unsigned k2 = tex_u8(c2, w, h, sx2, sy2);
+    int hamming = popcount8(k1 ^ k2);
+    float cost = max_abs_diff(p1, p2);
+    cost = 1 - orc_fast_exp(-(cost * cost) / (LAMBDA_AD * LAMBDA_AD));
+    cost += cn[hamming];
+    float weight = max_abs_diff(center1, p1);
+    weight *= weight;
+    float temp = max_abs_diff(center2, p2);
+    temp *= temp;
+    weight = orc_fast_exp(-(weight + temp) / (PM_SIG_R * PM_SIG_R));
+    weight *= gs_j * gs_i;
+    cost *= weight;
+    *cost_sum += cost;
+    *weight_sum += weight;
+}
+
+float orc_patch_dist(const orc_uchar4* img1, const orc_uchar4* img2, const uint8_t* c1, const uint8_t* c2,
+                     int w, int h, int R, const float* gs, const float* cn, int x1, int y1, int x2, int y2)
+{
+    init_unorm();
+    rgbf center1 = tex_rgb(img1, w, h, x1, y1);
+    rgbf center2 = tex_rgb(img2, w, h, x2, y2);
+    float cost_sum = 0.0f, weight_sum = 0.0f;
+    for (int i = -R; i <= R; i += 2)        /* "skip pixels": stride-2 grid, :269-272 */
+        for (int j = -R; j <= R; j += 2)
+            patch_sample(img1, img2, c1, c2, w, h, center1, center2, x1 + j, y1 + i, x2 + j, y2 + i,
+                         gs[abs(j)], gs[abs(i)], cn, &cost_sum, &weight_sum);
+    return cost_sum / weight_sum;
+}
+
+/* bao_pmflow_kernel.cu:334-513: min over 4 affine-warped passes, float target coordinates
+ * then floor (point sampling).  Coordinates are formed left to right without contraction. */
+float orc_patch_dist_planefit(const orc_uchar4* img1, const orc_uchar4* img2, const uint8_t* c1, const uint8_t* c2,
+                              int w, int h, int R, const float* gs, const float* cn, int x1, int y1, int x2, int y2)
+{
+    init_unorm();
+    rgbf center1 = tex_rgb(img1, w, h, x1, y1);
+    rgbf center2 = tex_rgb(img2, w, h, x2, y2);
+    const float uu = (float)(x2 - x1);
+    const float vv = (float)(y2 - y1);
+    float c4[4];
+    for (int pass = 0; pass < 4; pass++) {
+        const float* cf = kPlaneCoef[pass];
+        float cost_sum = 0.0f, weight_sum = 0.0f;
+        for (int i = -R; i <= R; i += 2)
+            for (int j = -R; j <= R; j += 2) {
+                float cx1 = (float)(x1 + j);
+                float cy1 = (float)(y1 + i);
+                float cx2, cy2;
+                if (pass == 0) { cx2 = cx1 + uu; cy2 = cy1 + vv; }
+                else {
+                    cx2 = cx1 + uu + (j)*cf[0] + (i)*cf[1];
+                    cy2 = cy1 + vv + (j)*cf[2] + (i)*cf[3];
+                }
+                patch_sample(img1, img2, c1, c2, w, h, center1, center2, (int)floorf(cx1), (int)floorf(cy1),
+                             (int)floorf(cx2), (int)floorf(cy2), gs[abs(j)], gs[abs(i)], cn, &cost_sum, &weight_sum);
+            }
+        c4[pass] = cost_sum / weight_sum;
+    }
+    /* __min(cost1,__min(cost2,__min(cost3,cost4))) :512 with __min(a,b) = (a<b)?a:b
+     * (basic/bao_basic_cuda.h:45); the nesting is kept because it decides what a NaN does */
+    float m34 = (c4[2] < c4[3]) ? c4[2] : c4[3];
+    float m234 = (c4[1] < m34) ? c4[1] : m34;
+    return (c4[0] < m234) ? c4[0] : m234;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * PatchMatch
+ * ---------------------------------------------------------------------------------------- */
+/* bao_pmflow_kernel.cu:50-109 */
+void orc_gen_rand_field(orc_xorwow* states, orc_short2* nnf, int w, int h, unsigned long long seed)
+{
+    const int gx = (w + BLOCK_DIM - 1) / BLOCK_DIM, gy = (h + BLOCK_DIM - 1) / BLOCK_DIM;
+    for (int by = 0; by < gy; by++)
+        for (int bx = 0; bx < gx; bx++) {
+            int block_id = by * gx + bx;
+            orc_xorwow st;
+            orc_xorwow_init(&st, seed, (unsigned long long)block_id);       /* :68 */
+            for (int i = 0; i < BLOCK_DIM; i++)
+                for (int j = 0; j < BLOCK_DIM; j++) {
+                    uint32_t r1 = orc_xorwow_next(&st);
+                    uint32_t r2 = orc_xorwow_next(&st);
+                    int x = bx * BLOCK_DIM + j, y = by * BLOCK_DIM + i;
+                    if (x < w && y < h) {
+                        nnf[(size_t)y * w + x].x = (int16_t)(r1 % (uint32_t)(w + 1));   /* :98 */
+                        nnf[(size_t)y * w + x].y = (int16_t)(r2 % (uint32_t)(h + 1));   /* :99 */
+                    }
+                }
+            states[block_id] = st;
+        }
+}
+
+/* :636-645 */
+void orc_cost_field(float* cost, const orc_short2* nnf, const orc_uchar4* img1, const orc_uchar4* img2,
+                    const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p)
+{
+    float gs[64], cn[9];
+    orc_pm_luts(p->patch_r, gs, cn);
+    init_unorm();
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            orc_short2 d = nnf[(size_t)y * w + x];
+            cost[(size_t)y * w + x] = orc_patch_dist(img1, img2, c1, c2, w, h, p->patch_r, gs, cn, x, y, d.x, d.y);
+        }
+}
+
+/* one segment walk.  along = coordinate along the sweep, line = the other coordinate.
+ * Forward: :1049-1076 (rows), :1104-1131 (columns).  Reverse: :1078-1102, :1133-1160. */
+typedef struct {
+    float* cost; orc_short2* nnf; const orc_uchar4 *img1, *img2; const uint8_t *c1, *c2;
+    int w, h, R; const float *gs, *cn;
+} pm_ctx;
+
+static inline size_t pix_index(const pm_ctx* c, int is_row, int line, int along)
+{
+    return is_row ? (size_t)line * c->w + along : (size_t)along * c->w + line;
+}
+
+static void seg_walk(const pm_ctx* c, int is_row, int reverse, int line, int seg, int L, orc_short2 prev)
+{
+    const int len = is_row ? c->w : c->h;     /* extent along the sweep */
+    int start, end;
+    if (!reverse) {
+        start = (seg == 0) ? 0 : seg * L - 1;
+        end = imin(len - 1, start + L);
+        for (int i = start + 1; i <= end; i++) {
+            size_t idx = pix_index(c, is_row, line, i);
+            float cur_best = c->cost[idx];
+            if (is_row) prev.x = (int16_t)imin(prev.x + 1, c->w - 1);
+            else        prev.y = (int16_t)imin(prev.y + 1, c->h - 1);
+            int px = is_row ? i : line, py = is_row ? line : i;
+            float cv = orc_patch_dist(c->img1, c->img2, c->c1, c->c2, c->w, c->h, c->R, c->gs, c->cn, px, py, prev.x, prev.y);
+            if (cv < cur_best) { c->nnf[idx] = prev; c->cost[idx] = cv; }
+            else prev = c->nnf[idx];
+        }
+    } else {
+        start = (seg + 1) * L;
+        if (start >= len) start = len - 1;
+        end = seg * L;
+        for (int i = start - 1; i >= end; i--) {
+            size_t idx = pix_index(c, is_row, line, i);
+            float cur_best = c->cost[idx];
+            if (is_row) prev.x = (int16_t)imax(prev.x - 1, 0);
+            else        prev.y = (int16_t)imax(prev.y - 1, 0);
+            int px = is_row ? i : line, py = is_row ? line : i;
+            float cv = orc_patch_dist(c->img1, c->img2, c->c1, c->c2, c->w, c->h, c->R, c->gs, c->cn, px, py, prev.x, prev.y);
+            if (cv < cur_best) { c->nnf[idx] = prev; c->cost[idx] = cv; }
+            else prev = c->nnf[idx];
+        }
+    }
+}
+
+/* One of the four directional kernels of baoSegPropagate (:1167-1181), lockstep order:
+ * seeds are read before any walk writes; forward segments are replayed high to low so that
+ * segment 1's visit of pixel L precedes segment 0's; reverse segments low to high (their
+ * ranges are disjoint and each seed lies in the NEXT segment's range). */
+void orc_seg_propagate_dir(float* cost, orc_short2* nnf, const orc_uchar4* img1, const orc_uchar4* img2,
+                           const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p, int dir)
+{
+    float gs[64], cn[9];
+    orc_pm_luts(p->patch_r, gs, cn);
+    init_unorm();
+    pm_ctx c = {cost, nnf, img1, img2, c1, c2, w, h, p->patch_r, gs, cn};
+    const int is_row = (dir == 0 || dir == 2), reverse = (dir >= 2), L = p->seg_len;
+    const int len = is_row ? w : h, lines = is_row ? h : w;
+    const int nseg = (len + L - 1) / L;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int line = 0; line < lines; line++) {
+        orc_short2* seeds = (orc_short2*)malloc(sizeof(orc_short2) * nseg);
+        for (int s = 0; s < nseg; s++) {
+            int start;
+            if (!reverse) start = (s == 0) ? 0 : s * L - 1;
+            else { start = (s + 1) * L; if (start >= len) start = len - 1; }
+            seeds[s] = nnf[pix_index(&c, is_row, line, start)];
+        }
+        if (!reverse) for (int s = nseg - 1; s >= 0; s--) seg_walk(&c, is_row, 0, line, s, L, seeds[s]);
+        else          for (int s = 0; s < nseg; s++)      seg_walk(&c, is_row, 1, line, s, L, seeds[s]);
+        free(seeds);
+    }
+}
+
+/* :1519-1586 */
+void orc_random_search(orc_xorwow* states, float* cost, orc_short2* nnf, const orc_uchar4* img1, const orc_uchar4* img2,
+                       const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p)
+{
+    float gs[64], cn[9];
+    orc_pm_luts(p->patch_r, gs, cn);
+    init_unorm();
+    const int gx = (w + BLOCK_DIM - 1) / BLOCK_DIM, gy = (h + BLOCK_DIM - 1) / BLOCK_DIM;
+    const int G = p->num_guess;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int block_id = 0; block_id < gx * gy; block_id++) {
+        const int by = block_id / gx, bx = block_id % gx;
+        orc_xorwow st = states[block_id];
+        /* thread (0,0) fills the 16x16 table once per guess, :1540-1554 */
+        int16_t (*sr)[BLOCK_DIM * BLOCK_DIM][2] = malloc(sizeof(int16_t) * G * BLOCK_DIM * BLOCK_DIM * 2);
+        for (int k = 0; k < G; k++)
+            for (int t = 0; t < BLOCK_DIM * BLOCK_DIM; t++) {
+                uint32_t r1 = orc_xorwow_next(&st);
+                uint32_t r2 = orc_xorwow_next(&st);
+                sr[k][t][0] = (int16_t)r1;
+                sr[k][t][1] = (int16_t)r2;
+            }
+        states[block_id] = st;                                                  /* :1567 */
+        for (int i = 0; i < BLOCK_DIM; i++)
+            for (int j = 0; j < BLOCK_DIM; j++) {
+                const int x = bx * BLOCK_DIM + j, y = by * BLOCK_DIM + i;
+                if (x >= w || y >= h) continue;
+                const size_t idx = (size_t)y * w + x;
+                orc_short2 best = nnf[idx];
+                float best_cost = cost[idx];
+                orc_short2 guess[16];
+                int mag = p->search_range;
+                for (int k = 0; k < G; k++) {
+                    uint32_t rdn1 = (uint32_t)(int32_t)sr[k][i * BLOCK_DIM + j][0];   /* short -> unsigned int, :1558-1559 */
+                    uint32_t rdn2 = (uint32_t)(int32_t)sr[k][i * BLOCK_DIM + j][1];
+                    int16_t xmin = (int16_t)imax(best.x - mag, 0), xmax = (int16_t)imin(best.x + mag + 1, w + 1);
+                    int16_t ymin = (int16_t)imax(best.y - mag, 0), ymax = (int16_t)imin(best.y + mag + 1, h + 1);
+                    guess[k].x = (int16_t)((uint32_t)(int32_t)xmin + rdn1 % (uint32_t)(xmax - xmin));
+                    guess[k].y = (int16_t)((uint32_t)(int32_t)ymin + rdn2 % (uint32_t)(ymax - ymin));
+                    if (mag / 2 >= 1 /* SEARCH_RADIUS_MIN */) mag /= 2;
+                }
+                for (int k = 0; k < G; k++) {
+                    float cv = orc_patch_dist(img1, img2, c1, c2, w, h, p->patch_r, gs, cn, x, y, guess[k].x, guess[k].y);
+                    if (cv < best_cost) { best = guess[k]; best_cost = cv; }
+                }
+                nnf[idx] = best;
+                cost[idx] = best_cost;
+            }
+        free(sr);
+    }
+}
+
+/* :1760-1826 */
+void orc_patchmatch(orc_short2* nnf, float* cost, const orc_uchar4* img1, const orc_uchar4* img2,
+                    const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p, int iters_done)
+{
+    const int gx = (w + BLOCK_DIM - 1) / BLOCK_DIM, gy = (h + BLOCK_DIM - 1) / BLOCK_DIM;
+    orc_xorwow* states = (orc_xorwow*)malloc(sizeof(orc_xorwow) * gx * gy);
+    orc_gen_rand_field(states, nnf, w, h, p->seed);
+    orc_cost_field(cost, nnf, img1, img2, c1, c2, w, h, p);
+    const int iters = (iters_done < 0) ? p->num_iter : iters_done;
+    for (int it = 0; it < iters; it++) {
+        for (int dir = 0; dir < 4; dir++) orc_seg_propagate_dir(cost, nnf, img1, img2, c1, c2, w, h, p, dir);
+        orc_random_search(states, cost, nnf, img1, img2, c1, c2, w, h, p);
+    }
+    free(states);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * level-2 post-processing
+ * ---------------------------------------------------------------------------------------- */
+static void lr_pass(orc_short2* nnf, float* cost, const orc_short2* nnf2, int w, int h)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            size_t idx = (size_t)y * w + x;
+            orc_short2 d = nnf[idx];
+            int bad;
+            if (d.y < 0 || d.y >= h || d.x < 0 || d.x >= w) bad = 1;
+            else {
+                orc_short2 d2 = nnf2[(size_t)d.y * w + d.x];
+                bad = (abs(d2.x - x) > DIFF_THRESH || abs(d2.y - y) > DIFF_THRESH);
+            }
+            if (bad) { nnf[idx].x = INVALID_LOCATION; nnf[idx].y = INVALID_LOCATION; cost[idx] = FLT_MAX; }
+        }
+}
+/* refine :53-92: two launches; the second sees the first one's invalid marks */
+void orc_left_right_check(orc_short2* nnf1, float* cost1, orc_short2* nnf2, float* cost2, int w, int h)
+{
+    lr_pass(nnf1, cost1, nnf2, w, h);
+    lr_pass(nnf2, cost2, nnf1, w, h);
+}
+
+/* refine :149-193 (Jacobi) */
+void orc_outlier_removal(orc_short2* nnf, float* cost, int w, int h)
+{
+    orc_short2* in = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
+    memcpy(in, nnf, sizeof(orc_short2) * w * h);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            orc_short2 cur = in[(size_t)y * w + x];
+            if (cur.x < 0 && cur.y < 0) continue;
+            cur.x = (int16_t)(cur.x - x); cur.y = (int16_t)(cur.y - y);
+            int count = 0;
+            for (int dy = -STAT_RADIUS; dy <= STAT_RADIUS; dy++)
+                for (int dx = -STAT_RADIUS; dx <= STAT_RADIUS; dx++) {
+                    int cy = y + dy, cx = x + dx;
+                    if (cx < 0 || cy < 0 || cx >= w || cy >= h) continue;
+                    orc_short2 nb = in[(size_t)cy * w + cx];
+                    nb.x = (int16_t)(nb.x - cx); nb.y = (int16_t)(nb.y - cy);
+                    if (abs(nb.x - cur.x) <= STAT_SIM_THRESH && abs(nb.y - cur.y) <= STAT_SIM_THRESH) count++;
+                }
+            if (count < STAT_COUNT_THRESH) {
+                nnf[(size_t)y * w + x].x = INVALID_LOCATION; nnf[(size_t)y * w + x].y = INVALID_LOCATION;
+                cost[(size_t)y * w + x] = FLT_MAX;
+            }
+        }
+    free(in);
+}
+
+/* refine :198-204 */
+static inline float wmf_weight(rgbf a, rgbf b, int dx, int dy, const float* g)
+{
+    float delta_r = max_abs_diff(a, b);
+    float coef_r = orc_fast_exp(-(delta_r * delta_r) / (WMF_SIG_R * WMF_SIG_R));
+    float coef_s = g[dx] * g[dy];
+    return coef_r * coef_s;
+}
+/* refine :206-286 (Jacobi per launch) */
+void orc_weighted_median(orc_short2* nnf, const orc_uchar4* img, int w, int h, int num_iter, int only_occ)
+{
+    float g[WMF_RADIUS + 1];
+    orc_wmf_lut(g);
+    init_unorm();
+    orc_short2* in = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
+    for (int it = 0; it < num_iter; it++) {
+        memcpy(in, nnf, sizeof(orc_short2) * w * h);
+#pragma omp parallel for schedule(dynamic, 2)
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                orc_short2 out = in[(size_t)y * w + x];
+                if (only_occ && out.x >= 0 && out.y >= 0) continue;
+                rgbf center = tex_rgb(img, w, h, x, y);
+                float minCostSum = FLT_MAX;
+                for (int dy = -WMF_RADIUS; dy <= WMF_RADIUS; dy++)
+                    for (int dx = -WMF_RADIUS; dx <= WMF_RADIUS; dx++) {
+                        int cy = y + dy, cx = x + dx;
+                        if (cx < 0 || cy < 0 || cx >= w || cy >= h) continue;
+                        orc_short2 cand = in[(size_t)cy * w + cx];
+                        if (cand.x < 0 || cand.y < 0) continue;
+                        cand.x = (int16_t)(cand.x - cx); cand.y = (int16_t)(cand.y - cy);
+                        float costSum = 0.0f, weightSum = 0.0f;
+                        for (int dy2 = -WMF_RADIUS; dy2 <= WMF_RADIUS; dy2++)
+                            for (int dx2 = -WMF_RADIUS; dx2 <= WMF_RADIUS; dx2++) {
+                                int cy2 = y + dy2, cx2 = x + dx2;
+                                if (cx2 < 0 || cy2 < 0 || cx2 >= w || cy2 >= h) continue;
+                                orc_short2 cur = in[(size_t)cy2 * w + cx2];
+                                if (cur.x < 0 || cur.y < 0) continue;
+                                cur.x = (int16_t)(cur.x - cx2); cur.y = (int16_t)(cur.y - cy2);
+                                rgbf pix = tex_rgb(img, w, h, cx2, cy2);
+                                float wgt = wmf_weight(center, pix, abs(dx2), abs(dy2), g);
+                                costSum += wgt * imax(abs(cand.x - cur.x), abs(cand.y - cur.y));
+                                weightSum += wgt;
+                            }
+                        if (weightSum > 0.0f && costSum < minCostSum) {
+                            minCostSum = costSum;
+                            out.x = (int16_t)(cand.x + x);
+                            out.y = (int16_t)(cand.y + y);
+                        }
+                    }
+                if (out.x < 0 || out.y < 0) continue;
+                nnf[(size_t)y * w + x] = out;
+            }
+    }
+    free(in);
+}
+
+/* refine :297-371 (Jacobi) */
+void orc_fill_holes(orc_short2* nnf, const orc_uchar4* img, int w, int h)
+{
+    init_unorm();
+    orc_short2* in = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
+    memcpy(in, nnf, sizeof(orc_short2) * w * h);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            orc_short2 cur = in[(size_t)y * w + x];
+            if (cur.x >= 0 && cur.y >= 0) continue;
+            orc_short2 nd[4] = {cur, cur, cur, cur};
+            int nx[4] = {x, x, x, x}, ny[4] = {y, y, y, y};
+            for (int cx = x - 1; cx >= 0; cx--) { nd[0] = in[(size_t)y * w + cx]; if (nd[0].x >= 0 && nd[0].y >= 0) { nx[0] = cx; ny[0] = y; break; } }
+            for (int cx = x + 1; cx < w; cx++)  { nd[1] = in[(size_t)y * w + cx]; if (nd[1].x >= 0 && nd[1].y >= 0) { nx[1] = cx; ny[1] = y; break; } }
+            for (int cy = y - 1; cy >= 0; cy--) { nd[2] = in[(size_t)cy * w + x]; if (nd[2].x >= 0 && nd[2].y >= 0) { nx[2] = x; ny[2] = cy; break; } }
+            for (int cy = y + 1; cy < h; cy++)  { nd[3] = in[(size_t)cy * w + x]; if (nd[3].x >= 0 && nd[3].y >= 0) { nx[3] = x; ny[3] = cy; break; } }
+            rgbf curPix = tex_rgb(img, w, h, x, y);
+            float minPixDiff = FLT_MAX;
+            for (int i = 0; i < 4; i++) {
+                rgbf np = tex_rgb(img, w, h, nx[i], ny[i]);
+                float pd = max_abs_diff(curPix, np);
+                if (pd < minPixDiff && nd[i].x >= 0 && nd[i].y >= 0) {
+                    minPixDiff = pd;
+                    cur.x = (int16_t)(nd[i].x - nx[i]);
+                    cur.y = (int16_t)(nd[i].y - ny[i]);
+                }
+            }
+            cur.x = (int16_t)(cur.x + x);
+            cur.y = (int16_t)(cur.y + y);
+            nnf[(size_t)y * w + x] = cur;
+        }
+    free(in);
+}
+
+/* refine :636-655 */
+void orc_nnf2flow(orc_float2* flow, const orc_short2* nnf, int w, int h)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            orc_short2 d = nnf[(size_t)y * w + x];
+            orc_float2 f;
+            if (d.x <= INVALID_LOCATION || d.y <= INVALID_LOCATION) { f.x = (float)UNKNOWN_FLOW; f.y = (float)UNKNOWN_FLOW; }
+            else { f.x = (float)(d.x - x); f.y = (float)(d.y - y); }
+            flow[(size_t)y * w + x] = f;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * coarse to fine
+ * ---------------------------------------------------------------------------------------- */
+/* basic/bao_basic_cuda.cuh:511-537 */
+void orc_resize_flow(orc_float2* out, int outH, int outW, const orc_float2* in, int h, int w, float ratio)
+{
+    const float div_scale = 1.f / ratio;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < outH; y++)
+        for (int x = 0; x < outW; x++) {
+            float fx = (float)(x + 1) * div_scale - 1;
+            float fy = (float)(y + 1) * div_scale - 1;
+            int xx = (int)fx, yy = (int)fy;
+            float dx = fmax2(fminf(fx - xx, 1), 0);
+            float dy = fmax2(fminf(fy - yy, 1), 0);
+            float rx = 0, ry = 0;
+            for (int m = 0; m <= 1; m++)
+                for (int n = 0; n <= 1; n++) {
+                    int u = imax(0, imin(w - 1, xx + m));
+                    int v = imax(0, imin(h - 1, yy + n));
+                    float s = fabsf(1 - m - dx) * fabsf(1 - n - dy);
+                    orc_float2 t = in[(size_t)v * w + u];
+                    rx += t.x * s; ry += t.y * s;
+                }
+            out[(size_t)y * outW + x].x = rx;
+            out[(size_t)y * outW + x].y = ry;
+        }
+}
+
+/* basic/bao_basic_cuda.cuh:135-142 */
+void orc_mul_scalar(orc_float2* f, float s, int h, int w)
+{
+    for (size_t i = 0; i < (size_t)h * w; i++) { f[i].x = f[i].x * s; f[i].y = f[i].y * s; }
+}
+
+/* float -> short as cvt.rzi.s16.f32 (truncate, saturate) */
+static inline int16_t f2short(float f)
+{
+    if (!(f > -32768.0f)) return (int16_t)-32768;   /* also NaN -> 0 in PTX; NaN never occurs here */
+    if (f > 32767.0f) return (int16_t)32767;
+    return (int16_t)(int)f;
+}
+
+/* bao_pmflow_kernel.cu:2005-2041 */
+void orc_c2f_refine(orc_float2* flow, const orc_uchar4* img1, const orc_uchar4* img2, const uint8_t* c1, const uint8_t* c2,
+                    int w, int h, const orc_params* p)
+{
+    float gs[64], cn[9];
+    orc_pm_luts(p->patch_r, gs, cn);   /* LUTs left in constant memory by baoComputeCostField */
+    init_unorm();
+#pragma omp parallel for schedule(dynamic, 2)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            orc_float2 fv = flow[(size_t)y * w + x];
+            if (fv.x > UNKNOWN_FLOW_THRESH || fv.y > UNKNOWN_FLOW_THRESH) {
+                flow[(size_t)y * w + x].x = 0; flow[(size_t)y * w + x].y = 0;
+                continue;
+            }
+            int16_t cxs[3], cys[3];
+            cxs[1] = (int16_t)(f2short(fv.x) + x);
+            cys[1] = (int16_t)(f2short(fv.y) + y);
+            cxs[0] = (int16_t)(cxs[1] - 1); cys[0] = (int16_t)(cys[1] - 1);
+            cxs[2] = (int16_t)(cxs[1] + 1); cys[2] = (int16_t)(cys[1] + 1);
+            int bx = cxs[1], by = cys[1];
+            float min_cost = 999999;
+            for (int m = 0; m < 3; m++)
+                for (int n = 0; n < 3; n++) {
+                    if (cxs[m] < 0 || cys[n] < 0 || cxs[m] >= w || cys[n] >= h) continue;
+                    float cv = orc_patch_dist_planefit(img1, img2, c1, c2, w, h, p->patch_r, gs, cn, x, y, cxs[m], cys[n]);
+                    if (cv < min_cost) { min_cost = cv; bx = cxs[m]; by = cys[n]; }
+                }
+            flow[(size_t)y * w + x].x = (float)(bx - x);
+            flow[(size_t)y * w + x].y = (float)(by - y);
+        }
+}
+
+/* refine :756-799 (Jacobi) */
+void orc_flow_smoothing(orc_float2* flow, const orc_uchar4* img, int w, int h)
+{
+    float g[POSTPROC_BLF_RADIUS + 1];
+    orc_blf_lut(g);
+    init_unorm();
+    orc_float2* in = (orc_float2*)malloc(sizeof(orc_float2) * w * h);
+    memcpy(in, flow, sizeof(orc_float2) * w * h);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            rgbf center = tex_rgb(img, w, h, x, y);
+            float nx = 0.f, ny = 0.f, wsum = 0.f;
+            for (int dy = -POSTPROC_BLF_RADIUS; dy <= POSTPROC_BLF_RADIUS; dy++)
+                for (int dx = -POSTPROC_BLF_RADIUS; dx <= POSTPROC_BLF_RADIUS; dx++) {
+                    int cy = y + dy, cx = x + dx;
+                    if (cx < 0 || cy < 0 || cx >= w || cy >= h) continue;
+                    orc_float2 cf = in[(size_t)cy * w + cx];
+                    if (cf.x > UNKNOWN_FLOW_THRESH || cf.y > UNKNOWN_FLOW_THRESH) continue;
+                    rgbf pix = tex_rgb(img, w, h, cx, cy);
+                    float delta_r = max_abs_diff(center, pix);
+                    float coef_r = orc_fast_exp(-(delta_r * delta_r) / (POSTPROC_BLF_SIG_R * POSTPROC_BLF_SIG_R));
+                    float coef_s = g[abs(dx)] * g[abs(dy)];
+                    float wgt = coef_r * coef_s;
+                    nx += wgt * cf.x; ny += wgt * cf.y; wsum += wgt;
+                }
+            if (wsum != 0) {
+                flow[(size_t)y * w + x].x = nx / wsum;
+                flow[(size_t)y * w + x].y = ny / wsum;
+            }
+        }
+    free(in);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * the whole path: bao_flow_patchmatch_multiscale_cuda.cpp:159-168 (set_data) + :217-306
+ * ---------------------------------------------------------------------------------------- */
+void orc_free_dump(orc_dump* d)
+{
+    for (int i = 0; i < 8; i++) {
+        free(d->img1[i]); free(d->img2[i]); free(d->cen1[i]); free(d->cen2[i]); free(d->flow[i]); free(d->flow_c2f[i]);
+    }
+    free(d->nnf1_pm); free(d->nnf2_pm); free(d->cost1_pm); free(d->cost2_pm);
+    free(d->nnf1_lr); free(d->nnf1_out); free(d->nnf1_wmf); free(d->nnf1_fill);
+    memset(d, 0, sizeof(*d));
+}
+
+static void* dup_mem(const void* p, size_t n) { void* q = malloc(n); memcpy(q, p, n); return q; }
+
+int orc_compute_flow(const uint8_t* rgb1, const uint8_t* rgb2, int h, int w, const orc_params* p,
+                     float* u, float* v, orc_dump* dump)
+{
+    const int NL = 3;                                  /* PYR_MAX_DEPTH, defs.h:31 */
+    int arrH[8], arrW[8];
+    orc_pyr_init_dim(arrH, arrW, h, w, NL, PYR_RATIO); /* driver :116 */
+    orc_uchar4 *raw1 = malloc(sizeof(orc_uchar4) * h * w), *raw2 = malloc(sizeof(orc_uchar4) * h * w);
+    orc_rgb2rgba(raw1, rgb1, h, w);                    /* driver :161-162 */
+    orc_rgb2rgba(raw2, rgb2, h, w);
+    orc_uchar4 *img1[8] = {0}, *img2[8] = {0};
+    uint8_t *cen1[8] = {0}, *cen2[8] = {0};
+    orc_float2* flow[8] = {0};
+    for (int i = 0; i < NL; i++) {
+        size_t n = (size_t)arrH[i] * arrW[i];
+        img1[i] = malloc(sizeof(orc_uchar4) * n); img2[i] = malloc(sizeof(orc_uchar4) * n);
+        cen1[i] = malloc(n); cen2[i] = malloc(n);
+        flow[i] = malloc(sizeof(orc_float2) * n);
+    }
+    orc_prepare(img1, cen1, raw1, arrH, arrW, NL);     /* driver :212-215 */
+    orc_prepare(img2, cen2, raw2, arrH, arrW, NL);
+    free(raw1); free(raw2);
+    if (dump) {
+        memset(dump, 0, sizeof(*dump));
+        dump->n_levels = NL;
+        for (int i = 0; i < NL; i++) {
+            size_t n = (size_t)arrH[i] * arrW[i];
+            dump->arrH[i] = arrH[i]; dump->arrW[i] = arrW[i];
+            dump->img1[i] = dup_mem(img1[i], sizeof(orc_uchar4) * n); dump->img2[i] = dup_mem(img2[i], sizeof(orc_uchar4) * n);
+            dump->cen1[i] = dup_mem(cen1[i], n); dump->cen2[i] = dup_mem(cen2[i], n);
+        }
+    }
+
+    const int L = NL - 1;                              /* pm_layer, driver :219 */
+    const int lw = arrW[L], lh = arrH[L];
+    const size_t ln = (size_t)lw * lh;
+    orc_short2 *nnf1 = malloc(sizeof(orc_short2) * ln), *nnf2 = malloc(sizeof(orc_short2) * ln);
+    float *cost1 = malloc(sizeof(float) * ln), *cost2 = malloc(sizeof(float) * ln);
+    orc_patchmatch(nnf1, cost1, img1[L], img2[L], cen1[L], cen2[L], lw, lh, p, -1);   /* driver :223 */
+    orc_patchmatch(nnf2, cost2, img2[L], img1[L], cen2[L], cen1[L], lw, lh, p, -1);   /* driver :224 */
+    if (dump) {
+        dump->nnf1_pm = dup_mem(nnf1, sizeof(orc_short2) * ln); dump->nnf2_pm = dup_mem(nnf2, sizeof(orc_short2) * ln);
+        dump->cost1_pm = dup_mem(cost1, sizeof(float) * ln); dump->cost2_pm = dup_mem(cost2, sizeof(float) * ln);
+    }
+    orc_left_right_check(nnf1, cost1, nnf2, cost2, lw, lh);                            /* driver :233 */
+    if (dump) dump->nnf1_lr = dup_mem(nnf1, sizeof(orc_short2) * ln);
+    orc_outlier_removal(nnf1, cost1, lw, lh);                                          /* driver :237 */
+    if (dump) dump->nnf1_out = dup_mem(nnf1, sizeof(orc_short2) * ln);
+    orc_weighted_median(nnf1, img1[L], lw, lh, p->wmf_iters, 1);                       /* driver :239 */
+    if (dump) dump->nnf1_wmf = dup_mem(nnf1, sizeof(orc_short2) * ln);
+    orc_fill_holes(nnf1, img1[L], lw, lh);                                             /* driver :240 */
+    if (dump) dump->nnf1_fill = dup_mem(nnf1, sizeof(orc_short2) * ln);
+    orc_nnf2flow(flow[L], nnf1, lw, lh);                                               /* driver :258 */
+    if (dump) dump->flow[L] = dup_mem(flow[L], sizeof(orc_float2) * ln);
+
+    for (int l = L - 1; l >= 0; l--) {                                                 /* driver :275-282 */
+        /* baoCudaBLF_C2F, refine :1076-1087 */
+        orc_resize_flow(flow[l], arrH[l], arrW[l], flow[l + 1], arrH[l + 1], arrW[l + 1], 1.f / PYR_RATIO);
+        orc_mul_scalar(flow[l], 2.0f, arrH[l], arrW[l]);
+        orc_c2f_refine(flow[l], img1[l], img2[l], cen1[l], cen2[l], arrW[l], arrH[l], p);
+        if (dump) dump->flow_c2f[l] = dup_mem(flow[l], sizeof(orc_float2) * arrH[l] * arrW[l]);
+        orc_flow_smoothing(flow[l], img1[l], arrW[l], arrH[l]);                        /* driver :280 */
+        if (dump && l > 0) dump->flow[l] = dup_mem(flow[l], sizeof(orc_float2) * arrH[l] * arrW[l]);
+        /* driver :281: WMF on m_disp_vec1_pyramid[l] is dead work, no effect on the flow */
+    }
+    orc_flow_smoothing(flow[0], img1[0], arrW[0], arrH[0]);                            /* driver :289 */
+    if (dump) dump->flow[0] = dup_mem(flow[0], sizeof(orc_float2) * h * w);
+    for (size_t i = 0; i < (size_t)h * w; i++) { u[i] = flow[0][i].x; v[i] = flow[0][i].y; }  /* driver :302-306 */
+
+    free(nnf1); free(nnf2); free(cost1); free(cost2);
+    for (int i = 0; i < NL; i++) { free(img1[i]); free(img2[i]); free(cen1[i]); free(cen2[i]); free(flow[i]); }
+    return 0;
+}

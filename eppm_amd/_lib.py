@@ -1,0 +1,57 @@
+"""ctypes binding of the C ABI declared in include/eppm.h.  Fails loudly if the library is missing."""
+import ctypes as C
+import os
+
+from .build import lib_path
+
+
+class EppmError(RuntimeError):
+    pass
+
+
+class CParams(C.Structure):
+    _fields_ = [("patch_r", C.c_int), ("num_iter", C.c_int), ("search_range", C.c_int), ("num_guess", C.c_int),
+                ("seg_len", C.c_int), ("wmf_iters", C.c_int), ("seed", C.c_ulonglong)]
+
+
+_lib = None
+
+# every symbol include/eppm.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "eppm_default_params", "eppm_create", "eppm_destroy", "eppm_set_stream", "eppm_set_images", "eppm_set_images_device",
+    "eppm_compute", "eppm_compute_device", "eppm_synchronize", "eppm_num_levels", "eppm_level_dims", "eppm_get_plane",
+    "eppm_stage_times", "eppm_enable_stage_timing", "eppm_last_error", "eppm_version",
+    "eppm_device_count", "eppm_set_device", "eppm_malloc_device", "eppm_malloc_pitched", "eppm_free_device",
+    "eppm_memcpy_h2d", "eppm_memcpy_d2h", "eppm_memcpy2d_h2d", "eppm_memcpy2d_d2h", "eppm_memset_device",
+    "eppm_device_synchronize", "eppm_set_launcher_stream", "eppm_set_launcher_params", "eppm_launcher_status",
+    "baoCudaPatchMatchMultiscalePrepare", "baoCudaCensusTransform", "baoCudaPatchMatch", "baoCudaLeftRightCheck",
+    "baoCudaOutlierRemoval", "baoCudaWeightedMedianFilter", "baoCudaFillHole", "baoCudaNNF2Flow", "baoCudaBLF_C2F",
+    "baoCudaBLFCostFilterRefine", "baoCudaFlowSmoothing",
+    "eppm_pm_rng_create", "eppm_pm_rng_reset", "eppm_pm_rng_destroy", "eppm_pm_rng_block_states", "eppm_pm_gen_rand_field",
+    "eppm_pm_cost_field", "eppm_pm_seg_propagate", "eppm_pm_random_search", "eppm_gauss_filter_rgba", "eppm_resize_rgba",
+    "eppm_resize_flow", "eppm_probe_fast_exp", "eppm_probe_div_const",
+    "eppm_load_ppm", "eppm_ppm_size", "eppm_save_flo", "eppm_load_flo", "eppm_flo_size", "eppm_flow_error",
+]
+
+
+def lib():
+    """Load libeppm_hip.so.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise EppmError(f"{path} is missing: run eppm_amd.build() (hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(path)
+        L.eppm_last_error.restype = C.c_char_p
+        L.eppm_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        raise EppmError(f"{what}: status {status}: {lib().eppm_last_error().decode()}")
+
+
+def check_launcher(what=""):
+    check(lib().eppm_launcher_status(), what)

@@ -1,0 +1,135 @@
+"""Host-side mirror of ``class bao_flow_patchmatch_multiscale_cuda`` over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import CParams, EppmError, check, lib
+
+uchar4 = np.dtype([("x", "u1"), ("y", "u1"), ("z", "u1"), ("w", "u1")])
+short2 = np.dtype([("x", "i2"), ("y", "i2")])
+float2 = np.dtype([("x", "f4"), ("y", "f4")])
+
+_PLANE_DTYPES = {"img1": uchar4, "img2": uchar4, "census1": np.uint8, "census2": np.uint8, "nnf1": short2,
+                 "nnf2": short2, "cost1": np.float32, "cost2": np.float32, "flow": float2}
+
+
+def Params(**kw):
+    """Tunables with the defaults of defs.h:31-76 (patch_r, num_iter, search_range, num_guess, seg_len, wmf_iters, seed)."""
+    p = CParams()
+    check(lib().eppm_default_params(C.byref(p)), "eppm_default_params")
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError(f"unknown parameter {k}")
+        setattr(p, k, v)
+    return p
+
+
+class EPPM:
+    """``init`` / ``set_data`` / ``compute_flow`` as in bao_flow_patchmatch_multiscale_cuda.h:36-44.
+
+    Images are (h, w, 3) uint8 arrays in R,G,B order (the reference's ``unsigned char***``);
+    flows are (h, w) float32 arrays (``float**``).
+    """
+
+    def __init__(self, device=0, params=None):
+        self._ctx = C.c_void_p()
+        self._device = device
+        self._params = params
+        self.h = self.w = 0
+
+    # -- reference interface ---------------------------------------------------------------
+    def init(self, *args):
+        """init(h, w)  or  init(img1, img2, h, w)   (driver .cpp:106-157)"""
+        if len(args) == 4:
+            img1, img2, h, w = args
+            self.init(h, w)
+            self.set_data(img1, img2)
+            return
+        h, w = args
+        self.close()
+        ctx = C.c_void_p()
+        check(lib().eppm_create(C.byref(ctx), int(h), int(w), int(self._device),
+                                C.byref(self._params) if self._params is not None else None), "eppm_create")
+        self._ctx, self.h, self.w = ctx, int(h), int(w)
+
+    def set_data(self, img1, img2):
+        """RGB->RGBA, H2D, prefilter, pyramid, census (driver .cpp:159-168).  Returns True like the reference."""
+        self._need()
+        a = np.ascontiguousarray(img1, np.uint8)
+        b = np.ascontiguousarray(img2, np.uint8)
+        if a.shape != (self.h, self.w, 3) or b.shape != (self.h, self.w, 3):
+            raise EppmError(f"set_data: images must be ({self.h},{self.w},3) uint8")
+        check(lib().eppm_set_images(self._ctx, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                    C.c_size_t(self.w * 3)), "eppm_set_images")
+        return True
+
+    def compute_flow(self):
+        """Returns (disp1_x, disp1_y) (driver .cpp:217-306)."""
+        self._need()
+        u = np.empty((self.h, self.w), np.float32)
+        v = np.empty((self.h, self.w), np.float32)
+        check(lib().eppm_compute(self._ctx, u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "eppm_compute")
+        return u, v
+
+    # -- device-resident variants (no PCIe in the timed region) ----------------------------
+    def set_data_device(self, d_rgba1, d_rgba2, pitch):
+        self._need()
+        check(lib().eppm_set_images_device(self._ctx, C.c_void_p(d_rgba1), C.c_void_p(d_rgba2), C.c_size_t(pitch)),
+              "eppm_set_images_device")
+
+    def compute_flow_device(self, d_flow=None):
+        self._need()
+        check(lib().eppm_compute_device(self._ctx, C.c_void_p(d_flow) if d_flow else None), "eppm_compute_device")
+
+    def synchronize(self):
+        self._need()
+        check(lib().eppm_synchronize(self._ctx), "eppm_synchronize")
+
+    def set_stream(self, hip_stream):
+        self._need()
+        check(lib().eppm_set_stream(self._ctx, C.c_void_p(hip_stream)), "eppm_set_stream")
+
+    # -- introspection ---------------------------------------------------------------------
+    def level_dims(self):
+        self._need()
+        out = []
+        for l in range(lib().eppm_num_levels(self._ctx)):
+            h, w = C.c_int(), C.c_int()
+            check(lib().eppm_level_dims(self._ctx, l, C.byref(h), C.byref(w)), "eppm_level_dims")
+            out.append((h.value, w.value))
+        return out
+
+    def plane(self, name, level):
+        self._need()
+        h, w = self.level_dims()[level]
+        a = np.empty((h, w), _PLANE_DTYPES[name])
+        check(lib().eppm_get_plane(self._ctx, name.encode(), level, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes)),
+              "eppm_get_plane")
+        return a
+
+    def enable_stage_timing(self, on=True):
+        self._need()
+        check(lib().eppm_enable_stage_timing(self._ctx, int(on)), "eppm_enable_stage_timing")
+
+    def stage_times(self):
+        """[(stage name, ms)] of the last set_data / compute_flow with timing enabled."""
+        self._need()
+        names = (C.c_char_p * 64)()
+        ms = (C.c_float * 64)()
+        n = lib().eppm_stage_times(self._ctx, names, ms, 64)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+    def close(self):
+        if self._ctx:
+            lib().eppm_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def _need(self):
+        if not self._ctx:
+            raise EppmError("EPPM: init(h, w) has not been called")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,122 @@
+// bao_class.cpp -- class bao_flow_patchmatch_multiscale_cuda on top of the C ABI
+// (reference: bao_flow_patchmatch_multiscale_cuda.cpp:66-168, :217-315).
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/bao_flow_patchmatch_multiscale_cuda.h"
+#include "../../include/eppm.h"
+
+bao_flow_patchmatch_multiscale_cuda::bao_flow_patchmatch_multiscale_cuda()
+    : m_h(0), m_w(0), m_device(0), m_ctx(NULL), m_stage(NULL), m_u(NULL), m_v(NULL)
+{
+}
+
+bao_flow_patchmatch_multiscale_cuda::~bao_flow_patchmatch_multiscale_cuda() { _destroy(); }
+
+void bao_flow_patchmatch_multiscale_cuda::_destroy()
+{
+    if (m_ctx) eppm_destroy(m_ctx);
+    m_ctx = NULL;
+    free(m_stage); free(m_u); free(m_v);
+    m_stage = NULL; m_u = NULL; m_v = NULL;
+}
+
+// driver .cpp:106-110
+void bao_flow_patchmatch_multiscale_cuda::init(unsigned char*** img1, unsigned char*** img2, int h, int w)
+{
+    init(h, w);
+    set_data(img1, img2);
+}
+
+// driver .cpp:112-157
+void bao_flow_patchmatch_multiscale_cuda::init(int h, int w)
+{
+    _destroy();
+    m_h = h; m_w = w;
+    if (eppm_create(&m_ctx, h, w, m_device, NULL) != EPPM_OK) {
+        fprintf(stderr, "bao_flow_patchmatch_multiscale_cuda::init: %s\n", eppm_last_error());
+        m_ctx = NULL;
+        return;
+    }
+    m_stage = (unsigned char*)malloc((size_t)h * w * 3 * 2);
+    m_u = (float*)malloc(sizeof(float) * h * w);
+    m_v = (float*)malloc(sizeof(float) * h * w);
+}
+
+// driver .cpp:159-168 (bao_rgb2rgba indexes through the row tables, bao_basic_cuda.h:258-267)
+bool bao_flow_patchmatch_multiscale_cuda::set_data(unsigned char*** img1, unsigned char*** img2)
+{
+    if (!m_ctx || !img1 || !img2) return false;
+    unsigned char* a = m_stage;
+    unsigned char* b = m_stage + (size_t)m_h * m_w * 3;
+    for (int i = 0; i < m_h; i++)
+        for (int j = 0; j < m_w; j++)
+            for (int c = 0; c < 3; c++) {
+                a[((size_t)i * m_w + j) * 3 + c] = img1[i][j][c];
+                b[((size_t)i * m_w + j) * 3 + c] = img2[i][j][c];
+            }
+    if (eppm_set_images(m_ctx, a, b, (size_t)m_w * 3) != EPPM_OK) {
+        fprintf(stderr, "bao_flow_patchmatch_multiscale_cuda::set_data: %s\n", eppm_last_error());
+        return false;
+    }
+    return true;
+}
+
+// Middlebury colour wheel (3rdparty/middlebury/colorcode.cpp:30-78, also basic/bao_basic_cuda.cuh:751-829)
+static int g_ncols = 0;
+static int g_wheel[60][3];
+static void setcols(int r, int g, int b, int k) { g_wheel[k][0] = r; g_wheel[k][1] = g; g_wheel[k][2] = b; }
+static void make_wheel()
+{
+    const int RY = 15, YG = 6, GC = 4, CB = 11, BM = 13, MR = 6;
+    int k = 0;
+    for (int i = 0; i < RY; i++) setcols(255, 255 * i / RY, 0, k++);
+    for (int i = 0; i < YG; i++) setcols(255 - 255 * i / YG, 255, 0, k++);
+    for (int i = 0; i < GC; i++) setcols(0, 255, 255 * i / GC, k++);
+    for (int i = 0; i < CB; i++) setcols(0, 255 - 255 * i / CB, 255, k++);
+    for (int i = 0; i < BM; i++) setcols(255 * i / BM, 0, 255, k++);
+    for (int i = 0; i < MR; i++) setcols(255, 0, 255 - 255 * i / MR, k++);
+    g_ncols = k;
+}
+static void flow_color(float fx, float fy, unsigned char* pix)
+{
+    if (g_ncols == 0) make_wheel();
+    const float rad = sqrtf(fx * fx + fy * fy);
+    const float a = atan2f(-fy, -fx) / (float)M_PI;
+    const float fk = (a + 1.0f) / 2.0f * (g_ncols - 1);
+    const int k0 = (int)fk, k1 = (k0 + 1) % g_ncols;
+    const float f = fk - k0;
+    for (int b = 0; b < 3; b++) {
+        const float col0 = g_wheel[k0][b] / 255.0f, col1 = g_wheel[k1][b] / 255.0f;
+        float col = (1 - f) * col0 + f * col1;
+        if (rad <= 1) col = 1 - rad * (1 - col);
+        else col *= .75f;
+        pix[b] = (unsigned char)(255.0f * col);
+    }
+}
+
+// driver .cpp:217-315
+void bao_flow_patchmatch_multiscale_cuda::compute_flow(float** disp1_x, float** disp1_y, unsigned char*** color_flow)
+{
+    if (!m_ctx || !disp1_x || !disp1_y) return;
+    if (eppm_compute(m_ctx, m_u, m_v) != EPPM_OK) {
+        fprintf(stderr, "bao_flow_patchmatch_multiscale_cuda::compute_flow: %s\n", eppm_last_error());
+        return;
+    }
+    for (int i = 0; i < m_h; i++)
+        for (int j = 0; j < m_w; j++) {
+            disp1_x[i][j] = m_u[(size_t)i * m_w + j];
+            disp1_y[i][j] = m_v[(size_t)i * m_w + j];
+        }
+    if (color_flow != NULL) {
+        // bao_cuda_convert_flow_to_colorshow(d_colorflow, flow, h, w, 20, 20), driver .cpp:311: flow normalised by (20,20)
+        for (int i = 0; i < m_h; i++)
+            for (int j = 0; j < m_w; j++) {
+                float fx = m_u[(size_t)i * m_w + j], fy = m_v[(size_t)i * m_w + j];
+                if (fabsf(fx) > 1e9f || fabsf(fy) > 1e9f) { color_flow[i][j][0] = color_flow[i][j][1] = color_flow[i][j][2] = 0; continue; }
+                flow_color(fx / 20.0f, fy / 20.0f, color_flow[i][j]);
+            }
+    }
+}

@@ -1,0 +1,895 @@
+// eppm_api.cpp -- the C ABI of libeppm_hip.so (include/eppm.h): context + host pyramid driver, the
+// reference-signature stage launchers, and device-memory plumbing.
+//
+// The driver follows bao_flow_patchmatch_multiscale_cuda.cpp: init :112-157, set_data :159-168,
+// _prepare_data :212-215, compute_flow :217-306.  Dead work of the reference is not reproduced: the
+// level-1/0 weighted-median calls on never-initialised planes (driver :281), the debug D2H
+// of the level-2 flow (:265-270) and the per-call RNG cudaMalloc (kernel.cu:1767).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "eppm_internal.h"
+
+using namespace eppm;
+
+// ---------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return set_err(EPPM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(expr)                     \
+    do {                              \
+        int r_ = (expr);              \
+        if (r_ != EPPM_OK) return r_; \
+    } while (0)
+
+extern "C" const char* eppm_last_error(void) { return g_err; }
+extern "C" const char* eppm_version(void) { return "eppm-hip 0.1 (gfx950)"; }
+
+extern "C" int eppm_default_params(eppm_params* p)
+{
+    if (!p) return set_err(EPPM_ERR_ARG, "eppm_default_params: NULL");
+    p->patch_r = 9; p->num_iter = 10; p->search_range = 30; p->num_guess = 6;
+    p->seg_len = 10; p->wmf_iters = 20; p->seed = 1234ULL;
+    return EPPM_OK;
+}
+
+static int check_params(const eppm_params& p)
+{
+    if (p.patch_r < 1 || p.patch_r + 1 > kMaxS) return set_err(EPPM_ERR_ARG, "patch_r %d out of range [1,%d]", p.patch_r, kMaxS - 1);
+    if (p.num_iter < 0 || p.wmf_iters < 0) return set_err(EPPM_ERR_ARG, "negative iteration count");
+    if (p.num_guess < 1 || p.num_guess > 8) return set_err(EPPM_ERR_ARG, "num_guess %d out of range [1,8]", p.num_guess);
+    if (p.seg_len < 2) return set_err(EPPM_ERR_ARG, "seg_len %d < 2", p.seg_len);
+    if (p.search_range < 1) return set_err(EPPM_ERR_ARG, "search_range %d < 1", p.search_range);
+    return EPPM_OK;
+}
+
+// LUTs, host side (kernel.cu:670-687; refine :270-275, :811-816).  gs[0..R] then cn[0..8].
+static void host_pm_lut(int R, std::vector<float>& v)
+{
+    v.resize(R + 1 + 9);
+    const float sig_s = 0.5f * R;   // PM_SIG_S, defs.h:47
+    for (int i = 0; i <= R; i++) v[i] = expf(-(i * i) / (sig_s * sig_s));
+    for (int i = 0; i <= 8; i++) v[R + 1 + i] = 1 - expf(-float(i * i) / (0.3f * 8 * 0.3f * 8));
+}
+static void host_wmf_lut(std::vector<float>& v)
+{
+    v.resize(kWmfRadius + 1);
+    const float s = kWmfRadius * 1.0f;
+    for (int i = 0; i <= kWmfRadius; i++) v[i] = expf(-float(i * i) / (s * s));
+}
+static void host_blf_lut(std::vector<float>& v)
+{
+    v.resize(kBlfRadius + 1);
+    for (int i = 0; i <= kBlfRadius; i++) v[i] = expf(-float(i * i) / float(5 * 5));
+}
+
+// bao_pyr_init_dim (maxDepth overload), basic/bao_basic.h:196-211; BAO_FLOAT is double (:56)
+static int pyr_init_dim(int* arrH, int* arrW, int h, int w, int maxDepth, double ratio)
+{
+    int n = maxDepth <= 0 ? 1 : maxDepth;
+    arrH[0] = h; arrW[0] = w;
+    for (int i = 1; i < n; i++) {
+        arrH[i] = int(double(h) * pow(ratio, i));
+        arrW[i] = int(double(w) * pow(ratio, i));
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PatchMatch RNG object
+// ---------------------------------------------------------------------------------------------------
+struct eppm_pm_rng {
+    int device = 0, w = 0, h = 0, gx = 0, gy = 0, G = 0, per_lane = 0;
+    unsigned long long seed = 0;
+    uint32_t* init_tab = nullptr;
+    uint32_t* iter_tab = nullptr;
+    uint32_t* work[2] = {nullptr, nullptr};
+    uint32_t* skip_mat = nullptr;
+    uint32_t skip_weyl = 0;
+    PmRngDev dev(int which) const
+    {
+        PmRngDev d;
+        d.init_tab = init_tab; d.iter_tab = iter_tab; d.work = work[which]; d.skip_mat = skip_mat;
+        d.skip_weyl = skip_weyl; d.per_lane = per_lane; d.gx = gx; d.gy = gy;
+        return d;
+    }
+};
+
+static int rng_create(eppm_pm_rng** out, int w, int h, const eppm_params& p)
+{
+    eppm_pm_rng* r = new eppm_pm_rng();
+    HIPCHK(hipGetDevice(&r->device));
+    r->w = w; r->h = h; r->G = p.num_guess; r->seed = p.seed;
+    r->gx = (w + kBlock - 1) / kBlock; r->gy = (h + kBlock - 1) / kBlock;
+    r->per_lane = 512 * r->G / 64;
+    const int nb = r->gx * r->gy;
+    const size_t words = (size_t)nb * 64 * 6;
+    std::vector<uint32_t> it(words), st(words);
+    // walk every block's stream once: lane l of the init draw starts at draw 8*l, lane l of a search at
+    // 512 + per_lane*l (curand_init(seed, block_id, 0): kernel.cu:68)
+    for (int b = 0; b < nb; b++) {
+        XorwowState s;
+        xorwow_init(&s, p.seed, (unsigned long long)b);
+        for (int q = 0; q < 512; q++) {
+            if ((q & 7) == 0) memcpy(&it[((size_t)b * 64 + (q >> 3)) * 6], &s, 24);
+            xorwow_next(&s);
+        }
+        for (int q = 0; q < 512 * r->G; q++) {
+            if (q % r->per_lane == 0) memcpy(&st[((size_t)b * 64 + q / r->per_lane) * 6], &s, 24);
+            xorwow_next(&s);
+        }
+    }
+    const unsigned long long skip = (unsigned long long)(512 * r->G - r->per_lane);
+    std::vector<uint32_t> mat(160 * 5);
+    xorwow_skip_matrix(skip, mat.data());
+    r->skip_weyl = 362437u * (uint32_t)skip;
+    HIPCHK(hipMalloc(&r->init_tab, words * 4));
+    HIPCHK(hipMalloc(&r->iter_tab, words * 4));
+    HIPCHK(hipMalloc(&r->work[0], words * 4));
+    HIPCHK(hipMalloc(&r->work[1], words * 4));
+    HIPCHK(hipMalloc(&r->skip_mat, mat.size() * 4));
+    HIPCHK(hipMemcpy(r->init_tab, it.data(), words * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(r->iter_tab, st.data(), words * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(r->work[0], st.data(), words * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(r->work[1], st.data(), words * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(r->skip_mat, mat.data(), mat.size() * 4, hipMemcpyHostToDevice));
+    *out = r;
+    return EPPM_OK;
+}
+
+static void rng_free(eppm_pm_rng* r)
+{
+    if (!r) return;
+    (void)hipFree(r->init_tab); (void)hipFree(r->iter_tab); (void)hipFree(r->work[0]); (void)hipFree(r->work[1]);
+    (void)hipFree(r->skip_mat);
+    delete r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------
+static const int kMaxLevels = 8;
+static const int kNumLevels = 3;   // PYR_MAX_DEPTH, defs.h:31
+
+struct StageEv { const char* name; hipEvent_t a, b; };
+
+struct eppm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    eppm_params prm;
+    int h = 0, w = 0, nl = 0;
+    int H[kMaxLevels], W[kMaxLevels];
+    size_t ipitch[kMaxLevels], cpitch[kMaxLevels];   // bytes
+    uint32_t *raw1 = nullptr, *raw2 = nullptr;
+    size_t raw_pitch = 0;
+    uint32_t *img1[kMaxLevels] = {}, *img2[kMaxLevels] = {}, *tmpu[kMaxLevels] = {};
+    uint8_t *cen1[kMaxLevels] = {}, *cen2[kMaxLevels] = {};
+    int16_t *nnf1 = nullptr, *nnf2 = nullptr, *nnf_tmp = nullptr;
+    float *cost1 = nullptr, *cost2 = nullptr;
+    float *flow[kMaxLevels] = {}, *flow_tmp[kMaxLevels] = {};
+    float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
+    eppm_pm_rng* rng = nullptr;
+    uint8_t* d_rgb = nullptr;           // staging for host RGB input
+    uint8_t* h_rgb = nullptr;           // pinned
+    float* h_flow = nullptr;            // pinned
+    bool have_images = false, have_flow = false;
+    bool timing = false;
+    std::vector<StageEv> ev;
+    std::vector<StageEv> ev_prep;
+};
+
+static PlanesH planes(const eppm_ctx* c, int l, bool swap)
+{
+    PlanesH p;
+    p.img1 = swap ? c->img2[l] : c->img1[l];
+    p.img2 = swap ? c->img1[l] : c->img2[l];
+    p.cen1 = swap ? c->cen2[l] : c->cen1[l];
+    p.cen2 = swap ? c->cen1[l] : c->cen2[l];
+    p.w = c->W[l]; p.h = c->H[l];
+    p.ipitch = (int)(c->ipitch[l] / 4);
+    p.cpitch = (int)c->cpitch[l];
+    return p;
+}
+
+static void stage_begin(eppm_ctx* c, std::vector<StageEv>& v, const char* name)
+{
+    if (!c->timing) return;
+    StageEv e;
+    e.name = name;
+    (void)hipEventCreate(&e.a);
+    (void)hipEventCreate(&e.b);
+    (void)hipEventRecord(e.a, c->stream);
+    v.push_back(e);
+}
+static void stage_end(eppm_ctx* c, std::vector<StageEv>& v)
+{
+    if (!c->timing) return;
+    (void)hipEventRecord(v.back().b, c->stream);
+}
+static void clear_events(std::vector<StageEv>& v)
+{
+    for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    v.clear();
+}
+
+extern "C" int eppm_destroy(eppm_ctx* c)
+{
+    if (!c) return EPPM_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    clear_events(c->ev);
+    clear_events(c->ev_prep);
+    (void)hipFree(c->raw1); (void)hipFree(c->raw2);
+    for (int i = 0; i < kMaxLevels; i++) {
+        (void)hipFree(c->img1[i]); (void)hipFree(c->img2[i]); (void)hipFree(c->tmpu[i]);
+        (void)hipFree(c->cen1[i]); (void)hipFree(c->cen2[i]);
+        (void)hipFree(c->flow[i]); (void)hipFree(c->flow_tmp[i]);
+    }
+    (void)hipFree(c->nnf1); (void)hipFree(c->nnf2); (void)hipFree(c->nnf_tmp);
+    (void)hipFree(c->cost1); (void)hipFree(c->cost2);
+    (void)hipFree(c->lut_pm); (void)hipFree(c->lut_wmf); (void)hipFree(c->lut_blf);
+    (void)hipFree(c->d_rgb);
+    if (c->h_rgb) (void)hipHostFree(c->h_rgb);
+    if (c->h_flow) (void)hipHostFree(c->h_flow);
+    rng_free(c->rng);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return EPPM_OK;
+}
+
+static int upload_lut(float** dst, const std::vector<float>& v)
+{
+    HIPCHK(hipMalloc(dst, v.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return EPPM_OK;
+}
+
+static int ctx_alloc(eppm_ctx* c)
+{
+    const int h = c->h, w = c->w;
+    HIPCHK(hipMallocPitch((void**)&c->raw1, &c->raw_pitch, (size_t)w * 4, h));
+    HIPCHK(hipMallocPitch((void**)&c->raw2, &c->raw_pitch, (size_t)w * 4, h));
+    for (int i = 0; i < c->nl; i++) {
+        HIPCHK(hipMallocPitch((void**)&c->img1[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
+        HIPCHK(hipMallocPitch((void**)&c->img2[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
+        HIPCHK(hipMallocPitch((void**)&c->tmpu[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
+        HIPCHK(hipMallocPitch((void**)&c->cen1[i], &c->cpitch[i], (size_t)c->W[i], c->H[i]));
+        HIPCHK(hipMallocPitch((void**)&c->cen2[i], &c->cpitch[i], (size_t)c->W[i], c->H[i]));
+        const size_t n = (size_t)c->W[i] * c->H[i];
+        HIPCHK(hipMalloc((void**)&c->flow[i], n * 8));
+        HIPCHK(hipMalloc((void**)&c->flow_tmp[i], n * 8));
+    }
+    if (c->raw_pitch != c->ipitch[0]) return set_err(EPPM_ERR_HIP, "unexpected pitch mismatch");
+    const int L = c->nl - 1;
+    const size_t n = (size_t)c->W[L] * c->H[L];
+    HIPCHK(hipMalloc((void**)&c->nnf1, n * 4));
+    HIPCHK(hipMalloc((void**)&c->nnf2, n * 4));
+    HIPCHK(hipMalloc((void**)&c->nnf_tmp, n * 4));
+    HIPCHK(hipMalloc((void**)&c->cost1, n * 4));
+    HIPCHK(hipMalloc((void**)&c->cost2, n * 4));
+    std::vector<float> v;
+    host_pm_lut(c->prm.patch_r, v);  CHK(upload_lut(&c->lut_pm, v));
+    host_wmf_lut(v);                 CHK(upload_lut(&c->lut_wmf, v));
+    host_blf_lut(v);                 CHK(upload_lut(&c->lut_blf, v));
+    CHK(rng_create(&c->rng, c->W[L], c->H[L], c->prm));
+    HIPCHK(hipMalloc((void**)&c->d_rgb, (size_t)h * w * 3 * 2));
+    HIPCHK(hipHostMalloc((void**)&c->h_rgb, (size_t)h * w * 3 * 2, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->h_flow, (size_t)h * w * 8, hipHostMallocDefault));
+    return EPPM_OK;
+}
+
+extern "C" int eppm_create(eppm_ctx** out, int h, int w, int device, const eppm_params* params)
+{
+    if (!out) return set_err(EPPM_ERR_ARG, "eppm_create: NULL out");
+    *out = nullptr;
+    if (h < 4 || w < 4 || h > 32767 || w > 32767) return set_err(EPPM_ERR_ARG, "eppm_create: size %dx%d out of range (NNF coordinates are int16)", w, h);
+    eppm_params p;
+    eppm_default_params(&p);
+    if (params) p = *params;
+    CHK(check_params(p));
+    HIPCHK(hipSetDevice(device));
+    eppm_ctx* c = new eppm_ctx();
+    c->device = device; c->prm = p; c->h = h; c->w = w;
+    c->nl = pyr_init_dim(c->H, c->W, h, w, kNumLevels, 0.5f);
+    const int L = c->nl - 1;
+    if (c->H[L] < 1 || c->W[L] < 1 || (c->W[L] + p.seg_len - 1) / p.seg_len > 1024 || (c->H[L] + p.seg_len - 1) / p.seg_len > 1024) {
+        delete c;
+        return set_err(EPPM_ERR_ARG, "eppm_create: unsupported size %dx%d", w, h);
+    }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return set_err(EPPM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    c->own_stream = true;
+    int r = ctx_alloc(c);
+    if (r != EPPM_OK) { eppm_destroy(c); return r; }
+    *out = c;
+    return EPPM_OK;
+}
+
+extern "C" int eppm_set_stream(eppm_ctx* c, void* s)
+{
+    if (!c) return set_err(EPPM_ERR_ARG, "NULL ctx");
+    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    c->stream = (hipStream_t)s;
+    c->own_stream = false;
+    return EPPM_OK;
+}
+
+extern "C" int eppm_num_levels(const eppm_ctx* c) { return c ? c->nl : 0; }
+extern "C" int eppm_level_dims(const eppm_ctx* c, int level, int* h, int* w)
+{
+    if (!c || level < 0 || level >= c->nl) return set_err(EPPM_ERR_ARG, "bad level");
+    if (h) *h = c->H[level];
+    if (w) *w = c->W[level];
+    return EPPM_OK;
+}
+extern "C" int eppm_enable_stage_timing(eppm_ctx* c, int on)
+{
+    if (!c) return set_err(EPPM_ERR_ARG, "NULL ctx");
+    c->timing = on != 0;
+    return EPPM_OK;
+}
+
+// ---- prepare: refine :1060-1071 + .cuh:642-664 ----
+static int prepare_one(eppm_ctx* c, uint32_t** pyr, uint8_t** cen, uint32_t** tmp, const uint32_t* raw)
+{
+    hipStream_t s = c->stream;
+    const int p0 = (int)(c->ipitch[0] / 4);
+    launch_gauss_rgba(pyr[0], raw, p0, c->H[0], c->W[0], .5f, 2, s);                    // refine :1063-1064
+    const float ratio = 0.5f;                                                             // PYR_RATIO
+    const float baseSigma = (1 / ratio - 1);
+    const int n = (int)(log(0.25) / (double)logf(ratio));   // C++ float overload in the reference: n = 1, see oracle note
+    const float nSigma = baseSigma * n;
+    for (int i = 1; i < c->nl; i++) {
+        if (i <= n) {
+            const float sigma = baseSigma * i;
+            launch_gauss_rgba(tmp[0], pyr[0], p0, c->H[0], c->W[0], sigma, (int)(sigma * 3), s);
+            launch_resize_rgba(pyr[i], (int)(c->ipitch[i] / 4), c->H[i], c->W[i], tmp[0], p0, c->H[0], c->W[0], (float)pow(ratio, i), s);
+        } else {
+            const int j = i - n;
+            launch_gauss_rgba(tmp[j], pyr[j], (int)(c->ipitch[j] / 4), c->H[j], c->W[j], nSigma, (int)(nSigma * 3), s);
+            launch_resize_rgba(pyr[i], (int)(c->ipitch[i] / 4), c->H[i], c->W[i], tmp[j], (int)(c->ipitch[j] / 4), c->H[j], c->W[j],
+                               (float)pow(ratio, i) * c->W[0] / c->W[j], s);
+        }
+    }
+    for (int i = 0; i < c->nl; i++) launch_census(cen[i], (int)c->cpitch[i], pyr[i], (int)(c->ipitch[i] / 4), c->W[i], c->H[i], s);
+    return EPPM_OK;
+}
+
+static int prepare(eppm_ctx* c, const uint32_t* raw1, const uint32_t* raw2)
+{
+    clear_events(c->ev_prep);
+    stage_begin(c, c->ev_prep, "prepare");
+    CHK(prepare_one(c, c->img1, c->cen1, c->tmpu, raw1));
+    CHK(prepare_one(c, c->img2, c->cen2, c->tmpu, raw2));
+    stage_end(c, c->ev_prep);
+    HIPCHK(hipGetLastError());
+    c->have_images = true;
+    c->have_flow = false;
+    return EPPM_OK;
+}
+
+extern "C" int eppm_set_images(eppm_ctx* c, const uint8_t* rgb1, const uint8_t* rgb2, size_t row_stride)
+{
+    if (!c || !rgb1 || !rgb2) return set_err(EPPM_ERR_ARG, "eppm_set_images: NULL argument");
+    if (row_stride < (size_t)c->w * 3) return set_err(EPPM_ERR_ARG, "eppm_set_images: row_stride %zu < 3*w", row_stride);
+    HIPCHK(hipSetDevice(c->device));
+    const size_t row = (size_t)c->w * 3, img = row * c->h;
+    HIPCHK(hipStreamSynchronize(c->stream));       // the pinned staging buffer may still be in flight
+    for (int y = 0; y < c->h; y++) {
+        memcpy(c->h_rgb + (size_t)y * row, rgb1 + (size_t)y * row_stride, row);
+        memcpy(c->h_rgb + img + (size_t)y * row, rgb2 + (size_t)y * row_stride, row);
+    }
+    HIPCHK(hipMemcpyAsync(c->d_rgb, c->h_rgb, img * 2, hipMemcpyHostToDevice, c->stream));
+    const int p0 = (int)(c->raw_pitch / 4);
+    launch_rgb_to_rgba(c->raw1, p0, c->d_rgb, c->h, c->w, c->stream);          // bao_rgb2rgba, alpha = 0
+    launch_rgb_to_rgba(c->raw2, p0, c->d_rgb + img, c->h, c->w, c->stream);
+    return prepare(c, c->raw1, c->raw2);
+}
+
+extern "C" int eppm_set_images_device(eppm_ctx* c, const void* d1, const void* d2, size_t pitch)
+{
+    if (!c || !d1 || !d2) return set_err(EPPM_ERR_ARG, "eppm_set_images_device: NULL argument");
+    if (pitch < (size_t)c->w * 4 || (pitch & 3)) return set_err(EPPM_ERR_ARG, "eppm_set_images_device: bad pitch %zu", pitch);
+    HIPCHK(hipSetDevice(c->device));
+    // the prefilter reads the caller's planes directly when the pitch matches, else through a 2-D copy
+    if (pitch == c->raw_pitch) return prepare(c, (const uint32_t*)d1, (const uint32_t*)d2);
+    HIPCHK(hipMemcpy2DAsync(c->raw1, c->raw_pitch, d1, pitch, (size_t)c->w * 4, c->h, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpy2DAsync(c->raw2, c->raw_pitch, d2, pitch, (size_t)c->w * 4, c->h, hipMemcpyDeviceToDevice, c->stream));
+    return prepare(c, c->raw1, c->raw2);
+}
+
+// ---- one PatchMatch call, kernel.cu:1760-1826 ----
+static void run_patchmatch(const PlanesH& P, const PmRngDev& rng, int16_t* nnf, float* cost, int cpitch, int npitch,
+                           const float* lut, const eppm_params& prm, hipStream_t s)
+{
+    launch_pm_init_field(rng, nnf, npitch, P.w, P.h, s);
+    launch_pm_cost_field(P, cost, cpitch, nnf, npitch, lut, prm.patch_r, s);
+    for (int it = 0; it < prm.num_iter; it++) {
+        for (int dir = 0; dir < 4; dir++) launch_pm_seg_propagate(P, cost, cpitch, nnf, npitch, lut, prm.patch_r, prm.seg_len, dir, s);
+        launch_pm_random_search(P, rng, cost, cpitch, nnf, npitch, lut, prm.patch_r, prm.search_range, prm.num_guess, s);
+    }
+}
+
+extern "C" int eppm_compute_device(eppm_ctx* c, void* d_flow)
+{
+    if (!c) return set_err(EPPM_ERR_ARG, "NULL ctx");
+    if (!c->have_images) return set_err(EPPM_ERR_STATE, "eppm_compute: no images set");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    clear_events(c->ev);
+    const int L = c->nl - 1;                                            // pm_layer, driver :219
+    const int lw = c->W[L], lh = c->H[L];
+
+    stage_begin(c, c->ev, "patchmatch");
+    run_patchmatch(planes(c, L, false), c->rng->dev(0), c->nnf1, c->cost1, lw, lw, c->lut_pm, c->prm, s);   // driver :223
+    run_patchmatch(planes(c, L, true), c->rng->dev(1), c->nnf2, c->cost2, lw, lw, c->lut_pm, c->prm, s);    // driver :224
+    stage_end(c, c->ev);
+
+    stage_begin(c, c->ev, "l2_post");
+    launch_lr_check(c->nnf1, c->cost1, c->nnf2, lw, lh, lw, lw, s);                                          // driver :233
+    launch_lr_check(c->nnf2, c->cost2, c->nnf1, lw, lh, lw, lw, s);
+    launch_outlier(c->nnf_tmp, c->cost1, c->nnf1, lw, lh, lw, lw, s);                                        // driver :237
+    std::swap(c->nnf1, c->nnf_tmp);
+    for (int i = 0; i < c->prm.wmf_iters; i++) {                                                             // driver :239
+        launch_wmf(c->nnf_tmp, c->nnf1, c->img1[L], (int)(c->ipitch[L] / 4), lw, lh, lw, c->lut_wmf, 1, s);
+        std::swap(c->nnf1, c->nnf_tmp);
+    }
+    launch_fill_holes(c->nnf_tmp, c->nnf1, c->img1[L], (int)(c->ipitch[L] / 4), lw, lh, lw, s);              // driver :240
+    std::swap(c->nnf1, c->nnf_tmp);
+    launch_nnf2flow(c->flow[L], lw, c->nnf1, lw, lw, lh, s);                                                 // driver :258
+    stage_end(c, c->ev);
+
+    static const char* up_names[] = {"upsample_L0", "upsample_L1", "upsample_L2", "upsample_L3", "upsample_L4", "upsample_L5", "upsample_L6"};
+    static const char* rf_names[] = {"c2f_refine_L0", "c2f_refine_L1", "c2f_refine_L2", "c2f_refine_L3", "c2f_refine_L4", "c2f_refine_L5", "c2f_refine_L6"};
+    static const char* bl_names[] = {"flow_blf_L0", "flow_blf_L1", "flow_blf_L2", "flow_blf_L3", "flow_blf_L4", "flow_blf_L5", "flow_blf_L6"};
+    for (int l = L - 1; l >= 0; l--) {                                                                       // driver :275-282
+        stage_begin(c, c->ev, up_names[l]);
+        launch_resize_flow(c->flow[l], c->H[l], c->W[l], c->flow[l + 1], c->H[l + 1], c->W[l + 1], 2.0f, 2.0f, s);   // refine :1082-1083
+        stage_end(c, c->ev);
+        stage_begin(c, c->ev, rf_names[l]);
+        launch_c2f_refine(planes(c, l, false), c->flow[l], c->lut_pm, c->prm.patch_r, s);                    // refine :1086
+        stage_end(c, c->ev);
+        stage_begin(c, c->ev, bl_names[l]);
+        launch_flow_blf(c->flow_tmp[l], c->flow[l], c->img1[l], (int)(c->ipitch[l] / 4), c->W[l], c->H[l], c->W[l], c->lut_blf, s);  // driver :280
+        std::swap(c->flow[l], c->flow_tmp[l]);
+        stage_end(c, c->ev);
+    }
+    stage_begin(c, c->ev, "flow_blf_final");
+    launch_flow_blf(c->flow_tmp[0], c->flow[0], c->img1[0], (int)(c->ipitch[0] / 4), c->W[0], c->H[0], c->W[0], c->lut_blf, s);      // driver :289
+    std::swap(c->flow[0], c->flow_tmp[0]);
+    stage_end(c, c->ev);
+    if (d_flow) HIPCHK(hipMemcpyAsync(d_flow, c->flow[0], (size_t)c->h * c->w * 8, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipGetLastError());
+    c->have_flow = true;
+    return EPPM_OK;
+}
+
+extern "C" int eppm_compute(eppm_ctx* c, float* u, float* v)
+{
+    if (!c || !u || !v) return set_err(EPPM_ERR_ARG, "eppm_compute: NULL argument");
+    CHK(eppm_compute_device(c, nullptr));
+    const size_t n = (size_t)c->h * c->w;
+    HIPCHK(hipMemcpyAsync(c->h_flow, c->flow[0], n * 8, hipMemcpyDeviceToHost, c->stream));    // driver :299
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) { u[i] = c->h_flow[2 * i]; v[i] = c->h_flow[2 * i + 1]; }    // driver :302-306
+    return EPPM_OK;
+}
+
+extern "C" int eppm_synchronize(eppm_ctx* c)
+{
+    if (!c) return set_err(EPPM_ERR_ARG, "NULL ctx");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return EPPM_OK;
+}
+
+extern "C" int eppm_stage_times(eppm_ctx* c, const char** names, float* ms, int max)
+{
+    if (!c) return 0;
+    (void)hipStreamSynchronize(c->stream);
+    int n = 0;
+    for (auto* v : {&c->ev_prep, &c->ev})
+        for (auto& e : *v) {
+            if (n >= max) return n;
+            float t = 0;
+            if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) t = -1;
+            names[n] = e.name; ms[n] = t; n++;
+        }
+    return n;
+}
+
+extern "C" int eppm_get_plane(eppm_ctx* c, const char* name, int level, void* dst, size_t dst_bytes)
+{
+    if (!c || !name || !dst) return set_err(EPPM_ERR_ARG, "eppm_get_plane: NULL argument");
+    if (level < 0 || level >= c->nl) return set_err(EPPM_ERR_ARG, "eppm_get_plane: bad level %d", level);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int w = c->W[level], h = c->H[level], L = c->nl - 1;
+    const void* src = nullptr;
+    size_t esz = 0, pitch = 0;
+    std::string n(name);
+    if (n == "img1" || n == "img2") { src = (n == "img1") ? c->img1[level] : c->img2[level]; esz = 4; pitch = c->ipitch[level]; }
+    else if (n == "census1" || n == "census2") { src = (n == "census1") ? c->cen1[level] : c->cen2[level]; esz = 1; pitch = c->cpitch[level]; }
+    else if (n == "flow") { src = c->flow[level]; esz = 8; pitch = (size_t)w * 8; }
+    else if (level == L && (n == "nnf1" || n == "nnf2")) { src = (n == "nnf1") ? c->nnf1 : c->nnf2; esz = 4; pitch = (size_t)w * 4; }
+    else if (level == L && (n == "cost1" || n == "cost2")) { src = (n == "cost1") ? c->cost1 : c->cost2; esz = 4; pitch = (size_t)w * 4; }
+    else return set_err(EPPM_ERR_ARG, "eppm_get_plane: unknown plane '%s' at level %d", name, level);
+    if (dst_bytes < (size_t)w * h * esz) return set_err(EPPM_ERR_ARG, "eppm_get_plane: dst too small");
+    HIPCHK(hipMemcpy2D(dst, (size_t)w * esz, src, pitch, (size_t)w * esz, h, hipMemcpyDeviceToHost));
+    return EPPM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// device-memory plumbing
+// ---------------------------------------------------------------------------------------------------
+extern "C" int eppm_device_count(int* n) { HIPCHK(hipGetDeviceCount(n)); return EPPM_OK; }
+extern "C" int eppm_set_device(int d) { HIPCHK(hipSetDevice(d)); return EPPM_OK; }
+extern "C" int eppm_malloc_device(void** p, size_t bytes) { HIPCHK(hipMalloc(p, bytes ? bytes : 1)); return EPPM_OK; }
+extern "C" int eppm_malloc_pitched(void** p, size_t* pitch, size_t width_bytes, size_t rows) { HIPCHK(hipMallocPitch(p, pitch, width_bytes, rows)); return EPPM_OK; }
+extern "C" int eppm_free_device(void* p) { HIPCHK(hipFree(p)); return EPPM_OK; }
+extern "C" int eppm_memcpy_h2d(void* d, const void* s, size_t n) { HIPCHK(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); return EPPM_OK; }
+extern "C" int eppm_memcpy_d2h(void* d, const void* s, size_t n) { HIPCHK(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); return EPPM_OK; }
+extern "C" int eppm_memcpy2d_h2d(void* d, size_t dp, const void* s, size_t sp, size_t wb, size_t rows) { HIPCHK(hipMemcpy2D(d, dp, s, sp, wb, rows, hipMemcpyHostToDevice)); return EPPM_OK; }
+extern "C" int eppm_memcpy2d_d2h(void* d, size_t dp, const void* s, size_t sp, size_t wb, size_t rows) { HIPCHK(hipMemcpy2D(d, dp, s, sp, wb, rows, hipMemcpyDeviceToHost)); return EPPM_OK; }
+extern "C" int eppm_memset_device(void* p, int v, size_t n) { HIPCHK(hipMemset(p, v, n)); return EPPM_OK; }
+extern "C" int eppm_device_synchronize(void) { HIPCHK(hipDeviceSynchronize()); return EPPM_OK; }
+
+// ---------------------------------------------------------------------------------------------------
+// state of the context-less, reference-signature launchers (the reference keeps the equivalent in
+// file-scope textures, __constant__ tables and g_d_rand_states: SURVEY F12)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct DevState {
+    float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
+    int lut_R = -1;
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    std::map<std::tuple<int, int, int, unsigned long long>, eppm_pm_rng*> rngs;
+};
+std::mutex g_mu;
+std::map<int, DevState> g_dev;
+hipStream_t g_stream = nullptr;
+eppm_params g_prm = {9, 10, 30, 6, 10, 20, 1234ULL};
+int g_launch_status = EPPM_OK;
+
+int dev_state(DevState** out)
+{
+    int d = 0;
+    HIPCHK(hipGetDevice(&d));
+    DevState& s = g_dev[d];
+    if (s.lut_R != g_prm.patch_r) {
+        (void)hipFree(s.lut_pm); s.lut_pm = nullptr;
+        std::vector<float> v;
+        host_pm_lut(g_prm.patch_r, v);
+        CHK(upload_lut(&s.lut_pm, v));
+        s.lut_R = g_prm.patch_r;
+    }
+    if (!s.lut_wmf) { std::vector<float> v; host_wmf_lut(v); CHK(upload_lut(&s.lut_wmf, v)); }
+    if (!s.lut_blf) { std::vector<float> v; host_blf_lut(v); CHK(upload_lut(&s.lut_blf, v)); }
+    *out = &s;
+    return EPPM_OK;
+}
+int get_scratch(DevState* s, size_t bytes, void** out)
+{
+    if (s->scratch_bytes < bytes) {
+        (void)hipStreamSynchronize(g_stream);
+        (void)hipFree(s->scratch);
+        s->scratch = nullptr; s->scratch_bytes = 0;
+        HIPCHK(hipMalloc(&s->scratch, bytes));
+        s->scratch_bytes = bytes;
+    }
+    *out = s->scratch;
+    return EPPM_OK;
+}
+int get_rng(DevState* s, int w, int h, eppm_pm_rng** out)
+{
+    auto key = std::make_tuple(w, h, g_prm.num_guess, g_prm.seed);
+    auto it = s->rngs.find(key);
+    if (it == s->rngs.end()) {
+        eppm_pm_rng* r = nullptr;
+        CHK(rng_create(&r, w, h, g_prm));
+        it = s->rngs.emplace(key, r).first;
+    }
+    *out = it->second;
+    return EPPM_OK;
+}
+PlanesH mk_planes(const void* i1, const void* i2, const void* c1, const void* c2, int w, int h, size_t ip, size_t cp)
+{
+    PlanesH p;
+    p.img1 = (const uint32_t*)i1; p.img2 = (const uint32_t*)i2; p.cen1 = (const uint8_t*)c1; p.cen2 = (const uint8_t*)c2;
+    p.w = w; p.h = h; p.ipitch = (int)(ip / 4); p.cpitch = (int)cp;
+    return p;
+}
+int finish() { HIPCHK(hipGetLastError()); return EPPM_OK; }
+}  // namespace
+
+#define LAUNCHER_BEGIN std::lock_guard<std::mutex> lk_(g_mu); DevState* ds = nullptr; g_launch_status = dev_state(&ds); if (g_launch_status != EPPM_OK) return
+#define LAUNCHER_BEGIN_INT std::lock_guard<std::mutex> lk_(g_mu); DevState* ds = nullptr; CHK(dev_state(&ds))
+
+extern "C" int eppm_set_launcher_stream(void* s) { std::lock_guard<std::mutex> lk(g_mu); g_stream = (hipStream_t)s; return EPPM_OK; }
+extern "C" int eppm_set_launcher_params(const eppm_params* p)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!p) return eppm_default_params(&g_prm);
+    CHK(check_params(*p));
+    g_prm = *p;
+    return EPPM_OK;
+}
+
+// ---- PatchMatch sub-stages ----
+extern "C" int eppm_pm_rng_create(eppm_pm_rng** out, int w, int h, const eppm_params* p)
+{
+    if (!out || w < 1 || h < 1) return set_err(EPPM_ERR_ARG, "eppm_pm_rng_create: bad argument");
+    eppm_params q;
+    eppm_default_params(&q);
+    if (p) q = *p;
+    CHK(check_params(q));
+    return rng_create(out, w, h, q);
+}
+extern "C" int eppm_pm_rng_reset(eppm_pm_rng* r)
+{
+    if (!r) return set_err(EPPM_ERR_ARG, "NULL rng");
+    const size_t bytes = (size_t)r->gx * r->gy * 64 * 6 * 4;
+    HIPCHK(hipMemcpy(r->work[0], r->iter_tab, bytes, hipMemcpyDeviceToDevice));
+    return EPPM_OK;
+}
+extern "C" int eppm_pm_rng_destroy(eppm_pm_rng* r) { rng_free(r); return EPPM_OK; }
+extern "C" int eppm_pm_rng_block_states(eppm_pm_rng* r, uint32_t* dst, size_t dst_words)
+{
+    if (!r || !dst) return set_err(EPPM_ERR_ARG, "NULL argument");
+    const int nb = r->gx * r->gy;
+    if (dst_words < (size_t)nb * 6) return set_err(EPPM_ERR_ARG, "dst too small");
+    HIPCHK(hipDeviceSynchronize());
+    // lane 0 of each block sits at the block's sequential stream position
+    HIPCHK(hipMemcpy2D(dst, 24, r->work[0], 64 * 24, 24, nb, hipMemcpyDeviceToHost));
+    return EPPM_OK;
+}
+extern "C" int eppm_pm_gen_rand_field(eppm_pm_rng* r, eppm_short2* d_nnf, int w, int h, size_t disp_pitch)
+{
+    if (!r || !d_nnf || w != r->w || h != r->h) return set_err(EPPM_ERR_ARG, "eppm_pm_gen_rand_field: bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_pm_init_field(r->dev(0), (int16_t*)d_nnf, (int)(disp_pitch / 4), w, h, g_stream);
+    return finish();
+}
+extern "C" int eppm_pm_cost_field(float* d_cost, const eppm_short2* d_nnf, const eppm_uchar4* i1, const eppm_uchar4* i2,
+                                  const unsigned char* c1, const unsigned char* c2, int w, int h, size_t img_pitch,
+                                  size_t cost_pitch, size_t disp_pitch, size_t census_pitch)
+{
+    LAUNCHER_BEGIN_INT;
+    launch_pm_cost_field(mk_planes(i1, i2, c1, c2, w, h, img_pitch, census_pitch), d_cost, (int)(cost_pitch / 4), (const int16_t*)d_nnf,
+                         (int)(disp_pitch / 4), ds->lut_pm, g_prm.patch_r, g_stream);
+    return finish();
+}
+extern "C" int eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* i1, const eppm_uchar4* i2,
+                                     const unsigned char* c1, const unsigned char* c2, int w, int h, size_t img_pitch,
+                                     size_t cost_pitch, size_t disp_pitch, size_t census_pitch, int dir)
+{
+    LAUNCHER_BEGIN_INT;
+    const PlanesH P = mk_planes(i1, i2, c1, c2, w, h, img_pitch, census_pitch);
+    for (int d = 0; d < 4; d++)
+        if (dir < 0 || dir == d)
+            launch_pm_seg_propagate(P, d_cost, (int)(cost_pitch / 4), (int16_t*)d_nnf, (int)(disp_pitch / 4), ds->lut_pm, g_prm.patch_r,
+                                    g_prm.seg_len, d, g_stream);
+    return finish();
+}
+extern "C" int eppm_pm_random_search(eppm_pm_rng* r, float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* i1, const eppm_uchar4* i2,
+                                     const unsigned char* c1, const unsigned char* c2, int w, int h, size_t img_pitch,
+                                     size_t cost_pitch, size_t disp_pitch, size_t census_pitch)
+{
+    if (!r || w != r->w || h != r->h) return set_err(EPPM_ERR_ARG, "eppm_pm_random_search: bad rng");
+    LAUNCHER_BEGIN_INT;
+    if (r->G != g_prm.num_guess) return set_err(EPPM_ERR_ARG, "rng was created for num_guess=%d", r->G);
+    launch_pm_random_search(mk_planes(i1, i2, c1, c2, w, h, img_pitch, census_pitch), r->dev(0), d_cost, (int)(cost_pitch / 4),
+                            (int16_t*)d_nnf, (int)(disp_pitch / 4), ds->lut_pm, g_prm.patch_r, g_prm.search_range, g_prm.num_guess, g_stream);
+    return finish();
+}
+extern "C" int eppm_gauss_filter_rgba(eppm_uchar4* d_out, const eppm_uchar4* d_in, size_t pitch, int h, int w, float sigma, int radius)
+{
+    if (radius < 0 || radius > 6) return set_err(EPPM_ERR_ARG, "radius %d out of range [0,6]", radius);
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_gauss_rgba((uint32_t*)d_out, (const uint32_t*)d_in, (int)(pitch / 4), h, w, sigma, radius, g_stream);
+    return finish();
+}
+extern "C" int eppm_resize_rgba(eppm_uchar4* d_out, size_t out_pitch, int outH, int outW, const eppm_uchar4* d_in, size_t in_pitch,
+                                int h, int w, float ratio)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_resize_rgba((uint32_t*)d_out, (int)(out_pitch / 4), outH, outW, (const uint32_t*)d_in, (int)(in_pitch / 4), h, w, ratio, g_stream);
+    return finish();
+}
+extern "C" int eppm_resize_flow(eppm_float2* d_out, int outH, int outW, const eppm_float2* d_in, int h, int w, float ratio)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_resize_flow((float*)d_out, outH, outW, (const float*)d_in, h, w, ratio, 1.0f, g_stream);
+    return finish();
+}
+static int probe(const float* x, float* y, int n, int which)
+{
+    float *dx = nullptr, *dy = nullptr;
+    HIPCHK(hipMalloc(&dx, (size_t)n * 4));
+    HIPCHK(hipMalloc(&dy, (size_t)n * 4));
+    HIPCHK(hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    launch_probe(dx, dy, n, which, nullptr);
+    HIPCHK(hipMemcpy(y, dy, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy);
+    return finish();
+}
+extern "C" int eppm_probe_fast_exp(const float* x, float* y, int n) { return probe(x, y, n, 0); }
+extern "C" int eppm_probe_div_const(const float* x, float* y, int n, int which) { return probe(x, y, n, 1 + which); }
+
+// ---------------------------------------------------------------------------------------------------
+// the reference's live extern "C" launchers (driver :40-62)
+// ---------------------------------------------------------------------------------------------------
+extern "C" void baoCudaCensusTransform(unsigned char* d_census1, unsigned char* d_census2, eppm_uchar4* d_img1, eppm_uchar4* d_img2,
+                                       int w, int h, size_t img_pitch, size_t census_pitch)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_census(d_census1, (int)census_pitch, (const uint32_t*)d_img1, (int)(img_pitch / 4), w, h, g_stream);
+    launch_census(d_census2, (int)census_pitch, (const uint32_t*)d_img2, (int)(img_pitch / 4), w, h, g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaPatchMatchMultiscalePrepare(eppm_uchar4** pImgPyr1, eppm_uchar4** pImgPyr2, unsigned char** pCensusPyr1,
+        unsigned char** pCensusPyr2, eppm_uchar4** pTempPyr1, eppm_uchar4** pTempPyr2, int* arrH, int* arrW,
+        size_t* arrPitchUchar4, size_t* arrPitchUchar1, int nLevels, eppm_uchar4* d_img1, eppm_uchar4* d_img2, int h, int w)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    hipStream_t s = g_stream;
+    const float ratio = 0.5f;
+    const float baseSigma = (1 / ratio - 1);
+    const int n = (int)(log(0.25) / (double)logf(ratio));   // C++ float overload in the reference: n = 1, see oracle note
+    const float nSigma = baseSigma * n;
+    for (int k = 0; k < 2; k++) {
+        uint32_t** pyr = (uint32_t**)(k ? pImgPyr2 : pImgPyr1);
+        uint32_t** tmp = (uint32_t**)(k ? pTempPyr2 : pTempPyr1);
+        const uint32_t* raw = (const uint32_t*)(k ? d_img2 : d_img1);
+        // NOTE: the reference allocates its temp pyramid unpitched (driver :155-156) yet addresses it with the
+        // pitched stride; here temp planes are addressed with arrPitchUchar4 as well, so they must be pitched.
+        launch_gauss_rgba(pyr[0], raw, (int)(arrPitchUchar4[0] / 4), h, w, .5f, 2, s);
+        for (int i = 1; i < nLevels; i++) {
+            if (i <= n) {
+                const float sigma = baseSigma * i;
+                launch_gauss_rgba(tmp[0], pyr[0], (int)(arrPitchUchar4[0] / 4), arrH[0], arrW[0], sigma, (int)(sigma * 3), s);
+                launch_resize_rgba(pyr[i], (int)(arrPitchUchar4[i] / 4), arrH[i], arrW[i], tmp[0], (int)(arrPitchUchar4[0] / 4), arrH[0], arrW[0], (float)pow(ratio, i), s);
+            } else {
+                const int j = i - n;
+                launch_gauss_rgba(tmp[j], pyr[j], (int)(arrPitchUchar4[j] / 4), arrH[j], arrW[j], nSigma, (int)(nSigma * 3), s);
+                launch_resize_rgba(pyr[i], (int)(arrPitchUchar4[i] / 4), arrH[i], arrW[i], tmp[j], (int)(arrPitchUchar4[j] / 4), arrH[j], arrW[j],
+                                   (float)pow(ratio, i) * arrW[0] / arrW[j], s);
+            }
+        }
+    }
+    for (int i = 0; i < nLevels; i++) {
+        launch_census(pCensusPyr1[i], (int)arrPitchUchar1[i], (const uint32_t*)pImgPyr1[i], (int)(arrPitchUchar4[i] / 4), arrW[i], arrH[i], s);
+        launch_census(pCensusPyr2[i], (int)arrPitchUchar1[i], (const uint32_t*)pImgPyr2[i], (int)(arrPitchUchar4[i] / 4), arrW[i], arrH[i], s);
+    }
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaPatchMatch(eppm_short2* d_disp_vec, float* d_cost, eppm_uchar4* d_img1, eppm_uchar4* d_img2,
+        unsigned char* d_census1, unsigned char* d_census2, int w, int h, size_t img_pitch, size_t cost_pitch,
+        size_t disp_pitch, size_t census_pitch)
+{
+    LAUNCHER_BEGIN;
+    eppm_pm_rng* r = nullptr;
+    g_launch_status = get_rng(ds, w, h, &r);
+    if (g_launch_status != EPPM_OK) return;
+    run_patchmatch(mk_planes(d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch), r->dev(0), (int16_t*)d_disp_vec, d_cost,
+                   (int)(cost_pitch / 4), (int)(disp_pitch / 4), ds->lut_pm, g_prm, g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaLeftRightCheck(eppm_short2* d_disp_vec, float* d_cost, eppm_short2* d_disp_vec2, float* d_cost2,
+        int w, int h, size_t cost_pitch, size_t disp_pitch)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_lr_check((int16_t*)d_disp_vec, d_cost, (const int16_t*)d_disp_vec2, w, h, (int)(cost_pitch / 4), (int)(disp_pitch / 4), g_stream);
+    launch_lr_check((int16_t*)d_disp_vec2, d_cost2, (const int16_t*)d_disp_vec, w, h, (int)(cost_pitch / 4), (int)(disp_pitch / 4), g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaOutlierRemoval(eppm_short2* d_disp_vec, float* d_cost, int w, int h, size_t cost_pitch, size_t disp_pitch)
+{
+    LAUNCHER_BEGIN;
+    void* tmp = nullptr;
+    g_launch_status = get_scratch(ds, disp_pitch * h, &tmp);
+    if (g_launch_status != EPPM_OK) return;
+    (void)hipMemcpyAsync(tmp, d_disp_vec, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream);
+    launch_outlier((int16_t*)d_disp_vec, d_cost, (const int16_t*)tmp, w, h, (int)(cost_pitch / 4), (int)(disp_pitch / 4), g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaWeightedMedianFilter(eppm_short2* d_disp_vec, float* d_cost, eppm_uchar4* d_img, int w, int h,
+        size_t img_pitch, size_t cost_pitch, size_t disp_pitch, int num_iter, bool is_only_occlusion)
+{
+    (void)d_cost; (void)cost_pitch;
+    LAUNCHER_BEGIN;
+    void* tmp = nullptr;
+    g_launch_status = get_scratch(ds, disp_pitch * h, &tmp);
+    if (g_launch_status != EPPM_OK) return;
+    int16_t* a = (int16_t*)d_disp_vec;
+    int16_t* b = (int16_t*)tmp;
+    for (int i = 0; i < num_iter; i++) {
+        launch_wmf(b, a, (const uint32_t*)d_img, (int)(img_pitch / 4), w, h, (int)(disp_pitch / 4), ds->lut_wmf, is_only_occlusion ? 1 : 0, g_stream);
+        std::swap(a, b);
+    }
+    if (a != (int16_t*)d_disp_vec) (void)hipMemcpyAsync(d_disp_vec, a, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaFillHole(eppm_short2* d_disp_vec, float* d_cost, eppm_uchar4* d_img, int w, int h,
+        size_t img_pitch, size_t cost_pitch, size_t disp_pitch)
+{
+    (void)d_cost; (void)cost_pitch;
+    LAUNCHER_BEGIN;
+    void* tmp = nullptr;
+    g_launch_status = get_scratch(ds, disp_pitch * h, &tmp);
+    if (g_launch_status != EPPM_OK) return;
+    (void)hipMemcpyAsync(tmp, d_disp_vec, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream);
+    launch_fill_holes((int16_t*)d_disp_vec, (const int16_t*)tmp, (const uint32_t*)d_img, (int)(img_pitch / 4), w, h, (int)(disp_pitch / 4), g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaNNF2Flow(eppm_float2* d_flow, eppm_short2* d_disp_vec, int w, int h, size_t disp_pitch, size_t flow_pitch)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_nnf2flow((float*)d_flow, (int)(flow_pitch / 8), (const int16_t*)d_disp_vec, (int)(disp_pitch / 4), w, h, g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaBLFCostFilterRefine(eppm_float2* d_flow_vec, eppm_uchar4* d_img1, eppm_uchar4* d_img2, unsigned char* d_census1,
+        unsigned char* d_census2, int w, int h, size_t img_pitch, size_t census_pitch)
+{
+    LAUNCHER_BEGIN;
+    launch_c2f_refine(mk_planes(d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch), (float*)d_flow_vec, ds->lut_pm, g_prm.patch_r, g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaBLF_C2F(eppm_float2** pFlowPyr, eppm_uchar4** pImgPyr1, eppm_uchar4** pImgPyr2, unsigned char** pCensusPyr1,
+        unsigned char** pCensusPyr2, eppm_float2** pTempPyr1, eppm_float2** pTempPyr2, int* arrH, int* arrW,
+        size_t* arrPitchUchar4, size_t* arrPitchUchar1, int nLayerIdx)
+{
+    (void)pTempPyr1; (void)pTempPyr2;
+    LAUNCHER_BEGIN;
+    const int l = nLayerIdx;
+    launch_resize_flow((float*)pFlowPyr[l], arrH[l], arrW[l], (const float*)pFlowPyr[l + 1], arrH[l + 1], arrW[l + 1], 2.0f, 1.0f, g_stream);  // refine :1082
+    launch_mul_scalar((float*)pFlowPyr[l], 2.0f, arrH[l], arrW[l], g_stream);                                                                  // refine :1083
+    launch_c2f_refine(mk_planes(pImgPyr1[l], pImgPyr2[l], pCensusPyr1[l], pCensusPyr2[l], arrW[l], arrH[l], arrPitchUchar4[l], arrPitchUchar1[l]),
+                      (float*)pFlowPyr[l], ds->lut_pm, g_prm.patch_r, g_stream);                                                               // refine :1086
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaFlowSmoothing(eppm_float2* d_flow, eppm_uchar4* d_img, int w, int h, size_t img_pitch, size_t flow_pitch)
+{
+    LAUNCHER_BEGIN;
+    void* tmp = nullptr;
+    g_launch_status = get_scratch(ds, flow_pitch * h, &tmp);
+    if (g_launch_status != EPPM_OK) return;
+    (void)hipMemcpyAsync(tmp, d_flow, flow_pitch * h, hipMemcpyDeviceToDevice, g_stream);
+    launch_flow_blf((float*)d_flow, (const float*)tmp, (const uint32_t*)d_img, (int)(img_pitch / 4), w, h, (int)(flow_pitch / 8), ds->lut_blf, g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" int eppm_launcher_status(void) { return g_launch_status; }

@@ -1,0 +1,243 @@
+// eppm_device.cuh -- device-side building blocks shared by every EPPM kernel (gfx950 / CDNA4).
+//
+// The float formulas here are the product's own statement of the arithmetic that the CPU oracle
+// (oracle/eppm_oracle.c) restates from the reference; the two are written independently and must
+// agree bit for bit (tests/test_arith_gpu.py).  Everything is compiled with -ffp-contract=off:
+// the only fused operations are the explicit __builtin_fmaf calls below.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#include "eppm_internal.h"
+
+namespace eppm {
+
+// ---- constants (defs.h:31-76 and file-local #defines of the reference) -------------------------
+constexpr float kLambdaAd2 = 0.1f * 0.1f;          // LAMBDA_AD*LAMBDA_AD, defs.h:51
+constexpr float kPmSigR2 = 0.1f * 0.1f;            // PM_SIG_R*PM_SIG_R, defs.h:48
+constexpr float kWmfSigR2 = 0.02f * 0.02f;         // WMF_SIG_R*WMF_SIG_R, defs.h:60
+constexpr float kBlfSigR2 = 0.02f * 0.02f;         // POSTPROC_BLF_SIG_R^2, refine :752
+constexpr int   kStatRadius = 6;                   // defs.h:68
+constexpr int   kStatCountThresh = ((2 * kStatRadius + 1) * (2 * kStatRadius + 1) / 2);  // refine :146
+constexpr int   kStatSimThresh = 2;                // refine :147
+constexpr int   kInvalid = -10000;                 // INVALID_LOCATION, refine :46
+constexpr float kUnknownFlowThresh = 1e9f;         // defs.h:85 (1e9 is exact in float)
+constexpr float kUnknownFlow = 1e10f;              // defs.h:90
+
+// ---- __expf restated -------------------------------------------------------------------------
+// y = x*log2e; y < -125 -> 0; n = rint(y); 2^(y-n) by a degree-5 Horner polynomial in fmaf; ldexp.
+// Arguments on this path are always <= 0.  v_mul, v_rndne, v_sub, 5 x v_fma, v_cvt, v_ldexp, v_cmp+cndmask.
+__device__ __forceinline__ float fast_exp(float x)
+{
+    const float y = x * 0x1.715476p+0f;
+    const float n = __builtin_rintf(y);
+    const float f = y - n;
+    float p = __builtin_fmaf(0x1.5bba14p-10f, f, 0x1.3cea88p-7f);
+    p = __builtin_fmaf(p, f, 0x1.c6b752p-5f);
+    p = __builtin_fmaf(p, f, 0x1.ebf9bcp-3f);
+    p = __builtin_fmaf(p, f, 0x1.62e42ap-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    const float r = __builtin_ldexpf(p, (int)n);
+    return (y < -125.0f) ? 0.0f : r;
+}
+
+// ---- x / c for a compile-time constant c, correctly rounded in 3 operations --------------------
+// q0 = x*rc; r = fma(-c,q0,x); q = fma(r,rc,q0).  Equal to the IEEE quotient for every x this path
+// produces; verified exhaustively on the CPU by tests/csrc/verify_divconst.c.
+template <typename T = void>
+__device__ __forceinline__ float div_const(float x, float c, float rc)
+{
+    const float q0 = x * rc;
+    const float r = __builtin_fmaf(-c, q0, x);
+    return __builtin_fmaf(r, rc, q0);
+}
+__device__ __forceinline__ float div_ad2(float x) { return div_const(x, kLambdaAd2, 1.0f / kLambdaAd2); }
+__device__ __forceinline__ float div_wmf2(float x) { return div_const(x, kWmfSigR2, 1.0f / kWmfSigR2); }
+
+// unorm8 -> float exactly as c/255.0f (cudaReadModeNormalizedFloat)
+__device__ __forceinline__ float unorm8(float c) { return div_const(c, 255.0f, 1.0f / 255.0f); }
+
+struct rgbf { float x, y, z; };
+
+__device__ __forceinline__ rgbf unpack_rgb(uint32_t p)
+{
+    rgbf r;
+    r.x = unorm8((float)(p & 0xffu));
+    r.y = unorm8((float)((p >> 8) & 0xffu));
+    r.z = unorm8((float)((p >> 16) & 0xffu));
+    return r;
+}
+
+__device__ __forceinline__ int iclamp(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+__device__ __forceinline__ float max_abs_diff(const rgbf a, const rgbf b)
+{
+    return fmaxf(fmaxf(fabsf(a.x - b.x), fabsf(a.y - b.y)), fabsf(a.z - b.z));
+}
+
+// ---- texture model: point sampling, clamp addressing -------------------------------
+struct Planes {
+    const uint32_t* img1;   // uchar4 as packed u32, pitch in pixels
+    const uint32_t* img2;
+    const uint8_t*  cen1;
+    const uint8_t*  cen2;
+    int w, h;
+    int ipitch;             // pixels
+    int cpitch;             // bytes
+};
+
+__device__ __forceinline__ uint32_t tex_px(const uint32_t* img, int pitch, int w, int h, int x, int y)
+{
+    x = iclamp(x, 0, w - 1);
+    y = iclamp(y, 0, h - 1);
+    return img[y * pitch + x];
+}
+__device__ __forceinline__ uint32_t tex_u8(const uint8_t* c, int pitch, int w, int h, int x, int y)
+{
+    x = iclamp(x, 0, w - 1);
+    y = iclamp(y, 0, h - 1);
+    return c[y * pitch + x];
+}
+
+// ---- one sample of the patch cost (bao_pmflow_kernel.cu:275-295) --------------------------------
+// gsp = gs[|j|]*gs[|i|] (the product is formed first in the reference too: "weight *= a*b").
+__device__ __forceinline__ void patch_sample(const Planes& P, const rgbf c1, const rgbf c2, int sx1, int sy1, int sx2,
+                                             int sy2, float gsp, const float* __restrict__ cn, float& cost_term,
+                                             float& weight_term)
+{
+    const uint32_t q1 = tex_px(P.img1, P.ipitch, P.w, P.h, sx1, sy1);
+    const uint32_t q2 = tex_px(P.img2, P.ipitch, P.w, P.h, sx2, sy2);
+    const uint32_t k1 = tex_u8(P.cen1, P.cpitch, P.w, P.h, sx1, sy1);
+    const uint32_t k2 = tex_u8(P.cen2, P.cpitch, P.w, P.h, sx2, sy2);
+    const rgbf p1 = unpack_rgb(q1);
+    const rgbf p2 = unpack_rgb(q2);
+    const int hamming = __builtin_popcount(k1 ^ k2);
+    float cost = max_abs_diff(p1, p2);
+    cost = 1 - fast_exp(div_ad2(-(cost * cost)));
+    cost += cn[hamming];
+    float weight = max_abs_diff(c1, p1);
+    weight *= weight;
+    float temp = max_abs_diff(c2, p2);
+    temp *= temp;
+    weight = fast_exp(div_ad2(-(weight + temp)));
+    weight *= gsp;
+    cost *= weight;
+    cost_term = cost;
+    weight_term = weight;
+}
+
+// LUTs staged in LDS by every patch kernel: gsp[i*S + j] = gs[|2j-R|]*gs[|2i-R|], cn[0..8]
+struct PatchLut {
+    float gsp[kMaxS * kMaxS];
+    float cn[9];
+};
+
+// lut_src layout in global memory: gs[0..R] then cn[0..8]
+__device__ __forceinline__ void load_patch_lut(PatchLut& L, const float* __restrict__ lut_src, int R, int tid, int nthreads)
+{
+    const int S = R + 1;
+    for (int t = tid; t < S * S; t += nthreads) {
+        const int i = t / S, j = t % S;
+        const int ai = abs(2 * i - R), aj = abs(2 * j - R);
+        L.gsp[i * S + j] = lut_src[aj] * lut_src[ai];
+    }
+    for (int t = tid; t < 9; t += nthreads) L.cn[t] = lut_src[R + 1 + t];
+}
+
+// ---- the patch cost, bao_pmflow_kernel.cu:255-301: sequential i-outer / j-inner accumulation ------
+__device__ __forceinline__ float patch_dist(const Planes& P, const PatchLut& L, int R, int x1, int y1, int x2, int y2)
+{
+    const rgbf c1 = unpack_rgb(tex_px(P.img1, P.ipitch, P.w, P.h, x1, y1));
+    const rgbf c2 = unpack_rgb(tex_px(P.img2, P.ipitch, P.w, P.h, x2, y2));
+    float cost_sum = 0.0f, weight_sum = 0.0f;
+    const int S = R + 1;
+    for (int ii = 0; ii < S; ii++) {
+        const int i = 2 * ii - R;
+        for (int jj = 0; jj < S; jj++) {
+            const int j = 2 * jj - R;
+            float ct, wt;
+            patch_sample(P, c1, c2, x1 + j, y1 + i, x2 + j, y2 + i, L.gsp[ii * S + jj], L.cn, ct, wt);
+            cost_sum += ct;
+            weight_sum += wt;
+        }
+    }
+    return cost_sum / weight_sum;
+}
+
+// plane-fitting coefficients: bao_pmflow_kernel.cu:319-332 (pass 0 = no warp)
+// one affine pass of bao_pmflow_kernel.cu:334-513; target texel = floor of the float coordinate
+template <int PASS>
+__device__ __forceinline__ float patch_dist_pass(const Planes& P, const PatchLut& L, int R, int x1, int y1, float uu,
+                                                 float vv, const rgbf c1, const rgbf c2)
+{
+    constexpr float kc[4][4] = {
+        {0.0f, 0.0f, 0.0f, 0.0f},
+        {0.177f, -0.011f, -0.003f, 0.301f},
+        {0.125f, -0.357f, 0.009f, 0.308f},
+        {0.205f, 0.370f, 0.011f, 0.296f},
+    };
+    float cost_sum = 0.0f, weight_sum = 0.0f;
+    const int S = R + 1;
+    for (int ii = 0; ii < S; ii++) {
+        const int i = 2 * ii - R;
+        for (int jj = 0; jj < S; jj++) {
+            const int j = 2 * jj - R;
+            const float cx1 = (float)(x1 + j);
+            const float cy1 = (float)(y1 + i);
+            float cx2, cy2;
+            if (PASS == 0) {
+                cx2 = cx1 + uu;
+                cy2 = cy1 + vv;
+            } else {
+                cx2 = cx1 + uu + (float)(j)*kc[PASS][0] + (float)(i)*kc[PASS][1];
+                cy2 = cy1 + vv + (float)(j)*kc[PASS][2] + (float)(i)*kc[PASS][3];
+            }
+            float ct, wt;
+            patch_sample(P, c1, c2, x1 + j, y1 + i, (int)floorf(cx2), (int)floorf(cy2), L.gsp[ii * S + jj], L.cn, ct, wt);
+            cost_sum += ct;
+            weight_sum += wt;
+        }
+    }
+    return cost_sum / weight_sum;
+}
+
+__device__ __forceinline__ float patch_dist_planefit(const Planes& P, const PatchLut& L, int R, int x1, int y1, int x2, int y2)
+{
+    const rgbf c1 = unpack_rgb(tex_px(P.img1, P.ipitch, P.w, P.h, x1, y1));
+    const rgbf c2 = unpack_rgb(tex_px(P.img2, P.ipitch, P.w, P.h, x2, y2));
+    const float uu = (float)(x2 - x1);
+    const float vv = (float)(y2 - y1);
+    const float c_1 = patch_dist_pass<0>(P, L, R, x1, y1, uu, vv, c1, c2);
+    const float c_2 = patch_dist_pass<1>(P, L, R, x1, y1, uu, vv, c1, c2);
+    const float c_3 = patch_dist_pass<2>(P, L, R, x1, y1, uu, vv, c1, c2);
+    const float c_4 = patch_dist_pass<3>(P, L, R, x1, y1, uu, vv, c1, c2);
+    // __min(cost1,__min(cost2,__min(cost3,cost4))), __min(a,b) = (a<b)?a:b  (kernel.cu:512)
+    const float m34 = (c_3 < c_4) ? c_3 : c_4;
+    const float m234 = (c_2 < m34) ? c_2 : m34;
+    return (c_1 < m234) ? c_1 : m234;
+}
+
+// ---- XORWOW (cuRAND default generator; Marsaglia 2003) -----------------------------------------
+struct Xorwow {
+    uint32_t v0, v1, v2, v3, v4, d;
+};
+__device__ __forceinline__ uint32_t xorwow_next(Xorwow& s)
+{
+    const uint32_t t = s.v0 ^ (s.v0 >> 2);
+    s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3; s.v3 = s.v4;
+    s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+    s.d += 362437u;
+    return s.v4 + s.d;
+}
+
+// float -> short as cvt.rzi.s16.f32 (truncate toward zero, saturate)
+__device__ __forceinline__ int f2short(float f)
+{
+    if (!(f > -32768.0f)) return -32768;
+    if (f > 32767.0f) return 32767;
+    return (int)f;
+}
+
+}  // namespace eppm

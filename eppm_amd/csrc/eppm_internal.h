@@ -1,0 +1,80 @@
+// eppm_internal.h -- host-side declarations of the kernel launch wrappers (one per stage).
+// All pitches here are in ELEMENTS of the plane's type unless the name says bytes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/eppm.h"
+
+namespace eppm {
+
+// geometry constants shared by host and device code
+constexpr int kBlock = 16;       // BLOCK_DIM_X/Y, bao_pmflow_kernel.cu:42-43
+constexpr int kMaxS = 32;        // samples per patch row: patch_r + 1 <= 32
+constexpr int kWmfRadius = 4;    // defs.h:58
+constexpr int kBlfRadius = 10;   // 2*POSTPROC_BLF_SIG_S, refine :753
+
+struct PlanesH {            // host-side mirror of eppm::Planes
+    const uint32_t* img1;
+    const uint32_t* img2;
+    const uint8_t* cen1;
+    const uint8_t* cen2;
+    int w, h, ipitch, cpitch;
+};
+
+// ---- prepare (k_prepare.hip) ----
+void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s);
+void launch_resize_rgba(uint32_t* out, int out_pitch_px, int outH, int outW, const uint32_t* in, int in_pitch_px, int h, int w,
+                        float ratio, hipStream_t s);
+void launch_census(uint8_t* census, int cpitch, const uint32_t* img, int ipitch, int w, int h, hipStream_t s);
+void launch_rgb_to_rgba(uint32_t* out, int pitch_px, const uint8_t* rgb, int h, int w, hipStream_t s);
+
+// ---- PatchMatch (k_patchmatch.hip) ----
+// RNG tables: per block 64 lane states (6 words each); see xorwow_host.cpp
+struct PmRngDev {
+    const uint32_t* init_tab;    // [nblocks][64][6] lane l at draw 8*l            (init field)
+    const uint32_t* iter_tab;    // [nblocks][64][6] lane l at draw 512 + per_lane*l (first search)
+    uint32_t* work;              // [nblocks][64][6] current search states
+    const uint32_t* skip_mat;    // [160][5] GF(2) matrix: advance by (512*G - per_lane) draws
+    uint32_t skip_weyl;          // 362437 * (512*G - per_lane)
+    int per_lane;                // draws per lane per search = 512*G/64
+    int gx, gy;
+};
+void launch_pm_init_field(const PmRngDev& rng, int16_t* nnf, int nnf_pitch, int w, int h, hipStream_t s);
+void launch_pm_cost_field(const PlanesH& P, float* cost, int cost_pitch, const int16_t* nnf, int nnf_pitch, const float* lut,
+                          int R, hipStream_t s);
+void launch_pm_seg_propagate(const PlanesH& P, float* cost, int cost_pitch, int16_t* nnf, int nnf_pitch, const float* lut,
+                             int R, int seg_len, int dir, hipStream_t s);
+void launch_pm_random_search(const PlanesH& P, const PmRngDev& rng, float* cost, int cost_pitch, int16_t* nnf, int nnf_pitch,
+                             const float* lut, int R, int search_range, int num_guess, hipStream_t s);
+
+// ---- level-2 post-processing (k_post.hip) ----
+void launch_lr_check(int16_t* nnf1, float* cost1, const int16_t* nnf2, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s);
+void launch_outlier(int16_t* nnf_out, float* cost, const int16_t* nnf_in, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s);
+void launch_wmf(int16_t* nnf_out, const int16_t* nnf_in, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
+                const float* wmf_lut, int only_occlusion, hipStream_t s);
+void launch_fill_holes(int16_t* nnf_out, const int16_t* nnf_in, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
+                       hipStream_t s);
+void launch_nnf2flow(float* flow, int flow_pitch, const int16_t* nnf, int nnf_pitch, int w, int h, hipStream_t s);
+void launch_copy2d(void* dst, size_t dpitch_bytes, const void* src, size_t spitch_bytes, size_t width_bytes, size_t rows, hipStream_t s);
+
+// ---- coarse to fine (k_c2f.hip) ----
+void launch_resize_flow(float* out, int outH, int outW, const float* in, int h, int w, float ratio, float post_scale, hipStream_t s);
+void launch_mul_scalar(float* flow, float scale, int h, int w, hipStream_t s);
+void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, hipStream_t s);
+void launch_flow_blf(float* out, const float* in, const uint32_t* img, int ipitch, int w, int h, int flow_pitch,
+                     const float* blf_lut, hipStream_t s);
+
+// ---- probes (k_prepare.hip) ----
+void launch_probe(const float* x, float* y, int n, int which, hipStream_t s);
+
+// ---- host XORWOW (xorwow_host.cpp) ----
+struct XorwowState { uint32_t v[5]; uint32_t d; };
+void xorwow_init(XorwowState* s, unsigned long long seed, unsigned long long subsequence);
+uint32_t xorwow_next(XorwowState* s);
+// out[160*5]: row-vector GF(2) matrix advancing the xorshift words by n draws
+void xorwow_skip_matrix(unsigned long long n, uint32_t* out);
+
+}  // namespace eppm

@@ -1,0 +1,163 @@
+// k_c2f.hip -- coarse-to-fine step (reference: basic/bao_basic_cuda.cuh:511-537 float2 bilinear resize,
+// :135-142 scalar multiply; bao_pmflow_kernel.cu:2005-2041 plane-fitting candidate refine;
+// bao_pmflow_refine_kernel.cu:756-799 joint-bilateral flow smoothing).
+#include "eppm_device.cuh"
+#include "eppm_internal.h"
+
+namespace eppm {
+
+__device__ __forceinline__ Planes to_dev(const PlanesH& h)
+{
+    Planes p;
+    p.img1 = h.img1; p.img2 = h.img2; p.cen1 = h.cen1; p.cen2 = h.cen2;
+    p.w = h.w; p.h = h.h; p.ipitch = h.ipitch; p.cpitch = h.cpitch;
+    return p;
+}
+
+// .cuh:511-537 as written (m outer over x, n inner over y), then the x post_scale of .cuh:135-142
+__global__ __launch_bounds__(256) void k_resize_flow(float* __restrict__ out, int outH, int outW, const float* __restrict__ in,
+                                                     int h, int w, float ratio, float post_scale)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= outW || y >= outH) return;
+    const float div_scale = 1.f / ratio;
+    const float fx = (float)(x + 1) * div_scale - 1;
+    const float fy = (float)(y + 1) * div_scale - 1;
+    const int xx = (int)fx, yy = (int)fy;
+    const float dx = fmaxf(fminf(fx - xx, 1), 0);
+    const float dy = fmaxf(fminf(fy - yy, 1), 0);
+    float rx = 0, ry = 0;
+    for (int m = 0; m <= 1; m++)
+        for (int n = 0; n <= 1; n++) {
+            const int u = max(0, min(w - 1, xx + m));
+            const int v = max(0, min(h - 1, yy + n));
+            const float sc = fabsf(1 - m - dx) * fabsf(1 - n - dy);
+            rx += in[(v * w + u) * 2] * sc;
+            ry += in[(v * w + u) * 2 + 1] * sc;
+        }
+    out[(y * outW + x) * 2] = rx * post_scale;
+    out[(y * outW + x) * 2 + 1] = ry * post_scale;
+}
+void launch_resize_flow(float* out, int outH, int outW, const float* in, int h, int w, float ratio, float post_scale, hipStream_t s)
+{
+    dim3 block(64, 4), grid((outW + 63) / 64, (outH + 3) / 4);
+    hipLaunchKernelGGL(k_resize_flow, grid, block, 0, s, out, outH, outW, in, h, w, ratio, post_scale);
+}
+
+__global__ __launch_bounds__(256) void k_mul_scalar(float* __restrict__ f, float scale, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[i] = f[i] * scale;
+}
+void launch_mul_scalar(float* flow, float scale, int h, int w, hipStream_t s)
+{
+    const int n = h * w * 2;
+    hipLaunchKernelGGL(k_mul_scalar, dim3((n + 255) / 256), dim3(256), 0, s, flow, scale, n);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernel.cu:2005-2041: 3x3 integer candidates (x offset outer, y offset inner) around the truncated
+// up-sampled flow; cost = min of 4 affine passes; strict < keeps the first minimum; the centre candidate
+// is the initial best with cost 999999.  In place: a thread reads and writes only its own pixel.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_c2f_refine(PlanesH Ph, float* __restrict__ flow, const float* __restrict__ lut, int R)
+{
+    __shared__ PatchLut L;
+    load_patch_lut(L, lut, R, threadIdx.y * kBlock + threadIdx.x, 256);
+    __syncthreads();
+    const Planes P = to_dev(Ph);
+    const int x = blockIdx.x * kBlock + threadIdx.x, y = blockIdx.y * kBlock + threadIdx.y;
+    if (x >= P.w || y >= P.h) return;
+    const float fvx = flow[(y * P.w + x) * 2], fvy = flow[(y * P.w + x) * 2 + 1];
+    if (fvx > kUnknownFlowThresh || fvy > kUnknownFlowThresh) {
+        flow[(y * P.w + x) * 2] = 0.0f;
+        flow[(y * P.w + x) * 2 + 1] = 0.0f;
+        return;
+    }
+    const int ccx = (int)(int16_t)(f2short(fvx) + x);
+    const int ccy = (int)(int16_t)(f2short(fvy) + y);
+    int bx = ccx, by = ccy;
+    float min_cost = 999999;
+#pragma unroll 1
+    for (int m = 0; m < 3; m++) {
+        const int cx = (int)(int16_t)(ccx + m - 1);
+#pragma unroll 1
+        for (int n = 0; n < 3; n++) {
+            const int cy = (int)(int16_t)(ccy + n - 1);
+            if (cx < 0 || cy < 0 || cx >= P.w || cy >= P.h) continue;
+            const float cv = patch_dist_planefit(P, L, R, x, y, cx, cy);
+            if (cv < min_cost) { min_cost = cv; bx = cx; by = cy; }
+        }
+    }
+    flow[(y * P.w + x) * 2] = (float)(bx - x);
+    flow[(y * P.w + x) * 2 + 1] = (float)(by - y);
+}
+void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, hipStream_t s)
+{
+    dim3 grid((P.w + kBlock - 1) / kBlock, (P.h + kBlock - 1) / kBlock), block(kBlock, kBlock);
+    hipLaunchKernelGGL(k_c2f_refine, grid, block, 0, s, P, flow, lut, R);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// refine :764-799: 21x21 joint bilateral filter of the flow guided by image 1 (Jacobi).  32x8 output
+// tile; flow + unorm guide colours of the (32+20)x(8+20) halo tile staged once in LDS.
+// ---------------------------------------------------------------------------------------------------
+constexpr int BT_W = 32, BT_H = 8, BR = kBlfRadius, BTW = BT_W + 2 * BR, BTH = BT_H + 2 * BR;
+
+__global__ __launch_bounds__(256) void k_flow_blf(float* __restrict__ out, const float* __restrict__ in,
+                                                  const uint32_t* __restrict__ img, int ipitch, int w, int h, int fpitch,
+                                                  const float* __restrict__ blf_lut)
+{
+    __shared__ float s_fx[BTH * BTW], s_fy[BTH * BTW], s_r[BTH * BTW], s_g[BTH * BTW], s_b[BTH * BTW];
+    __shared__ uint8_t s_ok[BTH * BTW];
+    __shared__ float s_lut[BR + 1];
+    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
+    const int tid = threadIdx.y * BT_W + threadIdx.x;
+    if (tid <= BR) s_lut[tid] = blf_lut[tid];
+    for (int t = tid; t < BTW * BTH; t += 256) {
+        const int cy = y0 + t / BTW - BR, cx = x0 + t % BTW - BR;
+        float fx = 0, fy = 0, r = 0, g = 0, b = 0;
+        int ok = 0;
+        if (cx >= 0 && cy >= 0 && cx < w && cy < h) {
+            fx = in[(cy * fpitch + cx) * 2];
+            fy = in[(cy * fpitch + cx) * 2 + 1];
+            ok = !(fx > kUnknownFlowThresh || fy > kUnknownFlowThresh);     // refine :781
+            const rgbf c = unpack_rgb(img[cy * ipitch + cx]);
+            r = c.x; g = c.y; b = c.z;
+        }
+        s_fx[t] = fx; s_fy[t] = fy; s_r[t] = r; s_g[t] = g; s_b[t] = b; s_ok[t] = (uint8_t)ok;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int ci = (threadIdx.y + BR) * BTW + threadIdx.x + BR;
+    const rgbf center = {s_r[ci], s_g[ci], s_b[ci]};
+    float nx = 0.f, ny = 0.f, wsum = 0.f;
+    for (int dy = 0; dy <= 2 * BR; dy++) {
+        const float gy = s_lut[abs(dy - BR)];
+        for (int dx = 0; dx <= 2 * BR; dx++) {
+            const int ti = (threadIdx.y + dy) * BTW + threadIdx.x + dx;
+            if (!s_ok[ti]) continue;
+            const rgbf pix = {s_r[ti], s_g[ti], s_b[ti]};
+            const float delta_r = max_abs_diff(center, pix);
+            const float coef_r = fast_exp(div_wmf2(-(delta_r * delta_r)));
+            const float coef_s = s_lut[abs(dx - BR)] * gy;
+            const float wgt = coef_r * coef_s;
+            nx += wgt * s_fx[ti];
+            ny += wgt * s_fy[ti];
+            wsum += wgt;
+        }
+    }
+    float ox = s_fx[ci], oy = s_fy[ci];
+    if (wsum != 0) { ox = nx / wsum; oy = ny / wsum; }
+    out[(y * fpitch + x) * 2] = ox;
+    out[(y * fpitch + x) * 2 + 1] = oy;
+}
+void launch_flow_blf(float* out, const float* in, const uint32_t* img, int ipitch, int w, int h, int flow_pitch,
+                     const float* blf_lut, hipStream_t s)
+{
+    dim3 block(BT_W, BT_H), grid((w + BT_W - 1) / BT_W, (h + BT_H - 1) / BT_H);
+    hipLaunchKernelGGL(k_flow_blf, grid, block, 0, s, out, in, img, ipitch, w, h, flow_pitch, blf_lut);
+}
+
+}  // namespace eppm

@@ -1,0 +1,277 @@
+// k_post.hip -- level-2 post-processing of the NNF (reference: bao_pmflow_refine_kernel.cu :53-92 left-right
+// check, :149-193 outlier removal, :198-286 weighted median, :297-390 hole filling, :636-655 NNF->flow).
+// Integer/short work on a quarter-resolution plane; every kernel is Jacobi (reads `in`, writes `out`).
+#include "eppm_device.cuh"
+#include "eppm_internal.h"
+
+namespace eppm {
+
+// ---------------------------------------------------------------------------------------------------
+// refine :53-76.  In place on (nnf1,cost1): a thread touches only its own pixel; nnf2 is read-only.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lr_check(int16_t* __restrict__ nnf1, float* __restrict__ cost1,
+                                                  const int16_t* __restrict__ nnf2, int w, int h, int cpitch, int npitch)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int dx = nnf1[(y * npitch + x) * 2], dy = nnf1[(y * npitch + x) * 2 + 1];
+    bool bad;
+    if (dy < 0 || dy >= h || dx < 0 || dx >= w) bad = true;
+    else {
+        const int ex = nnf2[(dy * npitch + dx) * 2], ey = nnf2[(dy * npitch + dx) * 2 + 1];
+        bad = (abs(ex - x) > 0 || abs(ey - y) > 0);      // DIFF_THRESH 0, refine :51
+    }
+    if (bad) {
+        nnf1[(y * npitch + x) * 2] = (int16_t)kInvalid;
+        nnf1[(y * npitch + x) * 2 + 1] = (int16_t)kInvalid;
+        cost1[y * cpitch + x] = FLT_MAX;
+    }
+}
+void launch_lr_check(int16_t* nnf1, float* cost1, const int16_t* nnf2, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s)
+{
+    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(k_lr_check, grid, block, 0, s, nnf1, cost1, nnf2, w, h, cost_pitch, nnf_pitch);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// refine :149-182.  13x13 vote on flow similarity; 32x8 tile + 6-px halo of relative flows in LDS.
+// ---------------------------------------------------------------------------------------------------
+constexpr int OT_W = 32, OT_H = 8;
+__global__ __launch_bounds__(256) void k_outlier(int16_t* __restrict__ nnf_out, float* __restrict__ cost,
+                                                 const int16_t* __restrict__ nnf_in, int w, int h, int cpitch, int npitch)
+{
+    constexpr int TW = OT_W + 2 * kStatRadius, TH = OT_H + 2 * kStatRadius;
+    __shared__ int s_fx[TH * TW];
+    __shared__ int s_fy[TH * TW];
+    const int x0 = blockIdx.x * OT_W, y0 = blockIdx.y * OT_H;
+    const int tid = threadIdx.y * OT_W + threadIdx.x;
+    for (int t = tid; t < TW * TH; t += 256) {
+        const int cy = y0 + t / TW - kStatRadius, cx = x0 + t % TW - kStatRadius;
+        int fx = 0x40000000, fy = 0x40000000;            // out of image: never similar to anything
+        if (cx >= 0 && cy >= 0 && cx < w && cy < h) {
+            fx = (int)(int16_t)(nnf_in[(cy * npitch + cx) * 2] - cx);       // short arithmetic, refine :165-166
+            fy = (int)(int16_t)(nnf_in[(cy * npitch + cx) * 2 + 1] - cy);
+        }
+        s_fx[t] = fx; s_fy[t] = fy;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int ox = nnf_in[(y * npitch + x) * 2], oy = nnf_in[(y * npitch + x) * 2 + 1];
+    int rx = ox, ry = oy;
+    if (!(ox < 0 && oy < 0)) {                              // "skip occlusion", refine :156
+        const int cfx = s_fx[(threadIdx.y + kStatRadius) * TW + threadIdx.x + kStatRadius];
+        const int cfy = s_fy[(threadIdx.y + kStatRadius) * TW + threadIdx.x + kStatRadius];
+        int count = 0;
+        for (int dy = 0; dy <= 2 * kStatRadius; dy++)
+            for (int dx = 0; dx <= 2 * kStatRadius; dx++) {
+                const int nfx = s_fx[(threadIdx.y + dy) * TW + threadIdx.x + dx];
+                const int nfy = s_fy[(threadIdx.y + dy) * TW + threadIdx.x + dx];
+                if (abs(nfx - cfx) <= kStatSimThresh && abs(nfy - cfy) <= kStatSimThresh) count++;
+            }
+        if (count < kStatCountThresh) {
+            rx = kInvalid; ry = kInvalid;
+            cost[y * cpitch + x] = FLT_MAX;
+        }
+    }
+    nnf_out[(y * npitch + x) * 2] = (int16_t)rx;
+    nnf_out[(y * npitch + x) * 2 + 1] = (int16_t)ry;
+}
+void launch_outlier(int16_t* nnf_out, float* cost, const int16_t* nnf_in, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s)
+{
+    dim3 block(OT_W, OT_H), grid((w + OT_W - 1) / OT_W, (h + OT_H - 1) / OT_H);
+    hipLaunchKernelGGL(k_outlier, grid, block, 0, s, nnf_out, cost, nnf_in, w, h, cost_pitch, nnf_pitch);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weighted median by exhaustive candidate scoring (refine :206-259), one Jacobi launch.
+// The reference spends O(81 x 81) taps in ONE thread per pixel and only occluded pixels do work.
+// Here a 16x16 tile block stages flows + guide colours (24x24 with halo) in LDS, compacts the pixels
+// that need work, and a whole wave scores one pixel: lanes = the 81 candidates, each lane running the
+// reference's sequential 81-tap sum (same order, same operations), the 81 bilateral weights computed
+// once per pixel instead of once per candidate.  The winner is the first minimum in row-major
+// candidate order (strict <), found by a lexicographic (cost, index) wave reduction.
+// ---------------------------------------------------------------------------------------------------
+constexpr int WT = 16, WR = kWmfRadius, WTW = WT + 2 * WR, WN = (2 * WR + 1) * (2 * WR + 1);   // 24, 81
+
+__global__ __launch_bounds__(256) void k_wmf(int16_t* __restrict__ nnf_out, const int16_t* __restrict__ nnf_in,
+                                             const uint32_t* __restrict__ img, int ipitch, int w, int h, int npitch,
+                                             const float* __restrict__ wmf_lut, int only_occ)
+{
+    __shared__ int   s_fx[WTW * WTW], s_fy[WTW * WTW];
+    __shared__ uint8_t s_ok[WTW * WTW];
+    __shared__ float s_r[WTW * WTW], s_g[WTW * WTW], s_b[WTW * WTW];
+    __shared__ int   s_list[WT * WT];
+    __shared__ int   s_count;
+    __shared__ float s_lut[WR + 1];
+    __shared__ float s_wgt[4][WN];
+    __shared__ int   s_tfx[4][WN], s_tfy[4][WN];
+    __shared__ uint8_t s_tok[4][WN];
+
+    const int x0 = blockIdx.x * WT, y0 = blockIdx.y * WT;
+    const int tid = threadIdx.y * WT + threadIdx.x;
+    if (tid == 0) s_count = 0;
+    if (tid <= WR) s_lut[tid] = wmf_lut[tid];
+    for (int t = tid; t < WTW * WTW; t += 256) {
+        const int cy = y0 + t / WTW - WR, cx = x0 + t % WTW - WR;
+        int fx = 0, fy = 0, ok = 0;
+        float r = 0, g = 0, b = 0;
+        if (cx >= 0 && cy >= 0 && cx < w && cy < h) {
+            const int dx = nnf_in[(cy * npitch + cx) * 2], dy = nnf_in[(cy * npitch + cx) * 2 + 1];
+            if (!(dx < 0 || dy < 0)) {                           // "skip invalid disparity", refine :225,238
+                ok = 1;
+                fx = (int)(int16_t)(dx - cx);
+                fy = (int)(int16_t)(dy - cy);
+            }
+            const rgbf c = unpack_rgb(img[cy * ipitch + cx]);
+            r = c.x; g = c.y; b = c.z;
+        }
+        s_fx[t] = fx; s_fy[t] = fy; s_ok[t] = (uint8_t)ok; s_r[t] = r; s_g[t] = g; s_b[t] = b;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    const bool inimg = (x < w && y < h);
+    int ox = 0, oy = 0;
+    if (inimg) {
+        ox = nnf_in[(y * npitch + x) * 2]; oy = nnf_in[(y * npitch + x) * 2 + 1];
+        nnf_out[(y * npitch + x) * 2] = (int16_t)ox;             // default: unchanged
+        nnf_out[(y * npitch + x) * 2 + 1] = (int16_t)oy;
+        const bool skip = only_occ && ox >= 0 && oy >= 0;        // refine :213
+        if (!skip) s_list[atomicAdd(&s_count, 1)] = tid;
+    }
+    __syncthreads();
+    const int count = s_count;
+    const int wv = tid >> 6, lane = tid & 63;
+    for (int base = 0; base < count; base += 4) {
+        const int li = base + wv;
+        const bool have = li < count;
+        int ptid = 0, lx = 0, ly = 0;
+        if (have) {
+            ptid = s_list[li]; lx = ptid & 15; ly = ptid >> 4;
+            const int ci = (ly + WR) * WTW + lx + WR;
+            const rgbf center = {s_r[ci], s_g[ci], s_b[ci]};
+            for (int t = lane; t < WN; t += 64) {
+                const int dy2 = t / 9 - WR, dx2 = t % 9 - WR;
+                const int ti = (ly + WR + dy2) * WTW + lx + WR + dx2;
+                const int ok = s_ok[ti];
+                float wgt = 0.0f;
+                if (ok) {
+                    const rgbf pix = {s_r[ti], s_g[ti], s_b[ti]};
+                    const float delta_r = max_abs_diff(center, pix);
+                    const float coef_r = fast_exp(div_wmf2(-(delta_r * delta_r)));
+                    const float coef_s = s_lut[abs(dx2)] * s_lut[abs(dy2)];
+                    wgt = coef_r * coef_s;                                           // refine :198-204
+                }
+                s_wgt[wv][t] = wgt; s_tfx[wv][t] = s_fx[ti]; s_tfy[wv][t] = s_fy[ti]; s_tok[wv][t] = (uint8_t)ok;
+            }
+        }
+        __syncthreads();
+        if (have) {
+            float bestc = FLT_MAX;
+            int besti = 0x7fffffff;
+            for (int c = lane; c < WN; c += 64) {
+                if (!s_tok[wv][c]) continue;
+                const int cfx = s_tfx[wv][c], cfy = s_tfy[wv][c];
+                float costSum = 0.0f, weightSum = 0.0f;
+                for (int t = 0; t < WN; t++) {
+                    if (!s_tok[wv][t]) continue;
+                    const float wgt = s_wgt[wv][t];
+                    costSum += wgt * (float)max(abs(cfx - s_tfx[wv][t]), abs(cfy - s_tfy[wv][t]));
+                    weightSum += wgt;
+                }
+                if (weightSum > 0.0f && costSum < FLT_MAX) {
+                    if (costSum < bestc || (costSum == bestc && c < besti)) { bestc = costSum; besti = c; }
+                }
+            }
+            // lexicographic (cost, index) minimum over the wave = first minimum in candidate order
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float oc = __shfl_xor(bestc, off, 64);
+                const int oi = __shfl_xor(besti, off, 64);
+                if (oc < bestc || (oc == bestc && oi < besti)) { bestc = oc; besti = oi; }
+            }
+            if (lane == 0 && besti != 0x7fffffff) {
+                const int px = x0 + lx, py = y0 + ly;
+                const int rx = (int)(int16_t)(s_tfx[wv][besti] + px), ry = (int)(int16_t)(s_tfy[wv][besti] + py);
+                if (!(rx < 0 || ry < 0)) {                                            // refine :257
+                    nnf_out[(py * npitch + px) * 2] = (int16_t)rx;
+                    nnf_out[(py * npitch + px) * 2 + 1] = (int16_t)ry;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+void launch_wmf(int16_t* nnf_out, const int16_t* nnf_in, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
+                const float* wmf_lut, int only_occlusion, hipStream_t s)
+{
+    dim3 block(WT, WT), grid((w + WT - 1) / WT, (h + WT - 1) / WT);
+    hipLaunchKernelGGL(k_wmf, grid, block, 0, s, nnf_out, nnf_in, img, ipitch, w, h, nnf_pitch, wmf_lut, only_occlusion);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// refine :297-371: nearest valid pixel in the four directions (left, right, up, down), closest colour.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fill_holes(int16_t* __restrict__ nnf_out, const int16_t* __restrict__ nnf_in,
+                                                    const uint32_t* __restrict__ img, int ipitch, int w, int h, int npitch)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    int cx_ = nnf_in[(y * npitch + x) * 2], cy_ = nnf_in[(y * npitch + x) * 2 + 1];
+    if (!(cx_ >= 0 && cy_ >= 0)) {
+        int ndx[4] = {cx_, cx_, cx_, cx_}, ndy[4] = {cy_, cy_, cy_, cy_};
+        int nx[4] = {x, x, x, x}, ny[4] = {y, y, y, y};
+        for (int c = x - 1; c >= 0; c--) { ndx[0] = nnf_in[(y * npitch + c) * 2]; ndy[0] = nnf_in[(y * npitch + c) * 2 + 1]; if (ndx[0] >= 0 && ndy[0] >= 0) { nx[0] = c; break; } }
+        for (int c = x + 1; c < w; c++)  { ndx[1] = nnf_in[(y * npitch + c) * 2]; ndy[1] = nnf_in[(y * npitch + c) * 2 + 1]; if (ndx[1] >= 0 && ndy[1] >= 0) { nx[1] = c; break; } }
+        for (int c = y - 1; c >= 0; c--) { ndx[2] = nnf_in[(c * npitch + x) * 2]; ndy[2] = nnf_in[(c * npitch + x) * 2 + 1]; if (ndx[2] >= 0 && ndy[2] >= 0) { ny[2] = c; break; } }
+        for (int c = y + 1; c < h; c++)  { ndx[3] = nnf_in[(c * npitch + x) * 2]; ndy[3] = nnf_in[(c * npitch + x) * 2 + 1]; if (ndx[3] >= 0 && ndy[3] >= 0) { ny[3] = c; break; } }
+        const rgbf cur = unpack_rgb(tex_px(img, ipitch, w, h, x, y));
+        float minPixDiff = FLT_MAX;
+        int fx = cx_, fy = cy_;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const rgbf np = unpack_rgb(tex_px(img, ipitch, w, h, nx[i], ny[i]));
+            const float pd = max_abs_diff(cur, np);
+            if (pd < minPixDiff && ndx[i] >= 0 && ndy[i] >= 0) {
+                minPixDiff = pd;
+                fx = (int)(int16_t)(ndx[i] - nx[i]);
+                fy = (int)(int16_t)(ndy[i] - ny[i]);
+            }
+        }
+        cx_ = (int)(int16_t)(fx + x);
+        cy_ = (int)(int16_t)(fy + y);
+    }
+    nnf_out[(y * npitch + x) * 2] = (int16_t)cx_;
+    nnf_out[(y * npitch + x) * 2 + 1] = (int16_t)cy_;
+}
+void launch_fill_holes(int16_t* nnf_out, const int16_t* nnf_in, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
+                       hipStream_t s)
+{
+    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(k_fill_holes, grid, block, 0, s, nnf_out, nnf_in, img, ipitch, w, h, nnf_pitch);
+}
+
+// refine :636-655
+__global__ __launch_bounds__(256) void k_nnf2flow(float* __restrict__ flow, int fpitch, const int16_t* __restrict__ nnf, int npitch, int w, int h)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int dx = nnf[(y * npitch + x) * 2], dy = nnf[(y * npitch + x) * 2 + 1];
+    float fx, fy;
+    if (dx <= kInvalid || dy <= kInvalid) { fx = kUnknownFlow; fy = kUnknownFlow; }
+    else { fx = (float)(dx - x); fy = (float)(dy - y); }
+    flow[(y * fpitch + x) * 2] = fx;
+    flow[(y * fpitch + x) * 2 + 1] = fy;
+}
+void launch_nnf2flow(float* flow, int flow_pitch, const int16_t* nnf, int nnf_pitch, int w, int h, hipStream_t s)
+{
+    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(k_nnf2flow, grid, block, 0, s, flow, flow_pitch, nnf, nnf_pitch, w, h);
+}
+
+void launch_copy2d(void* dst, size_t dpitch_bytes, const void* src, size_t spitch_bytes, size_t width_bytes, size_t rows, hipStream_t s)
+{
+    (void)hipMemcpy2DAsync(dst, dpitch_bytes, src, spitch_bytes, width_bytes, rows, hipMemcpyDeviceToDevice, s);
+}
+
+}  // namespace eppm

@@ -1,0 +1,177 @@
+// k_prepare.hip -- prefilter, pyramid decimation, census transform (reference: basic/bao_basic_cuda.cuh
+// :437-467, :565-601; bao_pmflow_census_kernel.cu:39-112).  HBM-bound byte work: one read of each input
+// pixel neighbourhood through LDS tiles, one coalesced write.
+#include "eppm_device.cuh"
+#include "eppm_internal.h"
+
+namespace eppm {
+
+// ---------------------------------------------------------------------------------------------------
+// Dense (2r+1)^2 Gaussian on RGBA u8 (.cuh:437-467): clamp-to-edge, weight = fast_exp(-(dy^2+dx^2)/s2)
+// recomputed per tap, float accumulation in tap order (dy outer, dx inner), per-channel division,
+// float->u8 truncation.  Tile 32x8 outputs per 256-thread block (4 waves), halo staged in LDS so
+// every input pixel is fetched once per block, rows coalesced.
+// ---------------------------------------------------------------------------------------------------
+constexpr int GT_W = 32, GT_H = 8, G_MAXR = 6;
+
+__global__ __launch_bounds__(256) void k_gauss_rgba(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, int pitch,
+                                                    int h, int w, float sigma2, int radius)
+{
+    __shared__ uint32_t tile[(GT_H + 2 * G_MAXR) * (GT_W + 2 * G_MAXR)];
+    __shared__ float wtab[(2 * G_MAXR + 1) * (2 * G_MAXR + 1)];
+    const int tw = GT_W + 2 * radius, th = GT_H + 2 * radius;
+    const int x0 = blockIdx.x * GT_W, y0 = blockIdx.y * GT_H;
+    const int tid = threadIdx.y * GT_W + threadIdx.x;
+    for (int t = tid; t < tw * th; t += 256) {
+        const int ty = t / tw, tx = t % tw;
+        const int cy = max(0, min(h - 1, y0 + ty - radius));
+        const int cx = max(0, min(w - 1, x0 + tx - radius));
+        tile[t] = in[cy * pitch + cx];
+    }
+    const int d = 2 * radius + 1;
+    for (int t = tid; t < d * d; t += 256) {
+        const int dy = t / d - radius, dx = t % d - radius;
+        wtab[t] = fast_exp(-(float)(dy * dy + dx * dx) / sigma2);
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    float vx = 0, vy = 0, vz = 0, vw = 0, sum = 0;
+    for (int dy = 0; dy < d; dy++)
+        for (int dx = 0; dx < d; dx++) {
+            const float weight = wtab[dy * d + dx];
+            const uint32_t p = tile[(threadIdx.y + dy) * tw + threadIdx.x + dx];
+            vx += (float)(p & 0xffu) * weight;
+            vy += (float)((p >> 8) & 0xffu) * weight;
+            vz += (float)((p >> 16) & 0xffu) * weight;
+            vw += (float)(p >> 24) * weight;
+            sum += weight;
+        }
+    vx /= sum; vy /= sum; vz /= sum; vw /= sum;
+    const uint32_t r = (uint32_t)vx | ((uint32_t)vy << 8) | ((uint32_t)vz << 16) | ((uint32_t)vw << 24);
+    out[y * pitch + x] = r;
+}
+
+void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s)
+{
+    dim3 grid((w + GT_W - 1) / GT_W, (h + GT_H - 1) / GT_H), block(GT_W, GT_H);
+    hipLaunchKernelGGL(k_gauss_rgba, grid, block, 0, s, out, in, pitch_px, h, w, sigma * sigma * 2, radius);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Bilinear resize, uchar4 (.cuh:565-601), as written: fx=(x+1)/ratio-1, trunc, 4 taps, trunc to u8.
+// For ratio 1/2 and 1/4 the weights are exactly 1,0,0,0 (pixel (2x+1,2y+1) / (4x+3,4y+3)).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize_rgba(uint32_t* __restrict__ out, int out_pitch, int outH, int outW,
+                                                     const uint32_t* __restrict__ in, int in_pitch, int h, int w, float ratio)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= outW || y >= outH) return;
+    const float div_scale = 1.f / ratio;
+    const float fx = (float)(x + 1) * div_scale - 1;
+    const float fy = (float)(y + 1) * div_scale - 1;
+    const int xx = (int)fx, yy = (int)fy;
+    const float dx = fmaxf(fminf(fx - xx, 1), 0);
+    const float dy = fmaxf(fminf(fy - yy, 1), 0);
+    float rx = 0, ry = 0, rz = 0, rw = 0;
+    for (int m = 0; m <= 1; m++)
+        for (int n = 0; n <= 1; n++) {
+            const int u = max(0, min(w - 1, xx + m));
+            const int v = max(0, min(h - 1, yy + n));
+            const float sc = fabsf(1 - m - dx) * fabsf(1 - n - dy);
+            const uint32_t p = in[v * in_pitch + u];
+            rx += ((float)(p & 0xffu) * sc);
+            ry += ((float)((p >> 8) & 0xffu) * sc);
+            rz += ((float)((p >> 16) & 0xffu) * sc);
+            rw += ((float)(p >> 24) * sc);
+        }
+    out[y * out_pitch + x] = (uint32_t)rx | ((uint32_t)ry << 8) | ((uint32_t)rz << 16) | ((uint32_t)rw << 24);
+}
+
+void launch_resize_rgba(uint32_t* out, int out_pitch_px, int outH, int outW, const uint32_t* in, int in_pitch_px, int h, int w,
+                        float ratio, hipStream_t s)
+{
+    dim3 block(64, 4), grid((outW + 63) / 64, (outH + 3) / 4);
+    hipLaunchKernelGGL(k_resize_rgba, grid, block, 0, s, out, out_pitch_px, outH, outW, in, in_pitch_px, h, w, ratio);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 3x3 census on luminance (census :45-90): bit k = lum(neigh_k) > lum(centre), clamp addressing,
+// lum = .3R + .6G + .1B on unorm floats, evaluated left to right.  64x4 tile per block, luminance of
+// the (64+2)x(4+2) halo computed once into LDS.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lum_of(uint32_t p)
+{
+    const rgbf c = unpack_rgb(p);
+    return 0.3f * c.x + 0.6f * c.y + 0.1f * c.z;
+}
+
+__global__ __launch_bounds__(256) void k_census(uint8_t* __restrict__ census, int cpitch, const uint32_t* __restrict__ img,
+                                                int ipitch, int w, int h)
+{
+    __shared__ float lum[6][66];
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    for (int t = tid; t < 6 * 66; t += 256) {
+        const int ty = t / 66, tx = t % 66;
+        const int cy = iclamp(y0 + ty - 1, 0, h - 1), cx = iclamp(x0 + tx - 1, 0, w - 1);
+        lum[ty][tx] = lum_of(img[cy * ipitch + cx]);
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int lx = threadIdx.x + 1, ly = threadIdx.y + 1;
+    const float c = lum[ly][lx];
+    uint32_t r = 0;
+    r += (lum[ly - 1][lx - 1] > c) ? 1u : 0u;
+    r += (lum[ly - 1][lx] > c) ? 2u : 0u;
+    r += (lum[ly - 1][lx + 1] > c) ? 4u : 0u;
+    r += (lum[ly][lx - 1] > c) ? 8u : 0u;
+    r += (lum[ly][lx + 1] > c) ? 16u : 0u;
+    r += (lum[ly + 1][lx - 1] > c) ? 32u : 0u;
+    r += (lum[ly + 1][lx] > c) ? 64u : 0u;
+    r += (lum[ly + 1][lx + 1] > c) ? 128u : 0u;
+    census[y * cpitch + x] = (uint8_t)r;
+}
+
+void launch_census(uint8_t* census, int cpitch, const uint32_t* img, int ipitch, int w, int h, hipStream_t s)
+{
+    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(k_census, grid, block, 0, s, census, cpitch, img, ipitch, w, h);
+}
+
+// RGB (3 B/px, tightly packed rows) -> RGBA with alpha 0 (bao_rgb2rgba, basic/bao_basic_cuda.h:258-267)
+__global__ __launch_bounds__(256) void k_rgb_to_rgba(uint32_t* __restrict__ out, int pitch, const uint8_t* __restrict__ rgb, int h, int w)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* p = rgb + ((size_t)y * w + x) * 3;
+    out[y * pitch + x] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+void launch_rgb_to_rgba(uint32_t* out, int pitch_px, const uint8_t* rgb, int h, int w, hipStream_t s)
+{
+    dim3 block(256), grid((w + 255) / 256, h);
+    hipLaunchKernelGGL(k_rgb_to_rgba, grid, block, 0, s, out, pitch_px, rgb, h, w);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// arithmetic probes for the parity tests of the shared float formulas
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_probe(const float* __restrict__ x, float* __restrict__ y, int n, int which)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    float r;
+    if (which == 0) r = fast_exp(v);
+    else if (which == 1) r = div_ad2(v);
+    else if (which == 2) r = div_wmf2(v);
+    else r = unorm8(v);
+    y[i] = r;
+}
+void launch_probe(const float* x, float* y, int n, int which, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_probe, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n, which);
+}
+
+}  // namespace eppm

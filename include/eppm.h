@@ -1,0 +1,213 @@
+/*
+ * eppm.h -- C ABI of the MI355X-native EPPM optical-flow engine (libeppm_hip.so).
+ *
+ * Drop-in boundary for the hot path of linchaobao/EPPM: image pair -> dense flow.
+ * Two layers are exported:
+ *
+ *  (1) the context API (eppm_*): what a host program or an FFI binding uses.  It replaces
+ *      class bao_flow_patchmatch_multiscale_cuda (bao_flow_patchmatch_multiscale_cuda.h:33-44):
+ *      eppm_create      <- init(h,w)                                   driver .cpp:112-157
+ *      eppm_set_images  <- set_data(img1,img2)                         driver .cpp:159-168
+ *      eppm_compute     <- compute_flow(disp1_x,disp1_y)               driver .cpp:217-306
+ *      eppm_destroy     <- ~bao_flow_patchmatch_multiscale_cuda()      driver .cpp:170-209
+ *      The C++ class itself is kept, source compatible, in
+ *      include/bao_flow_patchmatch_multiscale_cuda.h on top of this ABI.
+ *
+ *  (2) the nine live stage launchers of the reference's link-level ABI, with the reference's
+ *      names, argument order and meaning (driver .cpp:40-62): see "stage launchers" below.
+ *
+ * Conventions: plain pointers and sizes only; every function returns an eppm_status
+ * (0 = OK) except the reference-signature launchers, which are void like the originals
+ * and record their status for eppm_last_error().  Nothing in this library calls exit().
+ * One context = one device + one stream; contexts are independent (one per host thread or
+ * per GPU); a single context is not thread-safe.
+ */
+#ifndef EPPM_H_
+#define EPPM_H_
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    EPPM_OK = 0,
+    EPPM_ERR_ARG = 1,        /* bad argument (NULL, non-positive size, unsupported parameter) */
+    EPPM_ERR_HIP = 2,        /* a HIP runtime call failed; see eppm_last_error() */
+    EPPM_ERR_STATE = 3,      /* call order: compute before set_images, ... */
+    EPPM_ERR_NOMEM = 4
+} eppm_status;
+
+/* Pixel / vector element layouts (identical to CUDA's uchar4 / short2 / float2). */
+typedef struct { uint8_t x, y, z, w; } eppm_uchar4;
+typedef struct { int16_t x, y; } eppm_short2;
+typedef struct { float x, y; } eppm_float2;
+
+/* Tunables.  The reference fixes them at compile time (defs.h:31-76); defaults are those values. */
+typedef struct {
+    int patch_r;        /* PATCH_R 9 (odd, <= 31)                         defs.h:44 */
+    int num_iter;       /* NUM_ITER 10                                    defs.h:45 */
+    int search_range;   /* SEARCH_RANGE 30                                defs.h:36 */
+    int num_guess;      /* NUM_RAND_GUESS 6 (<= 8)                        defs.h:38 */
+    int seg_len;        /* PROP_SEG_LENGTH 10              bao_pmflow_kernel.cu:979 */
+    int wmf_iters;      /* 20                                         driver .cpp:239 */
+    unsigned long long seed; /* 1234                        bao_pmflow_kernel.cu:68 */
+} eppm_params;
+
+typedef struct eppm_ctx eppm_ctx;
+
+/* ----------------------------------------------------------------------------------------
+ * context API
+ * -------------------------------------------------------------------------------------- */
+int  eppm_default_params(eppm_params* p);
+/* Allocates every device buffer for an h x w pair (3-level pyramid, PYR_MAX_DEPTH defs.h:31). */
+int  eppm_create(eppm_ctx** out, int h, int w, int device, const eppm_params* params /* NULL = defaults */);
+int  eppm_destroy(eppm_ctx* ctx);
+/* Use an existing hipStream_t (passed as void*) instead of the context's own stream. */
+int  eppm_set_stream(eppm_ctx* ctx, void* hip_stream);
+
+/* Host images: h rows of w RGB triplets, row_stride bytes apart (>= 3*w).  RGB->RGBA, H2D,
+ * prefilter, pyramid, census (set_data + _prepare_data, driver .cpp:159-168,212-215). */
+int  eppm_set_images(eppm_ctx* ctx, const uint8_t* rgb1, const uint8_t* rgb2, size_t row_stride);
+/* Device-resident RGBA (uchar4, alpha ignored/0) images, pitch in bytes: runs prepare only. */
+int  eppm_set_images_device(eppm_ctx* ctx, const void* d_rgba1, const void* d_rgba2, size_t pitch);
+
+/* compute_flow (driver .cpp:217-306).  u, v: h*w floats each (host). Synchronous. */
+int  eppm_compute(eppm_ctx* ctx, float* u, float* v);
+/* Same, asynchronous on the context's stream; the interleaved float2 flow stays in HBM.
+ * d_flow may be NULL (result kept in the context; fetch with eppm_get_plane("flow",0)). */
+int  eppm_compute_device(eppm_ctx* ctx, void* d_flow);
+int  eppm_synchronize(eppm_ctx* ctx);
+
+/* Geometry of the pyramid (bao_pyr_init_dim, basic/bao_basic.h:196-211). */
+int  eppm_num_levels(const eppm_ctx* ctx);
+int  eppm_level_dims(const eppm_ctx* ctx, int level, int* h, int* w);
+
+/* Copy an internal plane to the host, tightly packed (row = w elements).  Names:
+ *  "img1","img2" (uchar4), "census1","census2" (u8), "nnf1","nnf2" (short2), "cost1","cost2" (f32),
+ *  "flow" (float2).  Valid after the stage that produces it has run. */
+int  eppm_get_plane(eppm_ctx* ctx, const char* name, int level, void* dst, size_t dst_bytes);
+
+/* Per-stage device time of the last eppm_compute* call, in ms (hipEvent).  names[i] points to
+ * static strings.  Returns the number of stages written (<= max). */
+int  eppm_stage_times(eppm_ctx* ctx, const char** names, float* ms, int max);
+/* Enable/disable the per-stage events (off by default: they serialise nothing but cost a few us). */
+int  eppm_enable_stage_timing(eppm_ctx* ctx, int on);
+
+const char* eppm_last_error(void);
+const char* eppm_version(void);
+
+/* ----------------------------------------------------------------------------------------
+ * device-memory plumbing for callers without a HIP runtime binding (tests, FFI hosts)
+ * -------------------------------------------------------------------------------------- */
+int  eppm_device_count(int* n);
+int  eppm_set_device(int device);
+int  eppm_malloc_device(void** p, size_t bytes);
+int  eppm_malloc_pitched(void** p, size_t* pitch, size_t width_bytes, size_t rows);  /* cudaMallocPitch analogue */
+int  eppm_free_device(void* p);
+int  eppm_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int  eppm_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int  eppm_memcpy2d_h2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows);
+int  eppm_memcpy2d_d2h(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows);
+int  eppm_memset_device(void* p, int value, size_t bytes);
+int  eppm_device_synchronize(void);
+/* Stream used by the reference-signature launchers below (default: the null stream). */
+int  eppm_set_launcher_stream(void* hip_stream);
+/* Parameters used by the reference-signature launchers (default: defs.h values). */
+int  eppm_set_launcher_params(const eppm_params* p);
+/* Status of the most recent void launcher below (they cannot return one). */
+int  eppm_launcher_status(void);
+
+/* ----------------------------------------------------------------------------------------
+ * stage launchers: the reference's live extern "C" ABI (driver .cpp:40-62).
+ * All pointers are DEVICE pointers, all *_pitch are in BYTES, argument order is (w,h).
+ * Pyramid tables (T**, int*, size_t*) are HOST arrays of device pointers
+ * (basic/bao_basic_cuda.h:209-229).  uchar4/short2/float2 are the layouts declared above.
+ * -------------------------------------------------------------------------------------- */
+/* bao_pmflow_refine_kernel.cu:1060-1071 */
+void baoCudaPatchMatchMultiscalePrepare(eppm_uchar4** pImgPyr1, eppm_uchar4** pImgPyr2, unsigned char** pCensusPyr1,
+        unsigned char** pCensusPyr2, eppm_uchar4** pTempPyr1, eppm_uchar4** pTempPyr2, int* arrH, int* arrW,
+        size_t* arrPitchUchar4, size_t* arrPitchUchar1, int nLevels, eppm_uchar4* d_img1, eppm_uchar4* d_img2, int h, int w);
+/* bao_pmflow_census_kernel.cu:93-112 */
+void baoCudaCensusTransform(unsigned char* d_census1, unsigned char* d_census2, eppm_uchar4* d_img1, eppm_uchar4* d_img2,
+        int w, int h, size_t img_pitch, size_t census_pitch);
+/* bao_pmflow_kernel.cu:1760-1826 */
+void baoCudaPatchMatch(eppm_short2* d_disp_vec, float* d_cost, eppm_uchar4* d_img1, eppm_uchar4* d_img2,
+        unsigned char* d_census1, unsigned char* d_census2, int w, int h, size_t img_pitch, size_t cost_pitch,
+        size_t disp_pitch, size_t census_pitch);
+/* bao_pmflow_refine_kernel.cu:78-92 */
+void baoCudaLeftRightCheck(eppm_short2* d_disp_vec, float* d_cost, eppm_short2* d_disp_vec2, float* d_cost2,
+        int w, int h, size_t cost_pitch, size_t disp_pitch);
+/* bao_pmflow_refine_kernel.cu:185-193 */
+void baoCudaOutlierRemoval(eppm_short2* d_disp_vec, float* d_cost, int w, int h, size_t cost_pitch, size_t disp_pitch);
+/* bao_pmflow_refine_kernel.cu:261-286 */
+void baoCudaWeightedMedianFilter(eppm_short2* d_disp_vec, float* d_cost, eppm_uchar4* d_img, int w, int h,
+        size_t img_pitch, size_t cost_pitch, size_t disp_pitch, int num_iter, bool is_only_occlusion);
+/* bao_pmflow_refine_kernel.cu:373-390 */
+void baoCudaFillHole(eppm_short2* d_disp_vec, float* d_cost, eppm_uchar4* d_img, int w, int h,
+        size_t img_pitch, size_t cost_pitch, size_t disp_pitch);
+/* bao_pmflow_refine_kernel.cu:724-734 */
+void baoCudaNNF2Flow(eppm_float2* d_flow, eppm_short2* d_disp_vec, int w, int h, size_t disp_pitch, size_t flow_pitch);
+/* bao_pmflow_refine_kernel.cu:1076-1087 */
+void baoCudaBLF_C2F(eppm_float2** pFlowPyr, eppm_uchar4** pImgPyr1, eppm_uchar4** pImgPyr2, unsigned char** pCensusPyr1,
+        unsigned char** pCensusPyr2, eppm_float2** pTempPyr1, eppm_float2** pTempPyr2, int* arrH, int* arrW,
+        size_t* arrPitchUchar4, size_t* arrPitchUchar1, int nLayerIdx);
+/* bao_pmflow_kernel.cu:2042-2069 */
+void baoCudaBLFCostFilterRefine(eppm_float2* d_flow_vec, eppm_uchar4* d_img1, eppm_uchar4* d_img2, unsigned char* d_census1,
+        unsigned char* d_census2, int w, int h, size_t img_pitch, size_t census_pitch);
+/* bao_pmflow_refine_kernel.cu:801-826 */
+void baoCudaFlowSmoothing(eppm_float2* d_flow, eppm_uchar4* d_img, int w, int h, size_t img_pitch, size_t flow_pitch);
+
+/* ----------------------------------------------------------------------------------------
+ * sub-stage entry points of PatchMatch (for parity tests at kernel granularity).  They mirror
+ * the reference's inner launchers baoGenerateRandomField / baoComputeCostField / baoSegPropagate /
+ * baoRandomSearch (bao_pmflow_kernel.cu:153-165, 689-696, 1167-1181, 1588-1594), with the
+ * texture bindings and the global RNG state made explicit arguments.
+ * rng: opaque device buffer from eppm_pm_rng_create (one XORWOW stream per 16x16 block).
+ * -------------------------------------------------------------------------------------- */
+typedef struct eppm_pm_rng eppm_pm_rng;
+int  eppm_pm_rng_create(eppm_pm_rng** out, int w, int h, const eppm_params* p);
+int  eppm_pm_rng_reset(eppm_pm_rng* rng);        /* back to curand_init(seed, block_id, 0) */
+int  eppm_pm_rng_destroy(eppm_pm_rng* rng);
+/* host copy of the per-block XORWOW state at the current stream position: 6 x uint32 per block (v[5], d) */
+int  eppm_pm_rng_block_states(eppm_pm_rng* rng, uint32_t* dst, size_t dst_words);
+int  eppm_pm_gen_rand_field(eppm_pm_rng* rng, eppm_short2* d_nnf, int w, int h, size_t disp_pitch);
+int  eppm_pm_cost_field(float* d_cost, const eppm_short2* d_nnf, const eppm_uchar4* d_img1, const eppm_uchar4* d_img2,
+        const unsigned char* d_census1, const unsigned char* d_census2, int w, int h, size_t img_pitch,
+        size_t cost_pitch, size_t disp_pitch, size_t census_pitch);
+/* dir: 0 row fwd, 1 col fwd, 2 row rev, 3 col rev; dir < 0: all four in the reference's order */
+int  eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* d_img1, const eppm_uchar4* d_img2,
+        const unsigned char* d_census1, const unsigned char* d_census2, int w, int h, size_t img_pitch,
+        size_t cost_pitch, size_t disp_pitch, size_t census_pitch, int dir);
+int  eppm_pm_random_search(eppm_pm_rng* rng, float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* d_img1,
+        const eppm_uchar4* d_img2, const unsigned char* d_census1, const unsigned char* d_census2, int w, int h,
+        size_t img_pitch, size_t cost_pitch, size_t disp_pitch, size_t census_pitch);
+/* basic/bao_basic_cuda.cuh:437-481 and :565-615 (uchar4), :511-537 (float2) */
+int  eppm_gauss_filter_rgba(eppm_uchar4* d_out, const eppm_uchar4* d_in, size_t pitch, int h, int w, float sigma, int radius);
+int  eppm_resize_rgba(eppm_uchar4* d_out, size_t out_pitch, int outH, int outW, const eppm_uchar4* d_in, size_t in_pitch,
+        int h, int w, float ratio);
+int  eppm_resize_flow(eppm_float2* d_out, int outH, int outW, const eppm_float2* d_in, int h, int w, float ratio);
+/* device-side arithmetic probes (parity of the shared float formulas): y[i] = f(x[i]) for n host floats */
+int  eppm_probe_fast_exp(const float* x, float* y, int n);
+int  eppm_probe_div_const(const float* x, float* y, int n, int which); /* 0: /(.1f*.1f) 1: /(.02f*.02f) 2: unorm8 (x = 0..255) */
+
+/* ----------------------------------------------------------------------------------------
+ * file formats used by the reference's CLI (main.cpp:56-69)
+ * -------------------------------------------------------------------------------------- */
+/* P6/P5 reader tolerant of '#' comment lines (basic/bao_basic.cpp:137-218). image: h*w*3 bytes. */
+int  eppm_load_ppm(const char* filename, uint8_t* image, int h, int w, int* channels);
+int  eppm_ppm_size(const char* filename, int* h, int* w);
+/* Middlebury .flo: "PIEH", int32 w, int32 h, interleaved f32 (u,v) rows (flowIO.cpp:122-163). */
+int  eppm_save_flo(const char* filename, const float* u, const float* v, int h, int w);
+int  eppm_load_flo(const char* filename, float* u, float* v, int h, int w);
+int  eppm_flo_size(const char* filename, int* h, int* w);
+/* EPE / AAE with the reference's validity rule (basic/bao_flow_tools.cpp:64-111). */
+int  eppm_flow_error(const float* u, const float* v, const float* gt_u, const float* gt_v, int h, int w, float* epe, float* aae);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPPM_H_ */

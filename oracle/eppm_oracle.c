@@ -343,7 +343,10 @@ void orc_prepare(orc_uchar4** img_pyr, uint8_t** census_pyr, const orc_uchar4* r
     orc_gauss_filter_rgba(img_pyr[0], raw, arrH[0], arrW[0], .5f, 2);        /* refine :1063 */
     /* construct_gauss_pyramid_pitched: pPyr[0] == d_img so no copy (.cuh:646) */
     float baseSigma = (1 / ratio - 1);
-    int n = (int)(log(0.25) / log(ratio));
+    /* .cuh:649 "int n=log(0.25)/log(ratio);" is C++: log(float) resolves to the float overload, and
+     * logf(0.5f) = -0.69314718246 is larger in magnitude than ln 2, so the quotient is 1.9999999945 and
+     * n = 1 (not 2): level 2 is built from level 1 through the else-branch below. */
+    int n = (int)(log(0.25) / (double)logf(ratio));
     float nSigma = baseSigma * n;
     orc_uchar4** tmp = (orc_uchar4**)calloc(n_levels, sizeof(orc_uchar4*));
     for (int i = 0; i < n_levels; i++) tmp[i] = (orc_uchar4*)malloc(sizeof(orc_uchar4) * arrH[i] * arrW[i]);

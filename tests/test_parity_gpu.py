@@ -1,0 +1,167 @@
+"""GPU parity: every HIP stage, called through the C ABI, against the CPU oracle on the same inputs.
+Bar: bit-exact for every plane (u8 / int16 / float32 alike) -- the float formulas are shared by
+construction, so exact equality is the test; the end-to-end EPE bound of
+BASELINE.json's north_star (1e-3 px) follows trivially and is asserted as well."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def eq(a, b, what):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, f"{what}: shape/dtype {a.shape}{a.dtype} vs {b.shape}{b.dtype}"
+    if a.dtype.kind == "f":
+        same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    else:
+        same = a.view(np.uint8) == b.view(np.uint8)
+    n = int((~same).sum())
+    assert n == 0, f"{what}: {n} of {same.size} elements differ"
+
+
+@pytest.fixture(scope="module")
+def S():
+    import eppm_amd
+    eppm_amd.lib()
+    from eppm_amd import stages
+    stages.set_params(None)
+    return stages
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def test_fast_exp_bits(S, O):
+    x = -np.concatenate([np.linspace(0, 120, 20001), np.float32(np.arange(0, 256)) ** 2 / np.float32(255 * 255 * 0.01)]).astype(np.float32)
+    eq(S.probe_fast_exp(x), O.fast_exp(x), "fast_exp")
+
+
+def test_div_const_bits(S):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.random(200000, dtype=np.float32) * 2, [0.0]]).astype(np.float32)
+    eq(S.probe_div_const(x, 0), (x / (np.float32(0.1) * np.float32(0.1))).astype(np.float32), "x/(.1f*.1f)")
+    eq(S.probe_div_const(x, 1), (x / (np.float32(0.02) * np.float32(0.02))).astype(np.float32), "x/(.02f*.02f)")
+    c = np.arange(256, dtype=np.float32)
+    eq(S.probe_div_const(c, 2), (c / np.float32(255)).astype(np.float32), "unorm8")
+
+
+def test_prepare_stages(S, O, crop):
+    raw = O.rgb2rgba(crop[0])
+    eq(S.gauss_filter_rgba(raw, 0.5, 2), O.gauss_filter_rgba(raw, 0.5, 2), "gauss s=.5 r=2")
+    eq(S.gauss_filter_rgba(raw, 2.0, 6), O.gauss_filter_rgba(raw, 2.0, 6), "gauss s=2 r=6")
+    eq(S.resize_rgba(raw, 60, 80, 0.5), O.resize_rgba(raw, 60, 80, 0.5), "resize 1/2")
+    eq(S.resize_rgba(raw, 30, 40, 0.25), O.resize_rgba(raw, 30, 40, 0.25), "resize 1/4")
+    c1, c2 = S.census_transform(raw, O.rgb2rgba(crop[1]))
+    eq(c1, O.census(raw), "census 1")
+    eq(c2, O.census(O.rgb2rgba(crop[1])), "census 2")
+
+
+def test_prepare_launcher(S, O, crop, crop_stages):
+    st = crop_stages
+    dims = list(zip(st["arrH"], st["arrW"]))
+    i1, i2, c1, c2 = S.prepare(O.rgb2rgba(crop[0]), O.rgb2rgba(crop[1]), dims)
+    for l in range(3):
+        eq(i1[l], st[f"img1_L{l}"], f"img1 L{l}")
+        eq(i2[l], st[f"img2_L{l}"], f"img2 L{l}")
+        eq(c1[l], st[f"cen1_L{l}"], f"census1 L{l}")
+        eq(c2[l], st[f"cen2_L{l}"], f"census2 L{l}")
+
+
+@pytest.fixture(scope="module")
+def L1(crop_stages):
+    """Level-1 planes of the crop (80x60): small enough for per-kernel PatchMatch parity."""
+    st = crop_stages
+    return st["img1_L1"], st["img2_L1"], st["cen1_L1"], st["cen2_L1"]
+
+
+def test_patchmatch_substages(S, O, L1):
+    i1, i2, c1, c2 = L1
+    h, w = i1.shape
+    P = S.PlaneSet(i1, i2, c1, c2)
+    rng = S.PmRng(w, h)
+    nnf = S.pm_gen_rand_field(rng)
+    onnf, ostates = O.gen_rand_field(w, h)
+    eq(nnf, onnf, "random NNF")
+    eq(rng.block_states(), ostates, "RNG states after init field")
+    cost = S.pm_cost_field(nnf, P)
+    ocost = O.cost_field(onnf, i1, i2, c1, c2)
+    eq(cost, ocost, "initial cost field")
+    for it in range(2):
+        for d in range(4):
+            cost, nnf = S.pm_seg_propagate(cost, nnf, P, d)
+            ocost, onnf = O.seg_propagate_dir(ocost, onnf, i1, i2, c1, c2, d)
+            eq(nnf, onnf, f"NNF after propagate dir {d} iter {it}")
+            eq(cost, ocost, f"cost after propagate dir {d} iter {it}")
+        cost, nnf = S.pm_random_search(rng, cost, nnf, P)
+        ostates, ocost, onnf = O.random_search(ostates, ocost, onnf, i1, i2, c1, c2)
+        eq(nnf, onnf, f"NNF after random search iter {it}")
+        eq(cost, ocost, f"cost after random search iter {it}")
+        eq(rng.block_states(), ostates, f"RNG states after search iter {it}")
+
+
+def test_patchmatch_launcher(S, O, crop_stages):
+    st = crop_stages
+    P = S.PlaneSet(st["img1_L2"], st["img2_L2"], st["cen1_L2"], st["cen2_L2"])
+    nnf, cost = S.patchmatch(P)
+    eq(nnf, st["nnf1_pm"], "baoCudaPatchMatch NNF (10 iterations)")
+    eq(cost, st["cost1_pm"], "baoCudaPatchMatch cost")
+    P2 = S.PlaneSet(st["img2_L2"], st["img1_L2"], st["cen2_L2"], st["cen1_L2"])
+    nnf2, cost2 = S.patchmatch(P2)
+    eq(nnf2, st["nnf2_pm"], "backward NNF")
+    eq(cost2, st["cost2_pm"], "backward cost")
+
+
+def test_level2_post(S, O, crop_stages):
+    st = crop_stages
+    a, b, c, d = S.left_right_check(st["nnf1_pm"], st["cost1_pm"], st["nnf2_pm"], st["cost2_pm"])
+    oa, ob, oc, od = O.left_right_check(st["nnf1_pm"], st["cost1_pm"], st["nnf2_pm"], st["cost2_pm"])
+    eq(a, oa, "LR nnf1"); eq(b, ob, "LR cost1"); eq(c, oc, "LR nnf2"); eq(d, od, "LR cost2")
+    eq(a, st["nnf1_lr"], "LR vs pipeline dump")
+    n2, c2 = S.outlier_removal(a, b)
+    on2, oc2 = O.outlier_removal(oa, ob)
+    eq(n2, on2, "outlier nnf"); eq(c2, oc2, "outlier cost")
+    img = st["img1_L2"]
+    for iters in (1, 3, 20):
+        eq(S.weighted_median(n2, img, iters, True), O.weighted_median(on2, img, iters, True), f"WMF x{iters} occlusion only")
+    eq(S.weighted_median(n2, img, 1, False), O.weighted_median(on2, img, 1, False), "WMF all pixels")
+    eq(S.fill_holes(n2, img), O.fill_holes(on2, img), "fill holes (before WMF: many holes)")
+    eq(S.fill_holes(st["nnf1_wmf"], img), st["nnf1_fill"], "fill holes")
+    eq(S.nnf2flow(st["nnf1_fill"]), st["flow_L2"], "NNF -> flow")
+    eq(S.nnf2flow(n2), O.nnf2flow(on2), "NNF -> flow with invalid pixels")
+
+
+def test_c2f(S, O, crop_stages):
+    st = crop_stages
+    up = S.resize_flow(st["flow_L2"], st["arrH"][1], st["arrW"][1], 2.0)
+    eq(up, O.resize_flow(st["flow_L2"], st["arrH"][1], st["arrW"][1], 2.0), "flow upsample x2")
+    P1 = S.PlaneSet(st["img1_L1"], st["img2_L1"], st["cen1_L1"], st["cen2_L1"])
+    f1 = S.blf_c2f(st["flow_L2"], P1, (st["arrH"][2], st["arrW"][2]))
+    eq(f1, st["flow_c2f_L1"], "baoCudaBLF_C2F level 1")
+    s1 = S.flow_smoothing(f1, st["img1_L1"])
+    eq(s1, st["flow_L1"], "flow smoothing level 1")
+    # unknown flow handling: plant 1e10 vectors
+    fl = st["flow_L1"].copy()
+    fl["x"][5:9, 7:30] = 1e10
+    fl["y"][5:9, 7:30] = 1e10
+    eq(S.flow_smoothing(fl, st["img1_L1"]), O.flow_smoothing(fl, st["img1_L1"]), "smoothing with unknown flow")
+    eq(S.c2f_refine(fl, P1), O.c2f_refine(fl, st["img1_L1"], st["img2_L1"], st["cen1_L1"], st["cen2_L1"]), "refine with unknown flow")
+
+
+def test_end_to_end_crop(crop, crop_stages):
+    import eppm_amd
+    e = eppm_amd.EPPM()
+    e.init(crop[0], crop[1], 120, 160)
+    u, v = e.compute_flow()
+    st = crop_stages
+    eq(e.plane("nnf1", 2), st["nnf1_fill"], "pipeline NNF")
+    eq(u, st["u"], "u")
+    eq(v, st["v"], "v")
+    epe = float(np.sqrt((u - st["u"]) ** 2 + (v - st["v"]) ** 2).mean())
+    assert epe <= 1e-3     # north_star tolerance
+    # set_data may be called repeatedly after one init (driver .cpp:159-168): same answer again
+    e.set_data(crop[0], crop[1])
+    u2, v2 = e.compute_flow()
+    eq(u2, u, "second run u"); eq(v2, v, "second run v")

@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py -- EPPM hot path on MI355X: Mflow-vectors/s on 1024x436 Sintel-shape pairs.
+
+A step = one pass of the hot path (set_data's device part: prefilter + pyramid + census, then
+compute_flow: PatchMatch fwd/bwd at 1/4 res, L-R check, outlier removal, weighted median, hole fill,
+two coarse-to-fine levels, final smoothing) over ONE synthetic 1024x436 pair whose RGBA planes are
+already resident in HBM.  N > 1: one process per GPU, each rank its own pairs (independent pairs, no
+data-path collective: SURVEY 8e); value = pairs of all ranks * W*H / max-over-ranks time.
+
+Prints one JSON line (see the task contract) with `roofline` (dominant kernel: the level-0 plane-fit
+candidate refine, algorithmic HBM bytes / HIP-event duration) and `cpu_baseline` (the CPU oracle on a
+bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+W, H = 1024, 436               # BASELINE.json configs[1]
+# algorithmic HBM bytes per level-0 pixel of one k_c2f_refine launch: reads flow 8 + img1 4 + img2 4 +
+# census1 1 + census2 1, writes flow 8  
+REFINE_BYTES_PER_PX = 26
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--patch-r", type=int, default=9)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per k_c2f_refine launch from a separate rocprofv3 --pmc pass (profiles/)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import eppm_amd
+    from eppm_amd import synth
+    w, h = args.width, args.height
+    params = eppm_amd.Params(patch_r=args.patch_r)
+    eng = eppm_amd.EPPM(device=local_rank, params=params)
+    eng.init(h, w)
+
+    # synthetic pair of this rank, as RGBA planes resident in HBM before the timed region
+    img1, img2, gu, gv = synth.make_pair(h, w, seed=1234 + rank)
+    def to_dev(img):
+        rgba = np.zeros((h, w, 4), np.uint8)
+        rgba[..., :3] = img
+        return torch.from_numpy(rgba).to(dev)
+    d1, d2 = to_dev(img1), to_dev(img2)
+    d_flow = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
+    pitch = w * 4
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        eng.set_data_device(d1.data_ptr(), d2.data_ptr(), pitch)
+        eng.compute_flow_device(d_flow.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    eng.synchronize()
+    eng.enable_stage_timing(True)
+    eng.stage_times(clear=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stages = eng.stage_times(clear=True)
+    eng.enable_stage_timing(False)
+
+    # sanity: the flow is finite and close to the synthetic ground truth (not a parity check)
+    flow = d_flow.cpu().numpy()
+    epe_gt = float(np.sqrt((flow[..., 0] - gu) ** 2 + (flow[..., 1] - gv) ** 2).mean())
+
+    if rank == 0:
+        agg = {}
+        for name, ms in stages:
+            agg.setdefault(name, []).append(ms)
+        stage_ms = {k: float(np.mean(v)) for k, v in agg.items()}
+        dom = "c2f_refine_L0"
+        dom_ms = stage_ms.get(dom, float("nan"))
+        alg_bytes = REFINE_BYTES_PER_PX * w * h
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mflow-vectors/sec", "value": world * args.steps * w * h / dt / 1e6, "unit": "Mflow-vectors/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"single {w}x{h} Sintel-shape synthetic pair per step, full 3-level pyramid, patch_r={args.patch_r}, "
+                                   f"default defs.h parameters; {world} rank(s), independent pairs",
+                       "pairs_per_step_per_gpu": 1, "width": w, "height": h},
+            "roofline": {"bound": "hbm", "kernel": "k_c2f_refine (level 0)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic_bytes,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms},
+            "stage_ms": stage_ms,
+            "epe_vs_synthetic_gt": epe_gt,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, h)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(w, h):
+    """The CPU oracle (oracle/, a port of the reference's kernel semantics: the reference has no CPU path)
+    timed on this host on a bounded sample: one pair of a quarter of the workload's pixels."""
+    from oracle import oracle as O
+    from eppm_amd import synth
+    sw, sh = w // 2, h // 2
+    a, b, _, _ = synth.make_pair(sh, sw, seed=1234)
+    O.compute_flow(a[:32, :32].copy(), b[:32, :32].copy())      # build + warm
+    t0 = time.perf_counter()
+    O.compute_flow(a, b)
+    dt = time.perf_counter() - t0
+    return {"value": sw * sh / dt / 1e6, "unit": "Mflow-vectors/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"1 pair {sw}x{sh} (same generator, 1/4 of the workload's pixels), full path, {dt:.1f} s, OpenMP oracle"}
+
+
+if __name__ == "__main__":
+    main()

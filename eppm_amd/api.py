@@ -111,13 +111,17 @@ class EPPM:
         self._need()
         check(lib().eppm_enable_stage_timing(self._ctx, int(on)), "eppm_enable_stage_timing")
 
-    def stage_times(self):
-        """[(stage name, ms)] of the last set_data / compute_flow with timing enabled."""
+    def stage_times(self, clear=True):
+        """[(stage name, ms)] for every set_data / compute_flow since the last clear (timing enabled)."""
         self._need()
-        names = (C.c_char_p * 64)()
-        ms = (C.c_float * 64)()
-        n = lib().eppm_stage_times(self._ctx, names, ms, 64)
-        return [(names[i].decode(), float(ms[i])) for i in range(n)]
+        cap = 1 << 16
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        n = lib().eppm_stage_times(self._ctx, names, ms, cap)
+        out = [(names[i].decode(), float(ms[i])) for i in range(n)]
+        if clear:
+            check(lib().eppm_clear_stage_times(self._ctx), "eppm_clear_stage_times")
+        return out
 
     def close(self):
         if self._ctx:

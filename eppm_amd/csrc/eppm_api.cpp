@@ -380,7 +380,6 @@ static int prepare_one(eppm_ctx* c, uint32_t** pyr, uint8_t** cen, uint32_t** tm
 
 static int prepare(eppm_ctx* c, const uint32_t* raw1, const uint32_t* raw2)
 {
-    clear_events(c->ev_prep);
     stage_begin(c, c->ev_prep, "prepare");
     CHK(prepare_one(c, c->img1, c->cen1, c->tmpu, raw1));
     CHK(prepare_one(c, c->img2, c->cen2, c->tmpu, raw2));
@@ -439,7 +438,6 @@ extern "C" int eppm_compute_device(eppm_ctx* c, void* d_flow)
     if (!c->have_images) return set_err(EPPM_ERR_STATE, "eppm_compute: no images set");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    clear_events(c->ev);
     const int L = c->nl - 1;                                            // pm_layer, driver :219
     const int lw = c->W[L], lh = c->H[L];
 
@@ -518,6 +516,15 @@ extern "C" int eppm_stage_times(eppm_ctx* c, const char** names, float* ms, int 
             names[n] = e.name; ms[n] = t; n++;
         }
     return n;
+}
+
+extern "C" int eppm_clear_stage_times(eppm_ctx* c)
+{
+    if (!c) return set_err(EPPM_ERR_ARG, "NULL ctx");
+    (void)hipStreamSynchronize(c->stream);
+    clear_events(c->ev);
+    clear_events(c->ev_prep);
+    return EPPM_OK;
 }
 
 extern "C" int eppm_get_plane(eppm_ctx* c, const char* name, int level, void* dst, size_t dst_bytes)

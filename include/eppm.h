@@ -91,9 +91,11 @@ int  eppm_level_dims(const eppm_ctx* ctx, int level, int* h, int* w);
  *  "flow" (float2).  Valid after the stage that produces it has run. */
 int  eppm_get_plane(eppm_ctx* ctx, const char* name, int level, void* dst, size_t dst_bytes);
 
-/* Per-stage device time of the last eppm_compute* call, in ms (hipEvent).  names[i] points to
- * static strings.  Returns the number of stages written (<= max). */
+/* Per-stage device times in ms (hipEvent pairs on the context's stream), one entry per stage per
+ * call since the last eppm_clear_stage_times (names repeat across calls; prepare entries first).
+ * names[i] points to static strings.  Returns the number of entries written (<= max). */
 int  eppm_stage_times(eppm_ctx* ctx, const char** names, float* ms, int max);
+int  eppm_clear_stage_times(eppm_ctx* ctx);
 /* Enable/disable the per-stage events (off by default: they serialise nothing but cost a few us). */
 int  eppm_enable_stage_timing(eppm_ctx* ctx, int on);
 

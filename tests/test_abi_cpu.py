@@ -1,0 +1,111 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/eppm.h declares, its argument
+checks work without a GPU, and its file I/O equals the reference's own code (oracle/_ref) byte for byte."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+import eppm_amd
+from eppm_amd import _lib
+from oracle import oracle as O
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "eppm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b((?:eppm|baoCuda)\w*)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = eppm_amd.lib()
+    for s in declared:
+        getattr(L, s)          # raises AttributeError if not exported
+
+
+def test_drop_in_class_header_compiles_and_links(tmp_path):
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "bao_flow_patchmatch_multiscale_cuda.h"\n'
+                   "int main(){ bao_flow_patchmatch_multiscale_cuda e; unsigned char*** a=0; float** u=0;\n"
+                   " if (0) { e.init(4,4); e.init(a,a,4,4); bool ok=e.set_data(a,a); (void)ok; e.compute_flow(u,u); e.compute_flow(u,u,a);} return 0; }\n")
+    libdir = os.path.dirname(eppm_amd.lib_path())
+    subprocess.check_call(["g++", "-std=c++11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "t"),
+                           "-L", libdir, "-leppm_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    subprocess.check_call([str(tmp_path / "t")])
+
+
+def test_argument_errors_without_gpu():
+    L = eppm_amd.lib()
+    ctx = C.c_void_p()
+    assert L.eppm_create(C.byref(ctx), 2, 2, 0, None) == 1            # EPPM_ERR_ARG: too small
+    assert b"out of range" in L.eppm_last_error()
+    p = eppm_amd.Params(patch_r=40)
+    assert L.eppm_create(C.byref(ctx), 100, 100, 0, C.byref(p)) == 1
+    assert L.eppm_compute(None, None, None) == 1
+    e = eppm_amd.EPPM()
+    with pytest.raises(eppm_amd.EppmError):
+        e.compute_flow()
+    with pytest.raises(TypeError):
+        eppm_amd.Params(nonsense=1)
+
+
+def test_default_params_are_defs_h():
+    p = eppm_amd.Params()
+    assert (p.patch_r, p.num_iter, p.search_range, p.num_guess, p.seg_len, p.wmf_iters, p.seed) == (9, 10, 30, 6, 10, 20, 1234)
+
+
+def test_flo_roundtrip_and_header(tmp_path):
+    rng = np.random.default_rng(0)
+    u = rng.standard_normal((7, 13)).astype(np.float32); v = rng.standard_normal((7, 13)).astype(np.float32)
+    path = str(tmp_path / "a.flo")
+    eppm_amd.io.save_flo(path, u, v)
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"PIEH" and np.frombuffer(raw[4:12], np.int32).tolist() == [13, 7] and len(raw) == 12 + 7 * 13 * 8
+    u2, v2 = eppm_amd.io.load_flo(path)
+    assert (u2 == u).all() and (v2 == v).all()
+    with pytest.raises(eppm_amd.EppmError):
+        eppm_amd.io.save_flo(str(tmp_path / "a.txt"), u, v)       # extension .flo required (flowIO.cpp:131)
+
+
+needs_ref = pytest.mark.skipif(O.refio() is None, reason="oracle/_ref not built (reference sources absent)")
+
+
+@needs_ref
+def test_flo_writer_equals_reference_bytes(tmp_path):
+    R = O.refio()
+    rng = np.random.default_rng(1)
+    u = (rng.standard_normal((20, 31)) * 30).astype(np.float32); v = (rng.standard_normal((20, 31)) * 30).astype(np.float32)
+    u[3, 4] = v[3, 4] = 1e10
+    ours, ref = str(tmp_path / "o.flo"), str(tmp_path / "r.flo")
+    eppm_amd.io.save_flo(ours, u, v)
+    R.refio_save_flo(ref.encode(), u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), 20, 31)
+    assert open(ours, "rb").read() == open(ref, "rb").read()
+    ru, rv = np.zeros_like(u), np.zeros_like(v)
+    assert R.refio_load_flo(ours.encode(), ru.ctypes.data_as(C.c_void_p), rv.ctypes.data_as(C.c_void_p), 20, 31) == 0
+    assert (ru == u).all() and (rv == v).all()
+
+
+@needs_ref
+def test_ppm_reader_equals_reference(frames):
+    R = O.refio()
+    path = os.path.join(GOLDEN, "frame10.ppm")
+    ours = eppm_amd.io.load_ppm(path)
+    ref = np.zeros((480, 640, 3), np.uint8)
+    assert R.refio_load_ppm(path.encode(), ref.ctypes.data_as(C.c_void_p), 480, 640) == 3
+    assert (ours == ref).all() and (ours == frames[0]).all()
+    assert eppm_amd.io.ppm_size(path) == (480, 640)
+
+
+@needs_ref
+def test_epe_aae_equal_reference():
+    R = O.refio()
+    rng = np.random.default_rng(2)
+    shp = (24, 40)
+    u, v, gu, gv = [(rng.standard_normal(shp) * 5).astype(np.float32) for _ in range(4)]
+    gu[0, :5] = 0; gv[0, :5] = 0          # zero ground truth is skipped by the reference's rule
+    gu[1, 1] = 1e10
+    epe, aae = C.c_float(), C.c_float()
+    R.refio_flow_error(*[a.ctypes.data_as(C.c_void_p) for a in (u, v, gu, gv)], 24, 40, C.byref(epe), C.byref(aae))
+    e2, a2 = eppm_amd.io.flow_error(u, v, gu, gv)
+    assert e2 == epe.value and a2 == aae.value

@@ -1,0 +1,57 @@
+"""The N > 1 path on CPU: world_size-2 gloo processes shard independent pairs with no data-path collective
+(SURVEY 8e); only the timing protocol of bench.py (barrier + MAX over ranks) uses torch.distributed."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+from conftest import ROOT
+from eppm_amd.shard import pairs_for_rank
+
+
+def test_round_robin_partition():
+    for n in (0, 1, 7, 64):
+        for world in (1, 2, 4, 8):
+            parts = [pairs_for_rank(n, r, world) for r in range(world)]
+            flat = sorted(i for p in parts for i in p)
+            assert flat == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert pairs_for_rank(64, 3, 8) == list(range(3, 64, 8))
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from eppm_amd.shard import pairs_for_rank
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = pairs_for_rank(13, rank, world)
+    # the data path needs nothing from the other rank; the checks below are test-only
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    assert sorted(i for p in got for i in p) == list(range(13))
+    dist.barrier()
+    t = torch.tensor([0.010 * (rank + 1)], dtype=torch.float64)      # bench.py: max over ranks of the local time
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert abs(t.item() - 0.010 * world) < 1e-12
+    vectors = sum(len(p) for p in got) * 1024 * 436
+    if rank == 0:
+        print("OK", vectors / t.item() / 1e6)
+    dist.destroy_process_group()
+""")
+
+
+def test_two_gloo_ranks_shard_pairs(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e
+    assert any(line.startswith("OK") for line in outs[0][0].splitlines())

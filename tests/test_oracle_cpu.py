@@ -1,0 +1,223 @@
+"""CPU tests of the oracle: committed golden vectors, hand-checkable known-answer tests,
+and the pieces of the reference that DO compile here (oracle/_ref: its host-side helpers)."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from oracle import oracle as O
+
+
+def eq(a, b, what):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, what
+    assert a.tobytes() == b.tobytes(), f"{what}: planes differ"
+
+
+# ---------------------------------------------------------------- golden vectors
+def test_golden_whole_path_crop(crop_stages):
+    g = np.load(os.path.join(GOLDEN, "crop160_stages.npz"))
+    for k in g.files:
+        eq(crop_stages[k], g[k], k)
+
+
+def test_golden_patchmatch_iterations(crop_stages):
+    st = crop_stages
+    g = np.load(os.path.join(GOLDEN, "pm_iters.npz"))
+    for it in (0, 1):
+        nnf, cost = O.patchmatch(st["img1_L2"], st["img2_L2"], st["cen1_L2"], st["cen2_L2"], iters_done=it)
+        eq(nnf, g[f"nnf_it{it}"], f"nnf after {it} iterations")
+        eq(cost, g[f"cost_it{it}"], f"cost after {it} iterations")
+    eq(st["nnf1_pm"], g["nnf_it10"], "nnf after 10 iterations")
+
+
+def test_golden_xorwow():
+    g = json.load(open(os.path.join(GOLDEN, "xorwow.json")))
+    for sub, vals in g.items():
+        assert [int(x) for x in O.xorwow_stream(1234, int(sub), 8)] == vals
+
+
+def test_fixture_frames_are_the_bundled_pair(frames):
+    man = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+    import hashlib
+    for n in ("frame10.ppm", "frame11.ppm"):
+        assert hashlib.sha256(open(os.path.join(GOLDEN, n), "rb").read()).hexdigest() == man[n]
+    assert frames[0].shape == (480, 640, 3)        # 640x480, not 584x388
+
+
+# ---------------------------------------------------------------- arithmetic
+def test_fast_exp_accuracy_and_anchors():
+    x = -np.linspace(0, 86, 50001).astype(np.float32)
+    y = O.fast_exp(x).astype(np.float64)
+    ref = np.exp(x.astype(np.float64))
+    # CUDA documents __expf's error as 2 + floor(|1.16 x|) ulp (the x*log2e product is rounded to float)
+    bound = (2 + np.floor(1.16 * np.abs(x.astype(np.float64)))) * 2.0 ** -23
+    assert (np.abs(y / ref - 1) <= bound).all()
+    assert np.max(np.abs(y / ref - 1)[x > -1]) < 4e-7
+    assert O.fast_exp([0.0])[0] == 1.0
+    assert O.fast_exp([-100.0])[0] == 0.0            # flushed, exp(-100) < 2^-125
+    assert O.fast_exp([-86.0])[0] > 0.0
+
+
+def test_luts_follow_the_reference_formulas():
+    gs, cn = O.pm_luts(9)
+    f = np.float32
+    assert np.allclose(gs, [np.exp(-(i * i) / 20.25) for i in range(10)], rtol=2e-7)
+    assert np.allclose(cn, [1 - np.exp(-(k * k) / 5.76) for k in range(9)], rtol=0, atol=2e-7)
+    assert gs[0] == f(1) and cn[0] == f(0)
+    assert np.allclose(O.wmf_lut(), [np.exp(-(i * i) / 16.0) for i in range(5)], rtol=2e-7)
+    assert np.allclose(O.blf_lut(), [np.exp(-(i * i) / 25.0) for i in range(11)], rtol=2e-7)
+
+
+def test_divconst_exhaustive_c_program(tmp_path):
+    exe = str(tmp_path / "verify_divconst")
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-fopenmp", os.path.join(ROOT, "tests", "csrc", "verify_divconst.c"),
+                           "-o", exe, "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+
+
+# ---------------------------------------------------------------- hand-checkable KATs
+def _const_img(h, w, val):
+    a = np.zeros((h, w), O.uchar4)
+    a["x"] = a["y"] = a["z"] = val
+    return a
+
+
+def test_patch_cost_of_identical_constant_images_is_zero():
+    img = _const_img(40, 40, 77)
+    cen = np.zeros((40, 40), np.uint8)
+    for planefit in (False, True):
+        assert O.patch_dist(img, img, cen, cen, 20, 20, 22, 19, planefit=planefit) == 0.0
+
+
+def test_patch_cost_black_vs_white():
+    a, b = _const_img(40, 40, 0), _const_img(40, 40, 255)
+    cen = np.zeros((40, 40), np.uint8)
+    # d = 1 -> 1 - exp(-100) = 1 (flushed); census equal -> +0; all weights equal -> exactly 1
+    assert O.patch_dist(a, b, cen, cen, 20, 20, 20, 20) == 1.0
+    # census all-ones vs zero: Hamming 8 -> + cn[8]
+    cen8 = np.full((40, 40), 255, np.uint8)
+    gs, cn = O.pm_luts(9)
+    assert O.patch_dist(a, a, cen, cen8, 20, 20, 20, 20) == cn[8]
+
+
+def test_patch_cost_clamps_out_of_range_targets():
+    rng = np.random.default_rng(0)
+    a = np.zeros((30, 30), O.uchar4); b = np.zeros((30, 30), O.uchar4)
+    for ch in "xyz":
+        a[ch] = rng.integers(0, 256, (30, 30)); b[ch] = rng.integers(0, 256, (30, 30))
+    c1 = rng.integers(0, 256, (30, 30)).astype(np.uint8); c2 = rng.integers(0, 256, (30, 30)).astype(np.uint8)
+    # target (30,30) is one past the image (random init draws x in [0,w], y in [0,h]); clamp addressing makes
+    # it differ from (29,29) only through the patch offsets, never crash
+    v = O.patch_dist(a, b, c1, c2, 0, 0, 30, 30)
+    assert np.isfinite(v) and 0 <= v <= 2
+
+
+def test_census_of_a_ramp():
+    img = np.zeros((3, 3), O.uchar4)
+    ramp = np.arange(9).reshape(3, 3) * 10
+    img["x"] = img["y"] = img["z"] = ramp
+    c = O.census(img)
+    # centre pixel (1,1)=40: neighbours larger are (2,1)=50 bit4, (0,2)=60 bit5, (1,2)=70 bit6, (2,2)=80 bit7
+    assert c[1, 1] == (1 << 4) | (1 << 5) | (1 << 6) | (1 << 7)
+    # corner (0,0)=0 with clamp addressing: bits 2 (x+1,y-1 -> (1,0)=10), 4 (1,0), 5 (x-1,y+1 -> (0,1)=30), 6, 7
+    assert c[0, 0] == (1 << 2) | (1 << 4) | (1 << 5) | (1 << 6) | (1 << 7)
+    assert c[2, 2] == 0
+
+
+def test_pyramid_dims_and_decimation_maps():
+    assert O.pyr_init_dim(436, 1024) == ([436, 218, 109], [1024, 512, 256])
+    assert O.pyr_init_dim(480, 640) == ([480, 240, 120], [640, 320, 160])
+    assert O.pyr_init_dim(437, 1023) == ([437, 218, 109], [1023, 511, 255])
+    img = np.zeros((16, 24), O.uchar4)
+    img["x"] = np.arange(24)[None, :]; img["y"] = np.arange(16)[:, None]
+    half = O.resize_rgba(img, 8, 12, 0.5)
+    assert (half["x"] == (2 * np.arange(12) + 1)[None, :]).all() and (half["y"] == (2 * np.arange(8) + 1)[:, None]).all()
+    quarter = O.resize_rgba(img, 4, 6, 0.25)
+    assert (quarter["x"] == (4 * np.arange(6) + 3)[None, :]).all() and (quarter["y"] == (4 * np.arange(4) + 3)[:, None]).all()
+
+
+def test_pyramid_level2_is_built_from_level1():
+    """.cuh:649 `int n=log(0.25)/log(ratio)` evaluates to 1 in C++ (float log overload), so level 2 is
+    decimate(blur_1(level 1)), not decimate_4(blur_2(level 0))."""
+    rng = np.random.default_rng(3)
+    raw = np.zeros((48, 64), O.uchar4)
+    for ch in "xyz":
+        raw[ch] = rng.integers(0, 256, (48, 64))
+    imgs, _ = O.prepare(raw)
+    l0 = O.gauss_filter_rgba(raw, 0.5, 2)
+    l1 = O.resize_rgba(O.gauss_filter_rgba(l0, 1.0, 3), 24, 32, 0.5)
+    l2 = O.resize_rgba(O.gauss_filter_rgba(l1, 1.0, 3), 12, 16, 0.5)
+    eq(imgs[0], l0, "L0"); eq(imgs[1], l1, "L1"); eq(imgs[2], l2, "L2")
+
+
+def test_flow_upsample_and_unknown_handling():
+    f = np.zeros((2, 2), O.float2)
+    f["x"] = [[1, 3], [5, 7]]
+    up = O.resize_flow(f, 4, 4, 2.0)
+    # fx = (x+1)/2 - 1 -> -0.5, 0, 0.5, 1: pixel 0, pixel 0, mean, pixel 1
+    assert list(up["x"][0]) == [1, 1, 2, 3]
+    assert list(up["x"][:, 0]) == [1, 1, 3, 5]
+    nnf = np.zeros((1, 3), O.short2)
+    nnf["x"] = [5, -10000, -9990]; nnf["y"] = [0, -10000, 0]
+    fl = O.nnf2flow(nnf)
+    assert fl["x"][0, 0] == 5 and fl["x"][0, 1] == np.float32(1e10) and fl["x"][0, 2] == -9992
+
+
+def test_left_right_check_and_outlier_rules():
+    w = h = 8
+    yy, xx = np.mgrid[0:h, 0:w]
+    n1 = np.zeros((h, w), O.short2); n2 = np.zeros((h, w), O.short2)
+    n1["x"], n1["y"] = xx, yy              # identity both ways: everything consistent
+    n2["x"], n2["y"] = xx, yy
+    n1["x"][0, 0] = 8                      # target outside [0,w) -> invalid
+    n1["x"][3, 3], n1["y"][3, 3] = 4, 3    # points at (4,3) whose backward match is (4,3) != (3,3) -> invalid
+    c = np.ones((h, w), np.float32)
+    a, ca, b, cb = O.left_right_check(n1, c, n2, c)
+    bad = (a["x"] == -10000)
+    assert bad[0, 0] and bad[3, 3] and bad.sum() == 2
+    assert ca[0, 0] == np.finfo(np.float32).max
+    # second launch sees the marks: nnf2[0,0] -> nnf1[0,0] is invalid now
+    assert b["x"][0, 0] == -10000 and b["x"][3, 3] == -10000
+    # outlier: 8x8 image, every pixel has < 84 neighbours in its clipped 13x13 window except none -> all invalid
+    o, _ = O.outlier_removal(a, ca)
+    assert (o["x"] == -10000).all()
+
+
+# ---------------------------------------------------------------- XORWOW
+def test_xorwow_skip_matrix_equals_stepping():
+    full = O.xorwow_stream(1234, 5, 700)
+    for k in (1, 48, 510, 643):
+        assert (O.xorwow_stream(1234, 5, 700 - k, skip=k) == full[k:]).all()
+
+
+def test_xorwow_marsaglia_recurrence():
+    """The state update is Marsaglia's xorwow (JSS 8(14), p.5): checked against an independent numpy restatement."""
+    st = O.xorwow_state(1234, 3)
+    v = [int(x) for x in st[:5]]; d = int(st[5])
+    out = []
+    M = 0xFFFFFFFF
+    for _ in range(16):
+        t = v[0] ^ (v[0] >> 2)
+        v = v[1:] + [((v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1))) & M]
+        d = (d + 362437) & M
+        out.append((v[4] + d) & M)
+    assert [int(x) for x in O.xorwow_stream(1234, 3, 16)] == out
+
+
+# ---------------------------------------------------------------- the reference's own host code (oracle/_ref)
+needs_ref = pytest.mark.skipif(O.refio() is None, reason="oracle/_ref not built (reference sources absent)")
+
+
+@needs_ref
+def test_pyr_dims_match_reference_code():
+    R = O.refio()
+    for h, w in [(436, 1024), (480, 640), (1080, 1920), (2160, 3840), (437, 1023), (101, 77)]:
+        ah, aw = (C.c_int * 8)(), (C.c_int * 8)()
+        n = R.refio_pyr_init_dim(ah, aw, h, w, 3, C.c_float(0.5))
+        assert (list(ah)[:n], list(aw)[:n]) == O.pyr_init_dim(h, w)

@@ -108,10 +108,10 @@ struct eppm_pm_rng {
     uint32_t* work[2] = {nullptr, nullptr};
     uint32_t* skip_mat = nullptr;
     uint32_t skip_weyl = 0;
-    PmRngDev dev(int which) const
+    PmRngDev dev() const
     {
         PmRngDev d;
-        d.init_tab = init_tab; d.iter_tab = iter_tab; d.work = work[which]; d.skip_mat = skip_mat;
+        d.init_tab = init_tab; d.iter_tab = iter_tab; d.skip_mat = skip_mat;
         d.skip_weyl = skip_weyl; d.per_lane = per_lane; d.gx = gx; d.gy = gy;
         return d;
     }
@@ -187,7 +187,7 @@ struct eppm_ctx {
     size_t raw_pitch = 0;
     uint32_t *img1[kMaxLevels] = {}, *img2[kMaxLevels] = {}, *tmpu[kMaxLevels] = {};
     uint8_t *cen1[kMaxLevels] = {}, *cen2[kMaxLevels] = {};
-    int16_t *nnf1 = nullptr, *nnf2 = nullptr, *nnf_tmp = nullptr;
+    int16_t *nnf1 = nullptr, *nnf2 = nullptr, *nnf_tmp = nullptr, *nnf_tmp2 = nullptr;
     float *cost1 = nullptr, *cost2 = nullptr;
     float *flow[kMaxLevels] = {}, *flow_tmp[kMaxLevels] = {};
     float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
@@ -248,7 +248,7 @@ extern "C" int eppm_destroy(eppm_ctx* c)
         (void)hipFree(c->cen1[i]); (void)hipFree(c->cen2[i]);
         (void)hipFree(c->flow[i]); (void)hipFree(c->flow_tmp[i]);
     }
-    (void)hipFree(c->nnf1); (void)hipFree(c->nnf2); (void)hipFree(c->nnf_tmp);
+    (void)hipFree(c->nnf1); (void)hipFree(c->nnf2); (void)hipFree(c->nnf_tmp); (void)hipFree(c->nnf_tmp2);
     (void)hipFree(c->cost1); (void)hipFree(c->cost2);
     (void)hipFree(c->lut_pm); (void)hipFree(c->lut_wmf); (void)hipFree(c->lut_blf);
     (void)hipFree(c->d_rgb);
@@ -288,6 +288,7 @@ static int ctx_alloc(eppm_ctx* c)
     HIPCHK(hipMalloc((void**)&c->nnf1, n * 4));
     HIPCHK(hipMalloc((void**)&c->nnf2, n * 4));
     HIPCHK(hipMalloc((void**)&c->nnf_tmp, n * 4));
+    HIPCHK(hipMalloc((void**)&c->nnf_tmp2, n * 4));
     HIPCHK(hipMalloc((void**)&c->cost1, n * 4));
     HIPCHK(hipMalloc((void**)&c->cost2, n * 4));
     std::vector<float> v;
@@ -420,15 +421,27 @@ extern "C" int eppm_set_images_device(eppm_ctx* c, const void* d1, const void* d
     return prepare(c, c->raw1, c->raw2);
 }
 
-// ---- one PatchMatch call, kernel.cu:1760-1826 ----
-static void run_patchmatch(const PlanesH& P, const PmRngDev& rng, int16_t* nnf, float* cost, int cpitch, int npitch,
-                           const float* lut, const eppm_params& prm, hipStream_t s)
+// ---- baoCudaPatchMatch (kernel.cu:1760-1826) for one problem or for the forward+backward pair at once ----
+static PmProblem mk_problem(const PlanesH& P, float* cost, int16_t* nnf, int16_t* nnf_alt, uint32_t* work)
 {
-    launch_pm_init_field(rng, nnf, npitch, P.w, P.h, s);
-    launch_pm_cost_field(P, cost, cpitch, nnf, npitch, lut, prm.patch_r, s);
+    PmProblem p;
+    p.P = P; p.cost = cost; p.nnf = nnf; p.nnf_alt = nnf_alt; p.rng_work = work;
+    return p;
+}
+// one directional sweep on the batch; keeps the result in p[k].nnf (swaps the ping-pong pair when needed)
+static void sweep(PmBatch& b, const float* lut, const eppm_params& prm, int dir, hipStream_t s)
+{
+    if (launch_pm_sweep(b, lut, prm.patch_r, prm.seg_len, dir, s))
+        for (int k = 0; k < b.n; k++) std::swap(b.p[k].nnf, b.p[k].nnf_alt);
+}
+// returns with the NNF of problem k in b.p[k].nnf (an even number of sweeps: the caller's buffer)
+static void run_patchmatch(PmBatch& b, const PmRngDev& rng, const float* lut, const eppm_params& prm, hipStream_t s)
+{
+    launch_pm_init_field(b, rng, s);
+    launch_pm_cost_field(b, lut, prm.patch_r, s);
     for (int it = 0; it < prm.num_iter; it++) {
-        for (int dir = 0; dir < 4; dir++) launch_pm_seg_propagate(P, cost, cpitch, nnf, npitch, lut, prm.patch_r, prm.seg_len, dir, s);
-        launch_pm_random_search(P, rng, cost, cpitch, nnf, npitch, lut, prm.patch_r, prm.search_range, prm.num_guess, s);
+        for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s);
+        launch_pm_random_search(b, rng, lut, prm.patch_r, prm.search_range, prm.num_guess, s);
     }
 }
 
@@ -442,8 +455,13 @@ extern "C" int eppm_compute_device(eppm_ctx* c, void* d_flow)
     const int lw = c->W[L], lh = c->H[L];
 
     stage_begin(c, c->ev, "patchmatch");
-    run_patchmatch(planes(c, L, false), c->rng->dev(0), c->nnf1, c->cost1, lw, lw, c->lut_pm, c->prm, s);   // driver :223
-    run_patchmatch(planes(c, L, true), c->rng->dev(1), c->nnf2, c->cost2, lw, lw, c->lut_pm, c->prm, s);    // driver :224
+    {
+        PmBatch b;
+        b.n = 2; b.cpitch = lw; b.npitch = lw;
+        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng->work[0]);     // driver :223
+        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng->work[1]);     // driver :224
+        run_patchmatch(b, c->rng->dev(), c->lut_pm, c->prm, s);
+    }
     stage_end(c, c->ev);
 
     stage_begin(c, c->ev, "l2_post");
@@ -677,7 +695,10 @@ extern "C" int eppm_pm_gen_rand_field(eppm_pm_rng* r, eppm_short2* d_nnf, int w,
 {
     if (!r || !d_nnf || w != r->w || h != r->h) return set_err(EPPM_ERR_ARG, "eppm_pm_gen_rand_field: bad argument");
     std::lock_guard<std::mutex> lk(g_mu);
-    launch_pm_init_field(r->dev(0), (int16_t*)d_nnf, (int)(disp_pitch / 4), w, h, g_stream);
+    PmBatch b;
+    b.n = 1; b.cpitch = w; b.npitch = (int)(disp_pitch / 4);
+    b.p[0] = mk_problem(mk_planes(nullptr, nullptr, nullptr, nullptr, w, h, 0, 0), nullptr, (int16_t*)d_nnf, nullptr, r->work[0]);
+    launch_pm_init_field(b, r->dev(), g_stream);
     return finish();
 }
 extern "C" int eppm_pm_cost_field(float* d_cost, const eppm_short2* d_nnf, const eppm_uchar4* i1, const eppm_uchar4* i2,
@@ -685,8 +706,10 @@ extern "C" int eppm_pm_cost_field(float* d_cost, const eppm_short2* d_nnf, const
                                   size_t cost_pitch, size_t disp_pitch, size_t census_pitch)
 {
     LAUNCHER_BEGIN_INT;
-    launch_pm_cost_field(mk_planes(i1, i2, c1, c2, w, h, img_pitch, census_pitch), d_cost, (int)(cost_pitch / 4), (const int16_t*)d_nnf,
-                         (int)(disp_pitch / 4), ds->lut_pm, g_prm.patch_r, g_stream);
+    PmBatch b;
+    b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
+    b.p[0] = mk_problem(mk_planes(i1, i2, c1, c2, w, h, img_pitch, census_pitch), d_cost, (int16_t*)d_nnf, nullptr, nullptr);
+    launch_pm_cost_field(b, ds->lut_pm, g_prm.patch_r, g_stream);
     return finish();
 }
 extern "C" int eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* i1, const eppm_uchar4* i2,
@@ -694,11 +717,14 @@ extern "C" int eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const ep
                                      size_t cost_pitch, size_t disp_pitch, size_t census_pitch, int dir)
 {
     LAUNCHER_BEGIN_INT;
-    const PlanesH P = mk_planes(i1, i2, c1, c2, w, h, img_pitch, census_pitch);
+    void* tmp = nullptr;
+    CHK(get_scratch(ds, disp_pitch * h, &tmp));
+    PmBatch b;
+    b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
+    b.p[0] = mk_problem(mk_planes(i1, i2, c1, c2, w, h, img_pitch, census_pitch), d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr);
     for (int d = 0; d < 4; d++)
-        if (dir < 0 || dir == d)
-            launch_pm_seg_propagate(P, d_cost, (int)(cost_pitch / 4), (int16_t*)d_nnf, (int)(disp_pitch / 4), ds->lut_pm, g_prm.patch_r,
-                                    g_prm.seg_len, d, g_stream);
+        if (dir < 0 || dir == d) sweep(b, ds->lut_pm, g_prm, d, g_stream);
+    if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
     return finish();
 }
 extern "C" int eppm_pm_random_search(eppm_pm_rng* r, float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* i1, const eppm_uchar4* i2,
@@ -708,8 +734,10 @@ extern "C" int eppm_pm_random_search(eppm_pm_rng* r, float* d_cost, eppm_short2*
     if (!r || w != r->w || h != r->h) return set_err(EPPM_ERR_ARG, "eppm_pm_random_search: bad rng");
     LAUNCHER_BEGIN_INT;
     if (r->G != g_prm.num_guess) return set_err(EPPM_ERR_ARG, "rng was created for num_guess=%d", r->G);
-    launch_pm_random_search(mk_planes(i1, i2, c1, c2, w, h, img_pitch, census_pitch), r->dev(0), d_cost, (int)(cost_pitch / 4),
-                            (int16_t*)d_nnf, (int)(disp_pitch / 4), ds->lut_pm, g_prm.patch_r, g_prm.search_range, g_prm.num_guess, g_stream);
+    PmBatch b;
+    b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
+    b.p[0] = mk_problem(mk_planes(i1, i2, c1, c2, w, h, img_pitch, census_pitch), d_cost, (int16_t*)d_nnf, nullptr, r->work[0]);
+    launch_pm_random_search(b, r->dev(), ds->lut_pm, g_prm.patch_r, g_prm.search_range, g_prm.num_guess, g_stream);
     return finish();
 }
 extern "C" int eppm_gauss_filter_rgba(eppm_uchar4* d_out, const eppm_uchar4* d_in, size_t pitch, int h, int w, float sigma, int radius)
@@ -803,8 +831,15 @@ extern "C" void baoCudaPatchMatch(eppm_short2* d_disp_vec, float* d_cost, eppm_u
     eppm_pm_rng* r = nullptr;
     g_launch_status = get_rng(ds, w, h, &r);
     if (g_launch_status != EPPM_OK) return;
-    run_patchmatch(mk_planes(d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch), r->dev(0), (int16_t*)d_disp_vec, d_cost,
-                   (int)(cost_pitch / 4), (int)(disp_pitch / 4), ds->lut_pm, g_prm, g_stream);
+    void* tmp = nullptr;
+    g_launch_status = get_scratch(ds, disp_pitch * h, &tmp);
+    if (g_launch_status != EPPM_OK) return;
+    PmBatch b;
+    b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
+    b.p[0] = mk_problem(mk_planes(d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch), d_cost, (int16_t*)d_disp_vec,
+                        (int16_t*)tmp, r->work[0]);
+    run_patchmatch(b, r->dev(), ds->lut_pm, g_prm, g_stream);
+    if (b.p[0].nnf != (int16_t*)d_disp_vec) (void)hipMemcpyAsync(d_disp_vec, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream);
     g_launch_status = finish();
 }
 

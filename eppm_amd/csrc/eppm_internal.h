@@ -32,23 +32,36 @@ void launch_census(uint8_t* census, int cpitch, const uint32_t* img, int ipitch,
 void launch_rgb_to_rgba(uint32_t* out, int pitch_px, const uint8_t* rgb, int h, int w, hipStream_t s);
 
 // ---- PatchMatch (k_patchmatch.hip) ----
-// RNG tables: per block 64 lane states (6 words each); see xorwow_host.cpp
+// One PatchMatch problem = (source planes, target planes, NNF, cost).  The forward (1->2) and backward (2->1)
+// problems of a pair have the same size and run in the same launches (blockIdx.z / blockIdx.y selects one).
+struct PmProblem {
+    PlanesH P;
+    float* cost;
+    int16_t* nnf;        // short2, current
+    int16_t* nnf_alt;    // short2, ping-pong partner for the sweeps
+    uint32_t* rng_work;  // [nblocks][64][6] XORWOW lane states of the random search
+};
+struct PmBatch {
+    PmProblem p[2];
+    int n;               // 1 or 2
+    int cpitch, npitch;  // elements
+};
+// RNG tables shared by both problems (same seed, same block ids: the reference re-initialises the states on
+// every baoCudaPatchMatch call, kernel.cu:160); see xorwow_host.cpp
 struct PmRngDev {
-    const uint32_t* init_tab;    // [nblocks][64][6] lane l at draw 8*l            (init field)
+    const uint32_t* init_tab;    // [nblocks][64][6] lane l at draw 8*l              (init field)
     const uint32_t* iter_tab;    // [nblocks][64][6] lane l at draw 512 + per_lane*l (first search)
-    uint32_t* work;              // [nblocks][64][6] current search states
     const uint32_t* skip_mat;    // [160][5] GF(2) matrix: advance by (512*G - per_lane) draws
     uint32_t skip_weyl;          // 362437 * (512*G - per_lane)
     int per_lane;                // draws per lane per search = 512*G/64
     int gx, gy;
 };
-void launch_pm_init_field(const PmRngDev& rng, int16_t* nnf, int nnf_pitch, int w, int h, hipStream_t s);
-void launch_pm_cost_field(const PlanesH& P, float* cost, int cost_pitch, const int16_t* nnf, int nnf_pitch, const float* lut,
-                          int R, hipStream_t s);
-void launch_pm_seg_propagate(const PlanesH& P, float* cost, int cost_pitch, int16_t* nnf, int nnf_pitch, const float* lut,
-                             int R, int seg_len, int dir, hipStream_t s);
-void launch_pm_random_search(const PlanesH& P, const PmRngDev& rng, float* cost, int cost_pitch, int16_t* nnf, int nnf_pitch,
-                             const float* lut, int R, int search_range, int num_guess, hipStream_t s);
+void launch_pm_init_field(const PmBatch& b, const PmRngDev& rng, hipStream_t s);
+void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t s);
+// one directional sweep; returns true when the result is in nnf_alt (caller swaps nnf/nnf_alt)
+bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s);
+void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float* lut, int R, int search_range, int num_guess,
+                             hipStream_t s);
 
 // ---- level-2 post-processing (k_post.hip) ----
 void launch_lr_check(int16_t* nnf1, float* cost1, const int16_t* nnf2, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s);

@@ -1,9 +1,14 @@
 // k_patchmatch.hip -- PatchMatch at the coarsest level (reference: bao_pmflow_kernel.cu:50-109 random
 // field, :636-645 cost field, :1049-1181 segmented propagation, :1519-1594 random search).
 //
-// Determinism (DESIGN.md section 3): every kernel realises the "lockstep" order of the racy original --
+// Determinism (DESIGN.md section 3.2): every kernel realises the "lockstep" order of the racy original --
 // all threads read before any thread writes, segment seeds are read at step 0, and the doubly visited
 // forward pixel L is visited by segment 1 before segment 0.
+//
+// MI355X mapping: the quarter-resolution level has only ~28 k pixels (436 waves of one pixel per lane on
+// 1024 SIMDs) and the sweeps only ~2.8 k serial chains per direction, so the kernels spread ONE patch
+// evaluation over 16 lanes (sweeps) or the six guesses of a pixel over separate lanes (search), and the
+// forward and backward problems of a pair share every launch.
 #include "eppm_device.cuh"
 #include "eppm_internal.h"
 
@@ -32,12 +37,14 @@ __device__ __forceinline__ void store_state(uint32_t* p, const Xorwow& s)
 // Random initial NNF (d_setup_randgen + d_gen_rand_field, kernel.cu:50-109).  The reference lets thread
 // (0,0) of each 16x16 block draw 2x256 numbers serially from the block's XORWOW stream; here the 64
 // lanes of one wave each own 8 consecutive draws of the same stream (lane states precomputed on the
-// host by walking the stream once, xorwow_host.cpp), so the numbers are identical and the draw is
-// parallel.  Also rewinds the search states to the position after the 512 init draws.
+// host by walking the stream once, eppm_api.cpp rng_create), so the numbers are identical and the draw
+// is parallel.  Also rewinds the search states to the position after the 512 init draws.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_pm_init_field(PmRngDev rng, int16_t* __restrict__ nnf, int npitch, int w, int h)
+__global__ __launch_bounds__(64) void k_pm_init_field(PmBatch B, PmRngDev rng)
 {
+    const PmProblem& pr = B.p[blockIdx.z];
     const int bx = blockIdx.x, by = blockIdx.y, lane = threadIdx.x;
+    const int w = pr.P.w, h = pr.P.h;
     const int block_id = by * rng.gx + bx;
     const size_t so = ((size_t)block_id * 64 + lane) * 6;
     Xorwow st = load_state(rng.init_tab + so);
@@ -48,59 +55,179 @@ __global__ __launch_bounds__(64) void k_pm_init_field(PmRngDev rng, int16_t* __r
         const int t = lane * 4 + q;                // t = 16*i + j, row-major over the block (kernel.cu:90-101)
         const int x = bx * kBlock + (t & 15), y = by * kBlock + (t >> 4);
         if (x < w && y < h) {
-            nnf[(y * npitch + x) * 2 + 0] = (int16_t)(r1 % (uint32_t)(w + 1));
-            nnf[(y * npitch + x) * 2 + 1] = (int16_t)(r2 % (uint32_t)(h + 1));
+            pr.nnf[(y * B.npitch + x) * 2 + 0] = (int16_t)(r1 % (uint32_t)(w + 1));
+            pr.nnf[(y * B.npitch + x) * 2 + 1] = (int16_t)(r2 % (uint32_t)(h + 1));
         }
     }
     // search stream position = 512 draws in (states are re-initialised on every call, kernel.cu:160)
 #pragma unroll
-    for (int k = 0; k < 6; k++) rng.work[so + k] = rng.iter_tab[so + k];
+    for (int k = 0; k < 6; k++) pr.rng_work[so + k] = rng.iter_tab[so + k];
 }
 
-void launch_pm_init_field(const PmRngDev& rng, int16_t* nnf, int nnf_pitch, int w, int h, hipStream_t s)
+void launch_pm_init_field(const PmBatch& b, const PmRngDev& rng, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pm_init_field, dim3(rng.gx, rng.gy), dim3(64), 0, s, rng, nnf, nnf_pitch, w, h);
+    hipLaunchKernelGGL(k_pm_init_field, dim3(rng.gx, rng.gy, b.n), dim3(64), 0, s, b, rng);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Initial cost field (kernel.cu:636-645)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pm_cost_field(PlanesH Ph, float* __restrict__ cost, int cpitch,
-                                                       const int16_t* __restrict__ nnf, int npitch,
-                                                       const float* __restrict__ lut, int R)
+__global__ __launch_bounds__(256) void k_pm_cost_field(PmBatch B, const float* __restrict__ lut, int R)
 {
     __shared__ PatchLut L;
     load_patch_lut(L, lut, R, threadIdx.y * kBlock + threadIdx.x, 256);
     __syncthreads();
-    const Planes P = to_dev(Ph);
+    const PmProblem& pr = B.p[blockIdx.z];
+    const Planes P = to_dev(pr.P);
     const int x = blockIdx.x * kBlock + threadIdx.x, y = blockIdx.y * kBlock + threadIdx.y;
     if (x >= P.w || y >= P.h) return;
-    const int dx = nnf[(y * npitch + x) * 2], dy = nnf[(y * npitch + x) * 2 + 1];
-    cost[y * cpitch + x] = patch_dist(P, L, R, x, y, dx, dy);
+    const int dx = pr.nnf[(y * B.npitch + x) * 2], dy = pr.nnf[(y * B.npitch + x) * 2 + 1];
+    pr.cost[y * B.cpitch + x] = patch_dist(P, L, R, x, y, dx, dy);
 }
 
-void launch_pm_cost_field(const PlanesH& P, float* cost, int cost_pitch, const int16_t* nnf, int nnf_pitch, const float* lut,
-                          int R, hipStream_t s)
+void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t s)
 {
-    dim3 grid((P.w + kBlock - 1) / kBlock, (P.h + kBlock - 1) / kBlock), block(kBlock, kBlock);
-    hipLaunchKernelGGL(k_pm_cost_field, grid, block, 0, s, P, cost, cost_pitch, nnf, nnf_pitch, lut, R);
+    const int w = b.p[0].P.w, h = b.p[0].P.h;
+    dim3 grid((w + kBlock - 1) / kBlock, (h + kBlock - 1) / kBlock, b.n), block(kBlock, kBlock);
+    hipLaunchKernelGGL(k_pm_cost_field, grid, block, 0, s, b, lut, R);
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Segmented scan-line propagation (kernel.cu:1049-1181).  One thread = (line, segment); all segments
-// of a line live in one workgroup so that the two ordering points of the lockstep semantics are
-// workgroup barriers: (a) every seed is read before any walk writes, (b) segment 1's first step
-// (pixel L) precedes segment 0's last step (the same pixel) -- barrier after step 0.
+// Segmented scan-line propagation (kernel.cu:1049-1181), cooperative form.
+//
+// A chain = (line, segment): up to L sequential steps, each one patch evaluation whose candidate depends
+// on the previous step's outcome.  The reference gives a chain ONE thread; at quarter resolution that is
+// ~45 waves on the whole chip.  Here one chain owns a DPP row of 16 lanes.  Per step the S*S samples of
+// the patch (row-major, the reference's order) are dealt to the lanes in contiguous chunks of CH; every
+// lane computes the (cost*w, w) terms of its chunk, then the two running sums travel lane to lane
+// (row_ror:1) while every lane adds its chunk in order: the sums are formed in exactly the reference's
+// sequential order, only the expensive per-sample terms are computed in parallel.
+//
+// Ordering points of the lockstep semantics:
+//  (a) seeds are read from nnf_in, all writes go to nnf_out (ping-pong) -- no cross-workgroup hazard;
+//  (b) forward pixel L: segment 1's first step precedes segment 0's last step; segments 0 and 1 of a
+//      line are always in one workgroup (chains per line padded to an even count, 16 chains per
+//      workgroup) and a workgroup barrier follows step 0.
+// cost is updated in place: a pixel's cost is touched only by its visitor(s).
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_row_ror1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+}
+
+template <int R, bool IS_ROW, bool REVERSE>
+__global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __restrict__ lut, int L_, int nseg, int nseg_pad)
+{
+    constexpr int S = R + 1, NS = S * S, CH = (NS + 15) / 16;
+    __shared__ PatchLut L;
+    load_patch_lut(L, lut, R, threadIdx.x, 256);
+    const PmProblem& pr = B.p[blockIdx.y];
+    const Planes P = to_dev(pr.P);
+    const int16_t* __restrict__ nin = pr.nnf;
+    int16_t* __restrict__ nout = pr.nnf_alt;
+    float* __restrict__ cost = pr.cost;
+    const int len = IS_ROW ? P.w : P.h, lines = IS_ROW ? P.h : P.w;
+    const int grp = threadIdx.x >> 4, r = threadIdx.x & 15;
+    const int chain = blockIdx.x * 16 + grp;
+    const int line = chain / nseg_pad, seg = chain % nseg_pad;
+    const bool active = (line < lines) && (seg < nseg);
+    int start, count, i, step;
+    if (!REVERSE) {
+        start = (seg == 0) ? 0 : seg * L_ - 1;
+        const int end = min(len - 1, start + L_);
+        count = end - start;
+        i = start + 1;
+        step = 1;
+    } else {
+        start = (seg + 1) * L_;
+        if (start >= len) start = len - 1;
+        count = start - seg * L_;
+        i = start - 1;
+        step = -1;
+    }
+    int px = 0, py = 0;
+    if (active) {
+        const int sidx = IS_ROW ? (line * B.npitch + start) : (start * B.npitch + line);
+        px = nin[sidx * 2];
+        py = nin[sidx * 2 + 1];
+        // the one pixel of the line no chain visits keeps its value
+        const bool copier = REVERSE ? (seg == nseg - 1) : (seg == 0);
+        if (copier && r == 0) {
+            const int u = REVERSE ? len - 1 : 0;
+            const int uidx = IS_ROW ? (line * B.npitch + u) : (u * B.npitch + line);
+            nout[uidx * 2] = nin[uidx * 2];
+            nout[uidx * 2 + 1] = nin[uidx * 2 + 1];
+        }
+    }
+    __syncthreads();   // LUT ready
+    const int t0 = r * CH;
+    for (int s = 0; s < L_; s++) {
+        if (active && s < count) {
+            const int x = IS_ROW ? i : line, y = IS_ROW ? line : i;
+            const int nidx = y * B.npitch + x, cidx = y * B.cpitch + x;
+            const float cur_best = cost[cidx];
+            if (IS_ROW) px = REVERSE ? max(px - 1, 0) : min(px + 1, P.w - 1);
+            else        py = REVERSE ? max(py - 1, 0) : min(py + 1, P.h - 1);
+            const rgbf c1 = unpack_rgb(tex_px(P.img1, P.ipitch, P.w, P.h, x, y));
+            const rgbf c2 = unpack_rgb(tex_px(P.img2, P.ipitch, P.w, P.h, px, py));
+            float tc[CH], tw[CH];
+#pragma unroll
+            for (int q = 0; q < CH; q++) {
+                const int t = t0 + q;
+                tc[q] = 0.0f; tw[q] = 0.0f;
+                if (t < NS) {
+                    const int ii = t / S, jj = t % S;
+                    const int di = 2 * ii - R, dj = 2 * jj - R;
+                    patch_sample(P, c1, c2, x + dj, y + di, px + dj, py + di, L.gsp[t], L.cn, tc[q], tw[q]);
+                }
+            }
+            // sequential sums in sample order: lane 0's chunk first, then the partial sums move one lane right
+            float ac = 0.0f, aw = 0.0f;
+            constexpr int NL = (NS + CH - 1) / CH;       // lanes that own samples
+#pragma unroll
+            for (int ln = 0; ln < NL; ln++) {
+                if (ln > 0) { ac = dpp_row_ror1(ac); aw = dpp_row_ror1(aw); }
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    if (ln * CH + q < NS) { ac += tc[q]; aw += tw[q]; }
+                }
+            }
+            const int src = (threadIdx.x & 48) | (NL - 1);          // lane holding the complete sums (wave-relative)
+            const float cs = __shfl(ac, src, 64), ws = __shfl(aw, src, 64);
+            const float cv = cs / ws;
+            const bool second_visit = (!REVERSE) && (seg == 0) && (s == L_ - 1) && (nseg > 1);   // pixel L, after segment 1
+            if (cv < cur_best) {
+                if (r == 0) {
+                    nout[nidx * 2] = (int16_t)px;
+                    nout[nidx * 2 + 1] = (int16_t)py;
+                    cost[cidx] = cv;
+                }
+            } else {
+                const int ox = nin[nidx * 2], oy = nin[nidx * 2 + 1];
+                if (r == 0 && !second_visit) {
+                    nout[nidx * 2] = (int16_t)ox;
+                    nout[nidx * 2 + 1] = (int16_t)oy;
+                }
+                px = ox; py = oy;
+            }
+            i += step;
+        }
+        if (!REVERSE && s == 0) __syncthreads();   // (b)
+    }
+}
+
+// Fallback for patch radii without a cooperative instantiation: the reference's one-thread-per-chain form,
+// in place, all segments of a line in one workgroup (seed reads / pixel-L order by workgroup barriers).
 template <bool IS_ROW, bool REVERSE>
-__global__ __launch_bounds__(1024) void k_pm_seg_propagate(PlanesH Ph, float* __restrict__ cost, int cpitch,
-                                                           int16_t* __restrict__ nnf, int npitch,
-                                                           const float* __restrict__ lut, int R, int L_, int nseg,
+__global__ __launch_bounds__(1024) void k_pm_seg_propagate(PmBatch B, const float* __restrict__ lut, int R, int L_, int nseg,
                                                            int lines_per_block)
 {
     __shared__ PatchLut L;
     load_patch_lut(L, lut, R, threadIdx.x, blockDim.x);
-    const Planes P = to_dev(Ph);
+    const PmProblem& pr = B.p[blockIdx.y];
+    const Planes P = to_dev(pr.P);
+    int16_t* __restrict__ nnf = pr.nnf;
+    float* __restrict__ cost = pr.cost;
     const int len = IS_ROW ? P.w : P.h, lines = IS_ROW ? P.h : P.w;
     const int lline = threadIdx.x / nseg, seg = threadIdx.x % nseg;
     const int line = blockIdx.x * lines_per_block + lline;
@@ -121,7 +248,7 @@ __global__ __launch_bounds__(1024) void k_pm_seg_propagate(PlanesH Ph, float* __
     }
     int px = 0, py = 0;
     if (active) {
-        const int sidx = IS_ROW ? (line * npitch + start) : (start * npitch + line);
+        const int sidx = IS_ROW ? (line * B.npitch + start) : (start * B.npitch + line);
         px = nnf[sidx * 2];
         py = nnf[sidx * 2 + 1];
     }
@@ -129,7 +256,7 @@ __global__ __launch_bounds__(1024) void k_pm_seg_propagate(PlanesH Ph, float* __
     for (int s = 0; s < L_; s++) {
         if (active && s < count) {
             const int x = IS_ROW ? i : line, y = IS_ROW ? line : i;
-            const int nidx = y * npitch + x, cidx = y * cpitch + x;
+            const int nidx = y * B.npitch + x, cidx = y * B.cpitch + x;
             const float cur_best = cost[cidx];
             if (IS_ROW) px = REVERSE ? max(px - 1, 0) : min(px + 1, P.w - 1);
             else        py = REVERSE ? max(py - 1, 0) : min(py + 1, P.h - 1);
@@ -148,44 +275,67 @@ __global__ __launch_bounds__(1024) void k_pm_seg_propagate(PlanesH Ph, float* __
     }
 }
 
-void launch_pm_seg_propagate(const PlanesH& P, float* cost, int cost_pitch, int16_t* nnf, int nnf_pitch, const float* lut,
-                             int R, int seg_len, int dir, hipStream_t s)
+template <int R>
+static void launch_sweep_r(const PmBatch& b, const float* lut, int seg_len, int dir, int nseg, int lines, hipStream_t s)
 {
+    const int nseg_pad = (nseg + 1) & ~1;
+    const int chains = lines * nseg_pad;
+    dim3 grid((chains + 15) / 16, b.n), block(256);
+    switch (dir) {
+        case 0: hipLaunchKernelGGL((k_pm_sweep<R, true, false>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
+        case 1: hipLaunchKernelGGL((k_pm_sweep<R, false, false>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
+        case 2: hipLaunchKernelGGL((k_pm_sweep<R, true, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
+        default: hipLaunchKernelGGL((k_pm_sweep<R, false, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
+    }
+}
+
+bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s)
+{
+    const PlanesH& P = b.p[0].P;
     const bool is_row = (dir == 0 || dir == 2);
     const int len = is_row ? P.w : P.h, lines = is_row ? P.h : P.w;
     const int nseg = (len + seg_len - 1) / seg_len;
-    if (nseg > 1024) return;   // caller validates (image wider than 10240*4 px)
+    if (R == 9) { launch_sweep_r<9>(b, lut, seg_len, dir, nseg, lines, s); return true; }
+    if (R == 17) { launch_sweep_r<17>(b, lut, seg_len, dir, nseg, lines, s); return true; }
+    if (nseg > 1024) return false;   // eppm_create / the launchers validate sizes
     int lpb = 256 / nseg;
     if (lpb < 1) lpb = 1;
-    int threads = ((nseg * lpb + 63) / 64) * 64;
-    dim3 grid((lines + lpb - 1) / lpb), block(threads);
+    const int threads = ((nseg * lpb + 63) / 64) * 64;
+    dim3 grid((lines + lpb - 1) / lpb, b.n), block(threads);
     switch (dir) {
-        case 0: hipLaunchKernelGGL((k_pm_seg_propagate<true, false>), grid, block, 0, s, P, cost, cost_pitch, nnf, nnf_pitch, lut, R, seg_len, nseg, lpb); break;
-        case 1: hipLaunchKernelGGL((k_pm_seg_propagate<false, false>), grid, block, 0, s, P, cost, cost_pitch, nnf, nnf_pitch, lut, R, seg_len, nseg, lpb); break;
-        case 2: hipLaunchKernelGGL((k_pm_seg_propagate<true, true>), grid, block, 0, s, P, cost, cost_pitch, nnf, nnf_pitch, lut, R, seg_len, nseg, lpb); break;
-        default: hipLaunchKernelGGL((k_pm_seg_propagate<false, true>), grid, block, 0, s, P, cost, cost_pitch, nnf, nnf_pitch, lut, R, seg_len, nseg, lpb); break;
+        case 0: hipLaunchKernelGGL((k_pm_seg_propagate<true, false>), grid, block, 0, s, b, lut, R, seg_len, nseg, lpb); break;
+        case 1: hipLaunchKernelGGL((k_pm_seg_propagate<false, false>), grid, block, 0, s, b, lut, R, seg_len, nseg, lpb); break;
+        case 2: hipLaunchKernelGGL((k_pm_seg_propagate<true, true>), grid, block, 0, s, b, lut, R, seg_len, nseg, lpb); break;
+        default: hipLaunchKernelGGL((k_pm_seg_propagate<false, true>), grid, block, 0, s, b, lut, R, seg_len, nseg, lpb); break;
     }
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Random search (kernel.cu:1519-1594): G guesses at radii search_range, /2, ... around the pre-search
-// best, evaluated in order with strict <.  Random numbers: the block's XORWOW stream, 2x256 draws per
-// guess in row-major pixel order; wave 0 produces the 512*G draws of this launch in parallel (lane l
-// owns draws [per_lane*l, per_lane*(l+1)) ), then jumps its state over the other lanes' draws with the
-// GF(2) skip matrix so that the next launch continues the same stream.
+// best, evaluated in order with strict <.
+// Random numbers: the block's XORWOW stream, 2x256 draws per guess in row-major pixel order; wave 0
+// produces the 512*G draws of this launch in parallel (lane l owns draws [per_lane*l, per_lane*(l+1)) ),
+// then jumps its state over the other lanes' draws with the GF(2) skip matrix so that the next launch
+// continues the same stream.
+// Evaluation: all guesses come from the pre-search best, so their costs are independent; thread
+// (slot, pixel) evaluates guesses slot and slot+NSLOT of its pixel, the costs meet in LDS and the pixel's
+// first thread replays the reference's in-order strict-< selection.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pm_random_search(PlanesH Ph, PmRngDev rng, float* __restrict__ cost, int cpitch,
-                                                          int16_t* __restrict__ nnf, int npitch,
-                                                          const float* __restrict__ lut, int R, int search_range, int G)
+__global__ __launch_bounds__(1024) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
+                                                           int search_range, int G, int nslot)
 {
     __shared__ PatchLut L;
     __shared__ int16_t s_rand[8 * 512];
-    const int tid = threadIdx.y * kBlock + threadIdx.x;
+    __shared__ float s_cost[8][256];
+    __shared__ int s_guess[8][256];
+    const PmProblem& pr = B.p[blockIdx.z];
+    const int tid = threadIdx.x;
     const int block_id = blockIdx.y * rng.gx + blockIdx.x;
-    load_patch_lut(L, lut, R, tid, 256);
+    load_patch_lut(L, lut, R, tid, blockDim.x);
     if (tid < 64) {
         const size_t so = ((size_t)block_id * 64 + tid) * 6;
-        Xorwow st = load_state(rng.work + so);
+        Xorwow st = load_state(pr.rng_work + so);
         const int base = rng.per_lane * tid;
         for (int q = 0; q < rng.per_lane; q++) s_rand[base + q] = (int16_t)xorwow_next(st);   // short(rdn), :1550-1551
         // jump over the other 63 lanes' draws: v <- v * skip_mat over GF(2); Weyl counter by multiplication
@@ -203,45 +353,53 @@ __global__ __launch_bounds__(256) void k_pm_random_search(PlanesH Ph, PmRngDev r
         }
         st.v0 = a0; st.v1 = a1; st.v2 = a2; st.v3 = a3; st.v4 = a4;
         st.d += rng.skip_weyl;
-        store_state(rng.work + so, st);
+        store_state(pr.rng_work + so, st);
     }
     __syncthreads();
-    const Planes P = to_dev(Ph);
-    const int x = blockIdx.x * kBlock + threadIdx.x, y = blockIdx.y * kBlock + threadIdx.y;
-    if (x >= P.w || y >= P.h) return;
-    const int nidx = y * npitch + x, cidx = y * cpitch + x;
-    int bx = nnf[nidx * 2], by = nnf[nidx * 2 + 1];
-    float best_cost = cost[cidx];
-    int gxs[8], gys[8];
-    int mag = search_range;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        if (k < G) {
-            const uint32_t rdn1 = (uint32_t)(int32_t)s_rand[512 * k + 2 * tid];       // short -> unsigned int
-            const uint32_t rdn2 = (uint32_t)(int32_t)s_rand[512 * k + 2 * tid + 1];
+    const Planes P = to_dev(pr.P);
+    const int pix = tid & 255, slot = tid >> 8;
+    const int x = blockIdx.x * kBlock + (pix & 15), y = blockIdx.y * kBlock + (pix >> 4);
+    const bool inimg = (x < P.w && y < P.h);
+    const int nidx = y * B.npitch + x, cidx = y * B.cpitch + x;
+    int bx = 0, by = 0;
+    if (inimg) { bx = pr.nnf[nidx * 2]; by = pr.nnf[nidx * 2 + 1]; }
+    if (inimg) {
+        for (int k = slot; k < G; k += nslot) {
+            // sampling window of guess k: mag = search_range halved k times while >= 1 (:1564)
+            int mag = search_range;
+            for (int q = 0; q < k; q++) if (mag / 2 >= 1) mag /= 2;
+            const uint32_t rdn1 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix];       // short -> unsigned int, :1558-1559
+            const uint32_t rdn2 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix + 1];
             const int xmin = max(bx - mag, 0), xmax = min(bx + mag + 1, P.w + 1);
             const int ymin = max(by - mag, 0), ymax = min(by + mag + 1, P.h + 1);
-            gxs[k] = (int)(int16_t)((uint32_t)xmin + rdn1 % (uint32_t)(xmax - xmin));
-            gys[k] = (int)(int16_t)((uint32_t)ymin + rdn2 % (uint32_t)(ymax - ymin));
-            if (mag / 2 >= 1) mag /= 2;
+            const int gx = (int)(int16_t)((uint32_t)xmin + rdn1 % (uint32_t)(xmax - xmin));
+            const int gy = (int)(int16_t)((uint32_t)ymin + rdn2 % (uint32_t)(ymax - ymin));
+            s_cost[k][pix] = patch_dist(P, L, R, x, y, gx, gy);
+            s_guess[k][pix] = (gx & 0xffff) | (gy << 16);
         }
     }
-#pragma unroll 1
-    for (int k = 0; k < G; k++) {
-        const float cv = patch_dist(P, L, R, x, y, gxs[k], gys[k]);
-        if (cv < best_cost) { bx = gxs[k]; by = gys[k]; best_cost = cv; }
+    __syncthreads();
+    if (slot == 0 && inimg) {
+        float best_cost = pr.cost[cidx];
+        for (int k = 0; k < G; k++) {
+            const float cv = s_cost[k][pix];
+            if (cv < best_cost) {
+                const int g = s_guess[k][pix];
+                bx = (int)(int16_t)(g & 0xffff); by = g >> 16; best_cost = cv;
+            }
+        }
+        pr.nnf[nidx * 2] = (int16_t)bx;
+        pr.nnf[nidx * 2 + 1] = (int16_t)by;
+        pr.cost[cidx] = best_cost;
     }
-    nnf[nidx * 2] = (int16_t)bx;
-    nnf[nidx * 2 + 1] = (int16_t)by;
-    cost[cidx] = best_cost;
 }
 
-void launch_pm_random_search(const PlanesH& P, const PmRngDev& rng, float* cost, int cost_pitch, int16_t* nnf, int nnf_pitch,
-                             const float* lut, int R, int search_range, int num_guess, hipStream_t s)
+void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float* lut, int R, int search_range, int num_guess,
+                             hipStream_t s)
 {
-    dim3 grid(rng.gx, rng.gy), block(kBlock, kBlock);
-    hipLaunchKernelGGL(k_pm_random_search, grid, block, 0, s, P, rng, cost, cost_pitch, nnf, nnf_pitch, lut, R, search_range,
-                       num_guess);
+    const int nslot = (num_guess + 1) / 2;         // two guesses per thread
+    dim3 grid(rng.gx, rng.gy, b.n), block(256 * nslot);
+    hipLaunchKernelGGL(k_pm_random_search, grid, block, 0, s, b, rng, lut, R, search_range, num_guess, nslot);
 }
 
 }  // namespace eppm

@@ -187,6 +187,7 @@ struct eppm_ctx {
     size_t raw_pitch = 0;
     uint32_t *img1[kMaxLevels] = {}, *img2[kMaxLevels] = {}, *tmpu[kMaxLevels] = {};
     uint8_t *cen1[kMaxLevels] = {}, *cen2[kMaxLevels] = {};
+    uint32_t *pk1[kMaxLevels] = {}, *pk2[kMaxLevels] = {};   // packed rgb|census<<24, same pitch as the images
     int16_t *nnf1 = nullptr, *nnf2 = nullptr, *nnf_tmp = nullptr, *nnf_tmp2 = nullptr;
     float *cost1 = nullptr, *cost2 = nullptr;
     float *flow[kMaxLevels] = {}, *flow_tmp[kMaxLevels] = {};
@@ -204,13 +205,10 @@ struct eppm_ctx {
 static PlanesH planes(const eppm_ctx* c, int l, bool swap)
 {
     PlanesH p;
-    p.img1 = swap ? c->img2[l] : c->img1[l];
-    p.img2 = swap ? c->img1[l] : c->img2[l];
-    p.cen1 = swap ? c->cen2[l] : c->cen1[l];
-    p.cen2 = swap ? c->cen1[l] : c->cen2[l];
+    p.pk1 = swap ? c->pk2[l] : c->pk1[l];
+    p.pk2 = swap ? c->pk1[l] : c->pk2[l];
     p.w = c->W[l]; p.h = c->H[l];
-    p.ipitch = (int)(c->ipitch[l] / 4);
-    p.cpitch = (int)c->cpitch[l];
+    p.pitch = (int)(c->ipitch[l] / 4);
     return p;
 }
 
@@ -245,7 +243,7 @@ extern "C" int eppm_destroy(eppm_ctx* c)
     (void)hipFree(c->raw1); (void)hipFree(c->raw2);
     for (int i = 0; i < kMaxLevels; i++) {
         (void)hipFree(c->img1[i]); (void)hipFree(c->img2[i]); (void)hipFree(c->tmpu[i]);
-        (void)hipFree(c->cen1[i]); (void)hipFree(c->cen2[i]);
+        (void)hipFree(c->cen1[i]); (void)hipFree(c->cen2[i]); (void)hipFree(c->pk1[i]); (void)hipFree(c->pk2[i]);
         (void)hipFree(c->flow[i]); (void)hipFree(c->flow_tmp[i]);
     }
     (void)hipFree(c->nnf1); (void)hipFree(c->nnf2); (void)hipFree(c->nnf_tmp); (void)hipFree(c->nnf_tmp2);
@@ -276,6 +274,8 @@ static int ctx_alloc(eppm_ctx* c)
         HIPCHK(hipMallocPitch((void**)&c->img1[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
         HIPCHK(hipMallocPitch((void**)&c->img2[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
         HIPCHK(hipMallocPitch((void**)&c->tmpu[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
+        HIPCHK(hipMallocPitch((void**)&c->pk1[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
+        HIPCHK(hipMallocPitch((void**)&c->pk2[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
         HIPCHK(hipMallocPitch((void**)&c->cen1[i], &c->cpitch[i], (size_t)c->W[i], c->H[i]));
         HIPCHK(hipMallocPitch((void**)&c->cen2[i], &c->cpitch[i], (size_t)c->W[i], c->H[i]));
         const size_t n = (size_t)c->W[i] * c->H[i];
@@ -354,7 +354,7 @@ extern "C" int eppm_enable_stage_timing(eppm_ctx* c, int on)
 }
 
 // ---- prepare: refine :1060-1071 + .cuh:642-664 ----
-static int prepare_one(eppm_ctx* c, uint32_t** pyr, uint8_t** cen, uint32_t** tmp, const uint32_t* raw)
+static int prepare_one(eppm_ctx* c, uint32_t** pyr, uint8_t** cen, uint32_t** pk, uint32_t** tmp, const uint32_t* raw)
 {
     hipStream_t s = c->stream;
     const int p0 = (int)(c->ipitch[0] / 4);
@@ -375,15 +375,16 @@ static int prepare_one(eppm_ctx* c, uint32_t** pyr, uint8_t** cen, uint32_t** tm
                                (float)pow(ratio, i) * c->W[0] / c->W[j], s);
         }
     }
-    for (int i = 0; i < c->nl; i++) launch_census(cen[i], (int)c->cpitch[i], pyr[i], (int)(c->ipitch[i] / 4), c->W[i], c->H[i], s);
+    for (int i = 0; i < c->nl; i++)
+        launch_census(cen[i], (int)c->cpitch[i], pk[i], (int)(c->ipitch[i] / 4), pyr[i], (int)(c->ipitch[i] / 4), c->W[i], c->H[i], s);
     return EPPM_OK;
 }
 
 static int prepare(eppm_ctx* c, const uint32_t* raw1, const uint32_t* raw2)
 {
     stage_begin(c, c->ev_prep, "prepare");
-    CHK(prepare_one(c, c->img1, c->cen1, c->tmpu, raw1));
-    CHK(prepare_one(c, c->img2, c->cen2, c->tmpu, raw2));
+    CHK(prepare_one(c, c->img1, c->cen1, c->pk1, c->tmpu, raw1));
+    CHK(prepare_one(c, c->img2, c->cen2, c->pk2, c->tmpu, raw2));
     stage_end(c, c->ev_prep);
     HIPCHK(hipGetLastError());
     c->have_images = true;
@@ -589,8 +590,8 @@ namespace {
 struct DevState {
     float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
     int lut_R = -1;
-    void* scratch = nullptr;
-    size_t scratch_bytes = 0;
+    void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
     std::map<std::tuple<int, int, int, unsigned long long>, eppm_pm_rng*> rngs;
 };
 std::mutex g_mu;
@@ -616,16 +617,16 @@ int dev_state(DevState** out)
     *out = &s;
     return EPPM_OK;
 }
-int get_scratch(DevState* s, size_t bytes, void** out)
+int get_scratch(DevState* s, size_t bytes, void** out, int slot = 0)
 {
-    if (s->scratch_bytes < bytes) {
+    if (s->scratch_bytes[slot] < bytes) {
         (void)hipStreamSynchronize(g_stream);
-        (void)hipFree(s->scratch);
-        s->scratch = nullptr; s->scratch_bytes = 0;
-        HIPCHK(hipMalloc(&s->scratch, bytes));
-        s->scratch_bytes = bytes;
+        (void)hipFree(s->scratch[slot]);
+        s->scratch[slot] = nullptr; s->scratch_bytes[slot] = 0;
+        HIPCHK(hipMalloc(&s->scratch[slot], bytes));
+        s->scratch_bytes[slot] = bytes;
     }
-    *out = s->scratch;
+    *out = s->scratch[slot];
     return EPPM_OK;
 }
 int get_rng(DevState* s, int w, int h, eppm_pm_rng** out)
@@ -640,12 +641,17 @@ int get_rng(DevState* s, int w, int h, eppm_pm_rng** out)
     *out = it->second;
     return EPPM_OK;
 }
-PlanesH mk_planes(const void* i1, const void* i2, const void* c1, const void* c2, int w, int h, size_t ip, size_t cp)
+// The reference-signature launchers receive image and census planes apart (they were separate textures,
+// kernel.cu:1770-1781); the kernels read the packed plane, built here into per-device scratch (slots 2,3).
+int mk_planes(DevState* ds, PlanesH* out, const void* i1, const void* i2, const void* c1, const void* c2, int w, int h, size_t ip, size_t cp)
 {
-    PlanesH p;
-    p.img1 = (const uint32_t*)i1; p.img2 = (const uint32_t*)i2; p.cen1 = (const uint8_t*)c1; p.cen2 = (const uint8_t*)c2;
-    p.w = w; p.h = h; p.ipitch = (int)(ip / 4); p.cpitch = (int)cp;
-    return p;
+    void *a = nullptr, *b = nullptr;
+    CHK(get_scratch(ds, (size_t)w * h * 4, &a, 2));
+    CHK(get_scratch(ds, (size_t)w * h * 4, &b, 3));
+    launch_pack((uint32_t*)a, w, (const uint32_t*)i1, (int)(ip / 4), (const uint8_t*)c1, (int)cp, w, h, g_stream);
+    launch_pack((uint32_t*)b, w, (const uint32_t*)i2, (int)(ip / 4), (const uint8_t*)c2, (int)cp, w, h, g_stream);
+    out->pk1 = (const uint32_t*)a; out->pk2 = (const uint32_t*)b; out->w = w; out->h = h; out->pitch = w;
+    return EPPM_OK;
 }
 int finish() { HIPCHK(hipGetLastError()); return EPPM_OK; }
 }  // namespace
@@ -697,7 +703,9 @@ extern "C" int eppm_pm_gen_rand_field(eppm_pm_rng* r, eppm_short2* d_nnf, int w,
     std::lock_guard<std::mutex> lk(g_mu);
     PmBatch b;
     b.n = 1; b.cpitch = w; b.npitch = (int)(disp_pitch / 4);
-    b.p[0] = mk_problem(mk_planes(nullptr, nullptr, nullptr, nullptr, w, h, 0, 0), nullptr, (int16_t*)d_nnf, nullptr, r->work[0]);
+    PlanesH P0;
+    P0.pk1 = P0.pk2 = nullptr; P0.w = w; P0.h = h; P0.pitch = w;
+    b.p[0] = mk_problem(P0, nullptr, (int16_t*)d_nnf, nullptr, r->work[0]);
     launch_pm_init_field(b, r->dev(), g_stream);
     return finish();
 }
@@ -708,7 +716,9 @@ extern "C" int eppm_pm_cost_field(float* d_cost, const eppm_short2* d_nnf, const
     LAUNCHER_BEGIN_INT;
     PmBatch b;
     b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
-    b.p[0] = mk_problem(mk_planes(i1, i2, c1, c2, w, h, img_pitch, census_pitch), d_cost, (int16_t*)d_nnf, nullptr, nullptr);
+    PlanesH P;
+    CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, nullptr, nullptr);
     launch_pm_cost_field(b, ds->lut_pm, g_prm.patch_r, g_stream);
     return finish();
 }
@@ -721,7 +731,9 @@ extern "C" int eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const ep
     CHK(get_scratch(ds, disp_pitch * h, &tmp));
     PmBatch b;
     b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
-    b.p[0] = mk_problem(mk_planes(i1, i2, c1, c2, w, h, img_pitch, census_pitch), d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr);
+    PlanesH P;
+    CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr);
     for (int d = 0; d < 4; d++)
         if (dir < 0 || dir == d) sweep(b, ds->lut_pm, g_prm, d, g_stream);
     if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
@@ -736,7 +748,9 @@ extern "C" int eppm_pm_random_search(eppm_pm_rng* r, float* d_cost, eppm_short2*
     if (r->G != g_prm.num_guess) return set_err(EPPM_ERR_ARG, "rng was created for num_guess=%d", r->G);
     PmBatch b;
     b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
-    b.p[0] = mk_problem(mk_planes(i1, i2, c1, c2, w, h, img_pitch, census_pitch), d_cost, (int16_t*)d_nnf, nullptr, r->work[0]);
+    PlanesH P;
+    CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, nullptr, r->work[0]);
     launch_pm_random_search(b, r->dev(), ds->lut_pm, g_prm.patch_r, g_prm.search_range, g_prm.num_guess, g_stream);
     return finish();
 }
@@ -781,8 +795,8 @@ extern "C" void baoCudaCensusTransform(unsigned char* d_census1, unsigned char* 
                                        int w, int h, size_t img_pitch, size_t census_pitch)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    launch_census(d_census1, (int)census_pitch, (const uint32_t*)d_img1, (int)(img_pitch / 4), w, h, g_stream);
-    launch_census(d_census2, (int)census_pitch, (const uint32_t*)d_img2, (int)(img_pitch / 4), w, h, g_stream);
+    launch_census(d_census1, (int)census_pitch, nullptr, 0, (const uint32_t*)d_img1, (int)(img_pitch / 4), w, h, g_stream);
+    launch_census(d_census2, (int)census_pitch, nullptr, 0, (const uint32_t*)d_img2, (int)(img_pitch / 4), w, h, g_stream);
     g_launch_status = finish();
 }
 
@@ -817,8 +831,8 @@ extern "C" void baoCudaPatchMatchMultiscalePrepare(eppm_uchar4** pImgPyr1, eppm_
         }
     }
     for (int i = 0; i < nLevels; i++) {
-        launch_census(pCensusPyr1[i], (int)arrPitchUchar1[i], (const uint32_t*)pImgPyr1[i], (int)(arrPitchUchar4[i] / 4), arrW[i], arrH[i], s);
-        launch_census(pCensusPyr2[i], (int)arrPitchUchar1[i], (const uint32_t*)pImgPyr2[i], (int)(arrPitchUchar4[i] / 4), arrW[i], arrH[i], s);
+        launch_census(pCensusPyr1[i], (int)arrPitchUchar1[i], nullptr, 0, (const uint32_t*)pImgPyr1[i], (int)(arrPitchUchar4[i] / 4), arrW[i], arrH[i], s);
+        launch_census(pCensusPyr2[i], (int)arrPitchUchar1[i], nullptr, 0, (const uint32_t*)pImgPyr2[i], (int)(arrPitchUchar4[i] / 4), arrW[i], arrH[i], s);
     }
     g_launch_status = finish();
 }
@@ -836,8 +850,10 @@ extern "C" void baoCudaPatchMatch(eppm_short2* d_disp_vec, float* d_cost, eppm_u
     if (g_launch_status != EPPM_OK) return;
     PmBatch b;
     b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
-    b.p[0] = mk_problem(mk_planes(d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch), d_cost, (int16_t*)d_disp_vec,
-                        (int16_t*)tmp, r->work[0]);
+    PlanesH P;
+    g_launch_status = mk_planes(ds, &P, d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch);
+    if (g_launch_status != EPPM_OK) return;
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r->work[0]);
     run_patchmatch(b, r->dev(), ds->lut_pm, g_prm, g_stream);
     if (b.p[0].nnf != (int16_t*)d_disp_vec) (void)hipMemcpyAsync(d_disp_vec, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream);
     g_launch_status = finish();
@@ -905,7 +921,10 @@ extern "C" void baoCudaBLFCostFilterRefine(eppm_float2* d_flow_vec, eppm_uchar4*
         unsigned char* d_census2, int w, int h, size_t img_pitch, size_t census_pitch)
 {
     LAUNCHER_BEGIN;
-    launch_c2f_refine(mk_planes(d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch), (float*)d_flow_vec, ds->lut_pm, g_prm.patch_r, g_stream);
+    PlanesH P;
+    g_launch_status = mk_planes(ds, &P, d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch);
+    if (g_launch_status != EPPM_OK) return;
+    launch_c2f_refine(P, (float*)d_flow_vec, ds->lut_pm, g_prm.patch_r, g_stream);
     g_launch_status = finish();
 }
 
@@ -918,8 +937,10 @@ extern "C" void baoCudaBLF_C2F(eppm_float2** pFlowPyr, eppm_uchar4** pImgPyr1, e
     const int l = nLayerIdx;
     launch_resize_flow((float*)pFlowPyr[l], arrH[l], arrW[l], (const float*)pFlowPyr[l + 1], arrH[l + 1], arrW[l + 1], 2.0f, 1.0f, g_stream);  // refine :1082
     launch_mul_scalar((float*)pFlowPyr[l], 2.0f, arrH[l], arrW[l], g_stream);                                                                  // refine :1083
-    launch_c2f_refine(mk_planes(pImgPyr1[l], pImgPyr2[l], pCensusPyr1[l], pCensusPyr2[l], arrW[l], arrH[l], arrPitchUchar4[l], arrPitchUchar1[l]),
-                      (float*)pFlowPyr[l], ds->lut_pm, g_prm.patch_r, g_stream);                                                               // refine :1086
+    PlanesH P;
+    g_launch_status = mk_planes(ds, &P, pImgPyr1[l], pImgPyr2[l], pCensusPyr1[l], pCensusPyr2[l], arrW[l], arrH[l], arrPitchUchar4[l], arrPitchUchar1[l]);
+    if (g_launch_status != EPPM_OK) return;
+    launch_c2f_refine(P, (float*)pFlowPyr[l], ds->lut_pm, g_prm.patch_r, g_stream);                                                            // refine :1086
     g_launch_status = finish();
 }
 

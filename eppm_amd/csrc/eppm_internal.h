@@ -16,19 +16,19 @@ constexpr int kMaxS = 32;        // samples per patch row: patch_r + 1 <= 32
 constexpr int kWmfRadius = 4;    // defs.h:58
 constexpr int kBlfRadius = 10;   // 2*POSTPROC_BLF_SIG_S, refine :753
 
-struct PlanesH {            // host-side mirror of eppm::Planes
-    const uint32_t* img1;
-    const uint32_t* img2;
-    const uint8_t* cen1;
-    const uint8_t* cen2;
-    int w, h, ipitch, cpitch;
+struct PlanesH {            // host-side mirror of eppm::Planes: packed rgb|census<<24 planes, pitch in pixels
+    const uint32_t* pk1;
+    const uint32_t* pk2;
+    int w, h, pitch;
 };
 
 // ---- prepare (k_prepare.hip) ----
 void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s);
 void launch_resize_rgba(uint32_t* out, int out_pitch_px, int outH, int outW, const uint32_t* in, int in_pitch_px, int h, int w,
                         float ratio, hipStream_t s);
-void launch_census(uint8_t* census, int cpitch, const uint32_t* img, int ipitch, int w, int h, hipStream_t s);
+// census plane and (optionally, packed != NULL) the packed rgb|census<<24 plane the patch kernels read
+void launch_census(uint8_t* census, int cpitch, uint32_t* packed, int ppitch, const uint32_t* img, int ipitch, int w, int h, hipStream_t s);
+void launch_pack(uint32_t* packed, int ppitch, const uint32_t* img, int ipitch, const uint8_t* census, int cpitch, int w, int h, hipStream_t s);
 void launch_rgb_to_rgba(uint32_t* out, int pitch_px, const uint8_t* rgb, int h, int w, hipStream_t s);
 
 // ---- PatchMatch (k_patchmatch.hip) ----

@@ -9,8 +9,8 @@ namespace eppm {
 __device__ __forceinline__ Planes to_dev(const PlanesH& h)
 {
     Planes p;
-    p.img1 = h.img1; p.img2 = h.img2; p.cen1 = h.cen1; p.cen2 = h.cen2;
-    p.w = h.w; p.h = h.h; p.ipitch = h.ipitch; p.cpitch = h.cpitch;
+    p.pk1 = h.pk1; p.pk2 = h.pk2;
+    p.w = h.w; p.h = h.h; p.pitch = h.pitch;
     return p;
 }
 
@@ -92,10 +92,146 @@ __global__ __launch_bounds__(256) void k_c2f_refine(PlanesH Ph, float* __restric
     flow[(y * P.w + x) * 2] = (float)(bx - x);
     flow[(y * P.w + x) * 2 + 1] = (float)(by - y);
 }
+// ---------------------------------------------------------------------------------------------------
+// The same stage restructured for CDNA4 (bit-identical results).  The reference evaluates the 36
+// (candidate, pass) patch costs of a pixel one after the other, re-fetching and re-converting the 100
+// source samples 36 times.  Here the sample loop is outermost within a pass: the source texel comes from
+// an LDS tile (16x16 + R halo, clamped at load), its conversion and its range term a^2 are computed once
+// per sample and shared by the 9 candidates, whose 9 pairs of running sums advance together -- each sum
+// still adds its terms in the reference's i-outer/j-inner order.  Target texels are one packed 4-byte
+// gather each (rgb + census).  The passes run 4th to 1st so the reference's nested
+// __min(c1,__min(c2,__min(c3,c4))) becomes a running select with the same NaN behaviour.
+// ---------------------------------------------------------------------------------------------------
+template <int R, int PASS>
+__device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, const uint32_t* __restrict__ s_src, int TW, int tx, int ty,
+                                         int x, int y, int ccx, int ccy, const rgbf c1, const rgbf (&c2)[9], float (&run)[9])
+{
+    constexpr int S = R + 1;
+    constexpr float kc[4][4] = {
+        {0.0f, 0.0f, 0.0f, 0.0f},
+        {0.177f, -0.011f, -0.003f, 0.301f},
+        {0.125f, -0.357f, 0.009f, 0.308f},
+        {0.205f, 0.370f, 0.011f, 0.296f},
+    };
+    float cs[9], ws[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { cs[k] = 0.0f; ws[k] = 0.0f; }
+    float uu[3], vv[3];
+#pragma unroll
+    for (int m = 0; m < 3; m++) { uu[m] = (float)(ccx + m - 1 - x); vv[m] = (float)(ccy + m - 1 - y); }
+#pragma unroll 1
+    for (int ii = 0; ii < S; ii++) {
+        const int i = 2 * ii - R;
+#pragma unroll 2
+        for (int jj = 0; jj < S; jj++) {
+            const int j = 2 * jj - R;
+            const uint32_t q1 = s_src[(ty + 2 * ii) * TW + tx + 2 * jj];
+            const rgbf p1 = unpack_rgb(q1);
+            float a2 = max_abs_diff(c1, p1);
+            a2 *= a2;
+            const float gsp = L.gsp[ii * S + jj];
+            int X[3], Yoff[3];
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                int xi, yi;
+                if (PASS == 0) {
+                    xi = ccx + m - 1 + j;       // cx1 + uu: integers, exact in float
+                    yi = ccy + m - 1 + i;
+                } else {
+                    const float cx1 = (float)(x + j), cy1 = (float)(y + i);
+                    const float cx2 = cx1 + uu[m] + (float)(j)*kc[PASS][0] + (float)(i)*kc[PASS][1];
+                    const float cy2 = cy1 + vv[m] + (float)(j)*kc[PASS][2] + (float)(i)*kc[PASS][3];
+                    xi = (int)floorf(cx2);
+                    yi = (int)floorf(cy2);
+                }
+                X[m] = iclamp(xi, 0, P.w - 1);
+                Yoff[m] = iclamp(yi, 0, P.h - 1) * P.pitch;
+            }
+#pragma unroll
+            for (int m = 0; m < 3; m++)
+#pragma unroll
+                for (int n = 0; n < 3; n++) {
+                    const int k = m * 3 + n;
+                    const uint32_t q2 = P.pk2[Yoff[n] + X[m]];
+                    const rgbf p2 = unpack_rgb(q2);
+                    const int hamming = __builtin_popcount((q1 ^ q2) >> 24);
+                    float cost = max_abs_diff(p1, p2);
+                    cost = 1 - fast_exp(div_ad2(-(cost * cost)));
+                    cost += L.cn[hamming];
+                    float temp = max_abs_diff(c2[k], p2);
+                    temp *= temp;
+                    float weight = fast_exp(div_ad2(-(a2 + temp)));
+                    weight *= gsp;
+                    cost *= weight;
+                    cs[k] += cost;
+                    ws[k] += weight;
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const float c = cs[k] / ws[k];
+        run[k] = (PASS == 3) ? c : ((c < run[k]) ? c : run[k]);
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_c2f_refine_tiled(PlanesH Ph, float* __restrict__ flow, const float* __restrict__ lut)
+{
+    constexpr int TW = kBlock + 2 * R;
+    __shared__ PatchLut L;
+    __shared__ uint32_t s_src[TW * TW];
+    const int tid = threadIdx.y * kBlock + threadIdx.x;
+    load_patch_lut(L, lut, R, tid, 256);
+    const Planes P = to_dev(Ph);
+    const int x0 = blockIdx.x * kBlock, y0 = blockIdx.y * kBlock;
+    for (int t = tid; t < TW * TW; t += 256) {
+        const int sy = iclamp(y0 + t / TW - R, 0, P.h - 1), sx = iclamp(x0 + t % TW - R, 0, P.w - 1);
+        s_src[t] = P.pk1[sy * P.pitch + sx];
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= P.w || y >= P.h) return;
+    const float fvx = flow[(y * P.w + x) * 2], fvy = flow[(y * P.w + x) * 2 + 1];
+    if (fvx > kUnknownFlowThresh || fvy > kUnknownFlowThresh) {
+        flow[(y * P.w + x) * 2] = 0.0f;
+        flow[(y * P.w + x) * 2 + 1] = 0.0f;
+        return;
+    }
+    const int ccx = (int)(int16_t)(f2short(fvx) + x);
+    const int ccy = (int)(int16_t)(f2short(fvy) + y);
+    const rgbf c1 = unpack_rgb(s_src[(threadIdx.y + R) * TW + threadIdx.x + R]);
+    rgbf c2[9];
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int n = 0; n < 3; n++) c2[m * 3 + n] = unpack_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, ccx + m - 1, ccy + n - 1));
+    float run[9];
+    c2f_pass<R, 3>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, ccx, ccy, c1, c2, run);
+    c2f_pass<R, 2>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, ccx, ccy, c1, c2, run);
+    c2f_pass<R, 1>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, ccx, ccy, c1, c2, run);
+    c2f_pass<R, 0>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, ccx, ccy, c1, c2, run);
+    int bx = ccx, by = ccy;
+    float min_cost = 999999;
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+            const int cx = (int)(int16_t)(ccx + m - 1), cy = (int)(int16_t)(ccy + n - 1);
+            if (cx < 0 || cy < 0 || cx >= P.w || cy >= P.h) continue;
+            const float cv = run[m * 3 + n];
+            if (cv < min_cost) { min_cost = cv; bx = cx; by = cy; }
+        }
+    flow[(y * P.w + x) * 2] = (float)(bx - x);
+    flow[(y * P.w + x) * 2 + 1] = (float)(by - y);
+}
+
 void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, hipStream_t s)
 {
     dim3 grid((P.w + kBlock - 1) / kBlock, (P.h + kBlock - 1) / kBlock), block(kBlock, kBlock);
-    hipLaunchKernelGGL(k_c2f_refine, grid, block, 0, s, P, flow, lut, R);
+    if (R == 9) hipLaunchKernelGGL((k_c2f_refine_tiled<9>), grid, block, 0, s, P, flow, lut);
+    else if (R == 17) hipLaunchKernelGGL((k_c2f_refine_tiled<17>), grid, block, 0, s, P, flow, lut);
+    else hipLaunchKernelGGL(k_c2f_refine, grid, block, 0, s, P, flow, lut, R);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -104,8 +104,9 @@ __global__ __launch_bounds__(256) void k_c2f_refine(PlanesH Ph, float* __restric
 // ---------------------------------------------------------------------------------------------------
 template <int R, int PASS>
 __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, const uint32_t* __restrict__ s_src, int TW, int tx, int ty,
-                                         int x, int y, int ccx, int ccy, const rgbf c1, const rgbf (&c2)[9], float (&run)[9])
+                                         int x, int y, int cx, int ccy, const rgbf c1, const rgbf (&c2)[3], float (&run)[3])
 {
+    // candidates (cx, ccy-1), (cx, ccy), (cx, ccy+1): one x offset m, the three y offsets n
     constexpr int S = R + 1;
     constexpr float kc[4][4] = {
         {0.0f, 0.0f, 0.0f, 0.0f},
@@ -113,12 +114,11 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, con
         {0.125f, -0.357f, 0.009f, 0.308f},
         {0.205f, 0.370f, 0.011f, 0.296f},
     };
-    float cs[9], ws[9];
+    float cs[3] = {0.0f, 0.0f, 0.0f}, ws[3] = {0.0f, 0.0f, 0.0f};
+    const float uu = (float)(cx - x);
+    float vv[3];
 #pragma unroll
-    for (int k = 0; k < 9; k++) { cs[k] = 0.0f; ws[k] = 0.0f; }
-    float uu[3], vv[3];
-#pragma unroll
-    for (int m = 0; m < 3; m++) { uu[m] = (float)(ccx + m - 1 - x); vv[m] = (float)(ccy + m - 1 - y); }
+    for (int n = 0; n < 3; n++) vv[n] = (float)(ccy + n - 1 - y);
 #pragma unroll 1
     for (int ii = 0; ii < S; ii++) {
         const int i = 2 * ii - R;
@@ -130,48 +130,43 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, con
             float a2 = max_abs_diff(c1, p1);
             a2 *= a2;
             const float gsp = L.gsp[ii * S + jj];
-            int X[3], Yoff[3];
+            int X, Yoff[3];
+            if (PASS == 0) {
+                X = iclamp(cx + j, 0, P.w - 1);                       // cx1 + uu: integers, exact in float
 #pragma unroll
-            for (int m = 0; m < 3; m++) {
-                int xi, yi;
-                if (PASS == 0) {
-                    xi = ccx + m - 1 + j;       // cx1 + uu: integers, exact in float
-                    yi = ccy + m - 1 + i;
-                } else {
-                    const float cx1 = (float)(x + j), cy1 = (float)(y + i);
-                    const float cx2 = cx1 + uu[m] + (float)(j)*kc[PASS][0] + (float)(i)*kc[PASS][1];
-                    const float cy2 = cy1 + vv[m] + (float)(j)*kc[PASS][2] + (float)(i)*kc[PASS][3];
-                    xi = (int)floorf(cx2);
-                    yi = (int)floorf(cy2);
-                }
-                X[m] = iclamp(xi, 0, P.w - 1);
-                Yoff[m] = iclamp(yi, 0, P.h - 1) * P.pitch;
-            }
-#pragma unroll
-            for (int m = 0; m < 3; m++)
+                for (int n = 0; n < 3; n++) Yoff[n] = iclamp(ccy + n - 1 + i, 0, P.h - 1) * P.pitch;
+            } else {
+                const float cx1 = (float)(x + j), cy1 = (float)(y + i);
+                const float cx2 = cx1 + uu + (float)(j)*kc[PASS][0] + (float)(i)*kc[PASS][1];
+                X = iclamp((int)floorf(cx2), 0, P.w - 1);
 #pragma unroll
                 for (int n = 0; n < 3; n++) {
-                    const int k = m * 3 + n;
-                    const uint32_t q2 = P.pk2[Yoff[n] + X[m]];
-                    const rgbf p2 = unpack_rgb(q2);
-                    const int hamming = __builtin_popcount((q1 ^ q2) >> 24);
-                    float cost = max_abs_diff(p1, p2);
-                    cost = 1 - fast_exp(div_ad2(-(cost * cost)));
-                    cost += L.cn[hamming];
-                    float temp = max_abs_diff(c2[k], p2);
-                    temp *= temp;
-                    float weight = fast_exp(div_ad2(-(a2 + temp)));
-                    weight *= gsp;
-                    cost *= weight;
-                    cs[k] += cost;
-                    ws[k] += weight;
+                    const float cy2 = cy1 + vv[n] + (float)(j)*kc[PASS][2] + (float)(i)*kc[PASS][3];
+                    Yoff[n] = iclamp((int)floorf(cy2), 0, P.h - 1) * P.pitch;
                 }
+            }
+#pragma unroll
+            for (int n = 0; n < 3; n++) {
+                const uint32_t q2 = P.pk2[Yoff[n] + X];
+                const rgbf p2 = unpack_rgb(q2);
+                const int hamming = __builtin_popcount((q1 ^ q2) >> 24);
+                float cost = max_abs_diff(p1, p2);
+                cost = 1 - fast_exp(div_ad2(-(cost * cost)));
+                cost += L.cn[hamming];
+                float temp = max_abs_diff(c2[n], p2);
+                temp *= temp;
+                float weight = fast_exp(div_ad2(-(a2 + temp)));
+                weight *= gsp;
+                cost *= weight;
+                cs[n] += cost;
+                ws[n] += weight;
+            }
         }
     }
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-        const float c = cs[k] / ws[k];
-        run[k] = (PASS == 3) ? c : ((c < run[k]) ? c : run[k]);
+    for (int n = 0; n < 3; n++) {
+        const float c = cs[n] / ws[n];
+        run[n] = (PASS == 3) ? c : ((c < run[n]) ? c : run[n]);
     }
 }
 
@@ -201,27 +196,28 @@ __global__ __launch_bounds__(256) void k_c2f_refine_tiled(PlanesH Ph, float* __r
     const int ccx = (int)(int16_t)(f2short(fvx) + x);
     const int ccy = (int)(int16_t)(f2short(fvy) + y);
     const rgbf c1 = unpack_rgb(s_src[(threadIdx.y + R) * TW + threadIdx.x + R]);
-    rgbf c2[9];
-#pragma unroll
-    for (int m = 0; m < 3; m++)
-#pragma unroll
-        for (int n = 0; n < 3; n++) c2[m * 3 + n] = unpack_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, ccx + m - 1, ccy + n - 1));
-    float run[9];
-    c2f_pass<R, 3>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, ccx, ccy, c1, c2, run);
-    c2f_pass<R, 2>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, ccx, ccy, c1, c2, run);
-    c2f_pass<R, 1>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, ccx, ccy, c1, c2, run);
-    c2f_pass<R, 0>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, ccx, ccy, c1, c2, run);
     int bx = ccx, by = ccy;
     float min_cost = 999999;
+#pragma unroll 1
+    for (int m = 0; m < 3; m++) {                    // x offset outer, as the reference's candidate loop (kernel.cu:2028)
+        const int cx = (int)(int16_t)(ccx + m - 1);
+        if (cx < 0 || cx >= P.w) continue;           // every candidate of this column is skipped (:2030)
+        rgbf c2[3];
 #pragma unroll
-    for (int m = 0; m < 3; m++)
+        for (int n = 0; n < 3; n++) c2[n] = unpack_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, cx, ccy + n - 1));
+        float run[3];
+        c2f_pass<R, 3>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, cx, ccy, c1, c2, run);
+        c2f_pass<R, 2>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, cx, ccy, c1, c2, run);
+        c2f_pass<R, 1>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, cx, ccy, c1, c2, run);
+        c2f_pass<R, 0>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, cx, ccy, c1, c2, run);
 #pragma unroll
         for (int n = 0; n < 3; n++) {
-            const int cx = (int)(int16_t)(ccx + m - 1), cy = (int)(int16_t)(ccy + n - 1);
-            if (cx < 0 || cy < 0 || cx >= P.w || cy >= P.h) continue;
-            const float cv = run[m * 3 + n];
+            const int cy = (int)(int16_t)(ccy + n - 1);
+            if (cy < 0 || cy >= P.h) continue;
+            const float cv = run[n];
             if (cv < min_cost) { min_cost = cv; bx = cx; by = cy; }
         }
+    }
     flow[(y * P.w + x) * 2] = (float)(bx - x);
     flow[(y * P.w + x) * 2 + 1] = (float)(by - y);
 }

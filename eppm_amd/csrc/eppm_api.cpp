@@ -187,9 +187,10 @@ struct eppm_ctx {
     size_t raw_pitch = 0;
     uint32_t *img1[kMaxLevels] = {}, *img2[kMaxLevels] = {}, *tmpu[kMaxLevels] = {};
     uint8_t *cen1[kMaxLevels] = {}, *cen2[kMaxLevels] = {};
-    uint32_t *pk1[kMaxLevels] = {}, *pk2[kMaxLevels] = {};   // packed rgb|census<<24, same pitch as the images
+    void *pk1[kMaxLevels] = {}, *pk2[kMaxLevels] = {};       // float4 texel planes {r,g,b,census}, linear (pitch = w)
     int16_t *nnf1 = nullptr, *nnf2 = nullptr, *nnf_tmp = nullptr, *nnf_tmp2 = nullptr;
     float *cost1 = nullptr, *cost2 = nullptr;
+    uint32_t* wmf_ws = nullptr;        // work lists + counters of the weighted median
     float *flow[kMaxLevels] = {}, *flow_tmp[kMaxLevels] = {};
     float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
     eppm_pm_rng* rng = nullptr;
@@ -208,7 +209,7 @@ static PlanesH planes(const eppm_ctx* c, int l, bool swap)
     p.pk1 = swap ? c->pk2[l] : c->pk1[l];
     p.pk2 = swap ? c->pk1[l] : c->pk2[l];
     p.w = c->W[l]; p.h = c->H[l];
-    p.pitch = (int)(c->ipitch[l] / 4);
+    p.pitch = c->W[l];
     return p;
 }
 
@@ -247,7 +248,7 @@ extern "C" int eppm_destroy(eppm_ctx* c)
         (void)hipFree(c->flow[i]); (void)hipFree(c->flow_tmp[i]);
     }
     (void)hipFree(c->nnf1); (void)hipFree(c->nnf2); (void)hipFree(c->nnf_tmp); (void)hipFree(c->nnf_tmp2);
-    (void)hipFree(c->cost1); (void)hipFree(c->cost2);
+    (void)hipFree(c->cost1); (void)hipFree(c->cost2); (void)hipFree(c->wmf_ws);
     (void)hipFree(c->lut_pm); (void)hipFree(c->lut_wmf); (void)hipFree(c->lut_blf);
     (void)hipFree(c->d_rgb);
     if (c->h_rgb) (void)hipHostFree(c->h_rgb);
@@ -274,8 +275,8 @@ static int ctx_alloc(eppm_ctx* c)
         HIPCHK(hipMallocPitch((void**)&c->img1[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
         HIPCHK(hipMallocPitch((void**)&c->img2[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
         HIPCHK(hipMallocPitch((void**)&c->tmpu[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
-        HIPCHK(hipMallocPitch((void**)&c->pk1[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
-        HIPCHK(hipMallocPitch((void**)&c->pk2[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
+        HIPCHK(hipMalloc(&c->pk1[i], (size_t)c->W[i] * c->H[i] * 16));
+        HIPCHK(hipMalloc(&c->pk2[i], (size_t)c->W[i] * c->H[i] * 16));
         HIPCHK(hipMallocPitch((void**)&c->cen1[i], &c->cpitch[i], (size_t)c->W[i], c->H[i]));
         HIPCHK(hipMallocPitch((void**)&c->cen2[i], &c->cpitch[i], (size_t)c->W[i], c->H[i]));
         const size_t n = (size_t)c->W[i] * c->H[i];
@@ -291,6 +292,7 @@ static int ctx_alloc(eppm_ctx* c)
     HIPCHK(hipMalloc((void**)&c->nnf_tmp2, n * 4));
     HIPCHK(hipMalloc((void**)&c->cost1, n * 4));
     HIPCHK(hipMalloc((void**)&c->cost2, n * 4));
+    HIPCHK(hipMalloc((void**)&c->wmf_ws, (2 * n + c->prm.wmf_iters + 2) * 4));
     std::vector<float> v;
     host_pm_lut(c->prm.patch_r, v);  CHK(upload_lut(&c->lut_pm, v));
     host_wmf_lut(v);                 CHK(upload_lut(&c->lut_wmf, v));
@@ -354,7 +356,7 @@ extern "C" int eppm_enable_stage_timing(eppm_ctx* c, int on)
 }
 
 // ---- prepare: refine :1060-1071 + .cuh:642-664 ----
-static int prepare_one(eppm_ctx* c, uint32_t** pyr, uint8_t** cen, uint32_t** pk, uint32_t** tmp, const uint32_t* raw)
+static int prepare_one(eppm_ctx* c, uint32_t** pyr, uint8_t** cen, void** pk, uint32_t** tmp, const uint32_t* raw)
 {
     hipStream_t s = c->stream;
     const int p0 = (int)(c->ipitch[0] / 4);
@@ -376,7 +378,7 @@ static int prepare_one(eppm_ctx* c, uint32_t** pyr, uint8_t** cen, uint32_t** pk
         }
     }
     for (int i = 0; i < c->nl; i++)
-        launch_census(cen[i], (int)c->cpitch[i], pk[i], (int)(c->ipitch[i] / 4), pyr[i], (int)(c->ipitch[i] / 4), c->W[i], c->H[i], s);
+        launch_census(cen[i], (int)c->cpitch[i], pk[i], c->W[i], pyr[i], (int)(c->ipitch[i] / 4), c->W[i], c->H[i], s);
     return EPPM_OK;
 }
 
@@ -470,10 +472,9 @@ extern "C" int eppm_compute_device(eppm_ctx* c, void* d_flow)
     launch_lr_check(c->nnf2, c->cost2, c->nnf1, lw, lh, lw, lw, s);
     launch_outlier(c->nnf_tmp, c->cost1, c->nnf1, lw, lh, lw, lw, s);                                        // driver :237
     std::swap(c->nnf1, c->nnf_tmp);
-    for (int i = 0; i < c->prm.wmf_iters; i++) {                                                             // driver :239
-        launch_wmf(c->nnf_tmp, c->nnf1, c->img1[L], (int)(c->ipitch[L] / 4), lw, lh, lw, c->lut_wmf, 1, s);
+    if (launch_wmf(c->nnf1, c->nnf_tmp, c->img1[L], (int)(c->ipitch[L] / 4), lw, lh, lw, c->lut_wmf, c->prm.wmf_iters, 1,      // driver :239
+                   c->wmf_ws, s) != c->nnf1)
         std::swap(c->nnf1, c->nnf_tmp);
-    }
     launch_fill_holes(c->nnf_tmp, c->nnf1, c->img1[L], (int)(c->ipitch[L] / 4), lw, lh, lw, s);              // driver :240
     std::swap(c->nnf1, c->nnf_tmp);
     launch_nnf2flow(c->flow[L], lw, c->nnf1, lw, lw, lh, s);                                                 // driver :258
@@ -646,11 +647,11 @@ int get_rng(DevState* s, int w, int h, eppm_pm_rng** out)
 int mk_planes(DevState* ds, PlanesH* out, const void* i1, const void* i2, const void* c1, const void* c2, int w, int h, size_t ip, size_t cp)
 {
     void *a = nullptr, *b = nullptr;
-    CHK(get_scratch(ds, (size_t)w * h * 4, &a, 2));
-    CHK(get_scratch(ds, (size_t)w * h * 4, &b, 3));
-    launch_pack((uint32_t*)a, w, (const uint32_t*)i1, (int)(ip / 4), (const uint8_t*)c1, (int)cp, w, h, g_stream);
-    launch_pack((uint32_t*)b, w, (const uint32_t*)i2, (int)(ip / 4), (const uint8_t*)c2, (int)cp, w, h, g_stream);
-    out->pk1 = (const uint32_t*)a; out->pk2 = (const uint32_t*)b; out->w = w; out->h = h; out->pitch = w;
+    CHK(get_scratch(ds, (size_t)w * h * 16, &a, 2));
+    CHK(get_scratch(ds, (size_t)w * h * 16, &b, 3));
+    launch_pack(a, w, (const uint32_t*)i1, (int)(ip / 4), (const uint8_t*)c1, (int)cp, w, h, g_stream);
+    launch_pack(b, w, (const uint32_t*)i2, (int)(ip / 4), (const uint8_t*)c2, (int)cp, w, h, g_stream);
+    out->pk1 = a; out->pk2 = b; out->w = w; out->h = h; out->pitch = w;
     return EPPM_OK;
 }
 int finish() { HIPCHK(hipGetLastError()); return EPPM_OK; }
@@ -887,13 +888,12 @@ extern "C" void baoCudaWeightedMedianFilter(eppm_short2* d_disp_vec, float* d_co
     void* tmp = nullptr;
     g_launch_status = get_scratch(ds, disp_pitch * h, &tmp);
     if (g_launch_status != EPPM_OK) return;
-    int16_t* a = (int16_t*)d_disp_vec;
-    int16_t* b = (int16_t*)tmp;
-    for (int i = 0; i < num_iter; i++) {
-        launch_wmf(b, a, (const uint32_t*)d_img, (int)(img_pitch / 4), w, h, (int)(disp_pitch / 4), ds->lut_wmf, is_only_occlusion ? 1 : 0, g_stream);
-        std::swap(a, b);
-    }
-    if (a != (int16_t*)d_disp_vec) (void)hipMemcpyAsync(d_disp_vec, a, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream);
+    void* ws = nullptr;
+    g_launch_status = get_scratch(ds, ((size_t)2 * w * h + (num_iter > 0 ? num_iter : 0) + 2) * 4, &ws, 1);
+    if (g_launch_status != EPPM_OK) return;
+    int16_t* res = launch_wmf((int16_t*)d_disp_vec, (int16_t*)tmp, (const uint32_t*)d_img, (int)(img_pitch / 4), w, h, (int)(disp_pitch / 4),
+                              ds->lut_wmf, num_iter, is_only_occlusion ? 1 : 0, (uint32_t*)ws, g_stream);
+    if (res != (int16_t*)d_disp_vec) (void)hipMemcpyAsync(d_disp_vec, res, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream);
     g_launch_status = finish();
 }
 

@@ -78,31 +78,46 @@ __device__ __forceinline__ float max_abs_diff(const rgbf a, const rgbf b)
 }
 
 // ---- texture model: point sampling, clamp addressing -------------------------------
-// The patch kernels read ONE packed plane per image: R | G<<8 | B<<16 | census<<24 (the reference's RGBA
-// alpha is always 0, bao_basic_cuda.h:258-267, so the census byte rides in its place): one 4-byte gather per
-// sample instead of a uchar4 and a u8 texture fetch.
+// The patch kernels read ONE "texel plane" per image: float4 { R/255, G/255, B/255, census bits } -- the
+// unorm8 -> float conversion of cudaReadModeNormalizedFloat is done once per pixel when the plane is built
+// (k_census / k_pack) instead of once per fetch, and colour + census arrive in a single 16-byte gather
+// where the reference issues a uchar4 and a u8 texture fetch.
 struct Planes {
-    const uint32_t* pk1;    // packed rgb+census of the source image, pitch in pixels
-    const uint32_t* pk2;    // ... of the target image
+    const float4* pk1;      // texel plane of the source image, pitch in pixels
+    const float4* pk2;      // ... of the target image
     int w, h;
     int pitch;              // pixels
 };
 
-__device__ __forceinline__ uint32_t tex_px(const uint32_t* img, int pitch, int w, int h, int x, int y)
+__device__ __forceinline__ float4 make_texel(uint32_t rgba, uint32_t census)
+{
+    const rgbf c = unpack_rgb(rgba);
+    return make_float4(c.x, c.y, c.z, __uint_as_float(census));
+}
+__device__ __forceinline__ rgbf texel_rgb(const float4 t) { return rgbf{t.x, t.y, t.z}; }
+
+__device__ __forceinline__ float4 tex_px(const float4* img, int pitch, int w, int h, int x, int y)
 {
     x = iclamp(x, 0, w - 1);
     y = iclamp(y, 0, h - 1);
-    return img[y * pitch + x];
+    return img[(unsigned)(y * pitch + x)];
+}
+// same for the plain RGBA planes (guide image of the WMF / hole filling)
+__device__ __forceinline__ uint32_t tex_rgba(const uint32_t* img, int pitch, int w, int h, int x, int y)
+{
+    x = iclamp(x, 0, w - 1);
+    y = iclamp(y, 0, h - 1);
+    return img[(unsigned)(y * pitch + x)];
 }
 
 // ---- one sample of the patch cost (bao_pmflow_kernel.cu:275-295), both texels already fetched ------
 // gsp = gs[|j|]*gs[|i|] (the product is formed first in the reference too: "weight *= a*b").
-__device__ __forceinline__ void patch_terms(uint32_t q1, uint32_t q2, const rgbf c1, const rgbf c2, float gsp,
+__device__ __forceinline__ void patch_terms(const float4 q1, const float4 q2, const rgbf c1, const rgbf c2, float gsp,
                                             const float* __restrict__ cn, float& cost_term, float& weight_term)
 {
-    const rgbf p1 = unpack_rgb(q1);
-    const rgbf p2 = unpack_rgb(q2);
-    const int hamming = __builtin_popcount((q1 ^ q2) >> 24);
+    const rgbf p1 = texel_rgb(q1);
+    const rgbf p2 = texel_rgb(q2);
+    const int hamming = __builtin_popcount(__float_as_uint(q1.w) ^ __float_as_uint(q2.w));
     float cost = max_abs_diff(p1, p2);
     cost = 1 - fast_exp(div_ad2(-(cost * cost)));
     cost += cn[hamming];
@@ -121,8 +136,8 @@ __device__ __forceinline__ void patch_sample(const Planes& P, const rgbf c1, con
                                              int sy2, float gsp, const float* __restrict__ cn, float& cost_term,
                                              float& weight_term)
 {
-    const uint32_t q1 = tex_px(P.pk1, P.pitch, P.w, P.h, sx1, sy1);
-    const uint32_t q2 = tex_px(P.pk2, P.pitch, P.w, P.h, sx2, sy2);
+    const float4 q1 = tex_px(P.pk1, P.pitch, P.w, P.h, sx1, sy1);
+    const float4 q2 = tex_px(P.pk2, P.pitch, P.w, P.h, sx2, sy2);
     patch_terms(q1, q2, c1, c2, gsp, cn, cost_term, weight_term);
 }
 
@@ -147,8 +162,8 @@ __device__ __forceinline__ void load_patch_lut(PatchLut& L, const float* __restr
 // ---- the patch cost, bao_pmflow_kernel.cu:255-301: sequential i-outer / j-inner accumulation ------
 __device__ __forceinline__ float patch_dist(const Planes& P, const PatchLut& L, int R, int x1, int y1, int x2, int y2)
 {
-    const rgbf c1 = unpack_rgb(tex_px(P.pk1, P.pitch, P.w, P.h, x1, y1));
-    const rgbf c2 = unpack_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, x2, y2));
+    const rgbf c1 = texel_rgb(tex_px(P.pk1, P.pitch, P.w, P.h, x1, y1));
+    const rgbf c2 = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, x2, y2));
     float cost_sum = 0.0f, weight_sum = 0.0f;
     const int S = R + 1;
     for (int ii = 0; ii < S; ii++) {
@@ -203,8 +218,8 @@ __device__ __forceinline__ float patch_dist_pass(const Planes& P, const PatchLut
 
 __device__ __forceinline__ float patch_dist_planefit(const Planes& P, const PatchLut& L, int R, int x1, int y1, int x2, int y2)
 {
-    const rgbf c1 = unpack_rgb(tex_px(P.pk1, P.pitch, P.w, P.h, x1, y1));
-    const rgbf c2 = unpack_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, x2, y2));
+    const rgbf c1 = texel_rgb(tex_px(P.pk1, P.pitch, P.w, P.h, x1, y1));
+    const rgbf c2 = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, x2, y2));
     const float uu = (float)(x2 - x1);
     const float vv = (float)(y2 - y1);
     const float c_1 = patch_dist_pass<0>(P, L, R, x1, y1, uu, vv, c1, c2);

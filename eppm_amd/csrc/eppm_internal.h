@@ -16,9 +16,9 @@ constexpr int kMaxS = 32;        // samples per patch row: patch_r + 1 <= 32
 constexpr int kWmfRadius = 4;    // defs.h:58
 constexpr int kBlfRadius = 10;   // 2*POSTPROC_BLF_SIG_S, refine :753
 
-struct PlanesH {            // host-side mirror of eppm::Planes: packed rgb|census<<24 planes, pitch in pixels
-    const uint32_t* pk1;
-    const uint32_t* pk2;
+struct PlanesH {            // host-side mirror of eppm::Planes: float4 texel planes {r,g,b,census bits}, pitch in pixels
+    const void* pk1;
+    const void* pk2;
     int w, h, pitch;
 };
 
@@ -26,9 +26,9 @@ struct PlanesH {            // host-side mirror of eppm::Planes: packed rgb|cens
 void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s);
 void launch_resize_rgba(uint32_t* out, int out_pitch_px, int outH, int outW, const uint32_t* in, int in_pitch_px, int h, int w,
                         float ratio, hipStream_t s);
-// census plane and (optionally, packed != NULL) the packed rgb|census<<24 plane the patch kernels read
-void launch_census(uint8_t* census, int cpitch, uint32_t* packed, int ppitch, const uint32_t* img, int ipitch, int w, int h, hipStream_t s);
-void launch_pack(uint32_t* packed, int ppitch, const uint32_t* img, int ipitch, const uint8_t* census, int cpitch, int w, int h, hipStream_t s);
+// census plane and (optionally, texels != NULL) the float4 texel plane the patch kernels read
+void launch_census(uint8_t* census, int cpitch, void* texels, int tpitch, const uint32_t* img, int ipitch, int w, int h, hipStream_t s);
+void launch_pack(void* texels, int tpitch, const uint32_t* img, int ipitch, const uint8_t* census, int cpitch, int w, int h, hipStream_t s);
 void launch_rgb_to_rgba(uint32_t* out, int pitch_px, const uint8_t* rgb, int h, int w, hipStream_t s);
 
 // ---- PatchMatch (k_patchmatch.hip) ----
@@ -66,8 +66,9 @@ void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float*
 // ---- level-2 post-processing (k_post.hip) ----
 void launch_lr_check(int16_t* nnf1, float* cost1, const int16_t* nnf2, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s);
 void launch_outlier(int16_t* nnf_out, float* cost, const int16_t* nnf_in, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s);
-void launch_wmf(int16_t* nnf_out, const int16_t* nnf_in, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
-                const float* wmf_lut, int only_occlusion, hipStream_t s);
+// all num_iter Jacobi launches; ping-pongs buf_a (input) / buf_b, ws = 2*w*h + num_iter + 2 uint32 words; returns the result buffer
+int16_t* launch_wmf(int16_t* buf_a, int16_t* buf_b, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
+                    const float* wmf_lut, int num_iter, int only_occlusion, uint32_t* ws, hipStream_t s);
 void launch_fill_holes(int16_t* nnf_out, const int16_t* nnf_in, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
                        hipStream_t s);
 void launch_nnf2flow(float* flow, int flow_pitch, const int16_t* nnf, int nnf_pitch, int w, int h, hipStream_t s);

@@ -9,7 +9,7 @@ namespace eppm {
 __device__ __forceinline__ Planes to_dev(const PlanesH& h)
 {
     Planes p;
-    p.pk1 = h.pk1; p.pk2 = h.pk2;
+    p.pk1 = (const float4*)h.pk1; p.pk2 = (const float4*)h.pk2;
     p.w = h.w; p.h = h.h; p.pitch = h.pitch;
     return p;
 }
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_c2f_refine(PlanesH Ph, float* __restric
 // __min(c1,__min(c2,__min(c3,c4))) becomes a running select with the same NaN behaviour.
 // ---------------------------------------------------------------------------------------------------
 template <int R, int PASS>
-__device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, const uint32_t* __restrict__ s_src, int TW, int tx, int ty,
+__device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, const float4* __restrict__ s_src, int TW, int tx, int ty,
                                          int x, int y, int cx, int ccy, const rgbf c1, const rgbf (&c2)[3], float (&run)[3])
 {
     // candidates (cx, ccy-1), (cx, ccy), (cx, ccy+1): one x offset m, the three y offsets n
@@ -125,8 +125,9 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, con
 #pragma unroll 2
         for (int jj = 0; jj < S; jj++) {
             const int j = 2 * jj - R;
-            const uint32_t q1 = s_src[(ty + 2 * ii) * TW + tx + 2 * jj];
-            const rgbf p1 = unpack_rgb(q1);
+            const float4 q1 = s_src[(ty + 2 * ii) * TW + tx + 2 * jj];
+            const rgbf p1 = texel_rgb(q1);
+            const uint32_t k1 = __float_as_uint(q1.w);
             float a2 = max_abs_diff(c1, p1);
             a2 *= a2;
             const float gsp = L.gsp[ii * S + jj];
@@ -147,9 +148,9 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, con
             }
 #pragma unroll
             for (int n = 0; n < 3; n++) {
-                const uint32_t q2 = P.pk2[Yoff[n] + X];
-                const rgbf p2 = unpack_rgb(q2);
-                const int hamming = __builtin_popcount((q1 ^ q2) >> 24);
+                const float4 q2 = P.pk2[(unsigned)(Yoff[n] + X)];
+                const rgbf p2 = texel_rgb(q2);
+                const int hamming = __builtin_popcount(k1 ^ __float_as_uint(q2.w));
                 float cost = max_abs_diff(p1, p2);
                 cost = 1 - fast_exp(div_ad2(-(cost * cost)));
                 cost += L.cn[hamming];
@@ -175,14 +176,14 @@ __global__ __launch_bounds__(256) void k_c2f_refine_tiled(PlanesH Ph, float* __r
 {
     constexpr int TW = kBlock + 2 * R;
     __shared__ PatchLut L;
-    __shared__ uint32_t s_src[TW * TW];
+    __shared__ float4 s_src[TW * TW];
     const int tid = threadIdx.y * kBlock + threadIdx.x;
     load_patch_lut(L, lut, R, tid, 256);
     const Planes P = to_dev(Ph);
     const int x0 = blockIdx.x * kBlock, y0 = blockIdx.y * kBlock;
     for (int t = tid; t < TW * TW; t += 256) {
         const int sy = iclamp(y0 + t / TW - R, 0, P.h - 1), sx = iclamp(x0 + t % TW - R, 0, P.w - 1);
-        s_src[t] = P.pk1[sy * P.pitch + sx];
+        s_src[t] = P.pk1[(unsigned)(sy * P.pitch + sx)];
     }
     __syncthreads();
     const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void k_c2f_refine_tiled(PlanesH Ph, float* __r
     }
     const int ccx = (int)(int16_t)(f2short(fvx) + x);
     const int ccy = (int)(int16_t)(f2short(fvy) + y);
-    const rgbf c1 = unpack_rgb(s_src[(threadIdx.y + R) * TW + threadIdx.x + R]);
+    const rgbf c1 = texel_rgb(s_src[(threadIdx.y + R) * TW + threadIdx.x + R]);
     int bx = ccx, by = ccy;
     float min_cost = 999999;
 #pragma unroll 1
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void k_c2f_refine_tiled(PlanesH Ph, float* __r
         if (cx < 0 || cx >= P.w) continue;           // every candidate of this column is skipped (:2030)
         rgbf c2[3];
 #pragma unroll
-        for (int n = 0; n < 3; n++) c2[n] = unpack_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, cx, ccy + n - 1));
+        for (int n = 0; n < 3; n++) c2[n] = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, cx, ccy + n - 1));
         float run[3];
         c2f_pass<R, 3>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, cx, ccy, c1, c2, run);
         c2f_pass<R, 2>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, cx, ccy, c1, c2, run);

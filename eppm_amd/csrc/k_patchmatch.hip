@@ -17,7 +17,7 @@ namespace eppm {
 __device__ __forceinline__ Planes to_dev(const PlanesH& h)
 {
     Planes p;
-    p.pk1 = h.pk1; p.pk2 = h.pk2;
+    p.pk1 = (const float4*)h.pk1; p.pk2 = (const float4*)h.pk2;
     p.w = h.w; p.h = h.h; p.pitch = h.pitch;
     return p;
 }
@@ -168,8 +168,8 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
             const float cur_best = cost[cidx];
             if (IS_ROW) px = REVERSE ? max(px - 1, 0) : min(px + 1, P.w - 1);
             else        py = REVERSE ? max(py - 1, 0) : min(py + 1, P.h - 1);
-            const rgbf c1 = unpack_rgb(tex_px(P.pk1, P.pitch, P.w, P.h, x, y));
-            const rgbf c2 = unpack_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, px, py));
+            const rgbf c1 = texel_rgb(tex_px(P.pk1, P.pitch, P.w, P.h, x, y));
+            const rgbf c2 = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, px, py));
             float tc[CH], tw[CH];
 #pragma unroll
             for (int q = 0; q < CH; q++) {

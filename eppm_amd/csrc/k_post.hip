@@ -84,129 +84,150 @@ void launch_outlier(int16_t* nnf_out, float* cost, const int16_t* nnf_in, int w,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Weighted median by exhaustive candidate scoring (refine :206-259), one Jacobi launch.
-// The reference spends O(81 x 81) taps in ONE thread per pixel and only occluded pixels do work.
-// Here a 16x16 tile block stages flows + guide colours (24x24 with halo) in LDS, compacts the pixels
-// that need work, and a whole wave scores one pixel: lanes = the 81 candidates, each lane running the
-// reference's sequential 81-tap sum (same order, same operations), the 81 bilateral weights computed
-// once per pixel instead of once per candidate.  The winner is the first minimum in row-major
-// candidate order (strict <), found by a lexicographic (cost, index) wave reduction.
+// Weighted median by exhaustive candidate scoring (refine :206-286): num_iter Jacobi launches.
+//
+// The reference spends O(81 x 81) taps in ONE thread per pixel, and in the live call (20 iterations,
+// occlusion only, driver :239) only the still-invalid pixels do any work.  Mapping here:
+//  * a work list of the pixels that need work is built once and shrinks from launch to launch (a pixel
+//    that became valid is carried one more launch as "copy only" so both ping-pong buffers stay equal
+//    outside the list);
+//  * ONE WAVE scores one pixel: the valid taps of the 9x9 window are compacted in row-major order into
+//    LDS together with their bilateral weight (computed once per pixel, not once per candidate), the
+//    candidates (the same taps) sit on the lanes, and every lane runs the reference's sequential sum over
+//    the taps -- same order, same operations;
+//  * the winner is the first minimum in candidate order (strict <): a lexicographic (cost, index) wave
+//    reduction.
 // ---------------------------------------------------------------------------------------------------
-constexpr int WT = 16, WR = kWmfRadius, WTW = WT + 2 * WR, WN = (2 * WR + 1) * (2 * WR + 1);   // 24, 81
+constexpr int WR = kWmfRadius, WN = (2 * WR + 1) * (2 * WR + 1);   // 4, 81
+constexpr uint32_t kCopyOnly = 0x80000000u;
 
-__global__ __launch_bounds__(256) void k_wmf(int16_t* __restrict__ nnf_out, const int16_t* __restrict__ nnf_in,
-                                             const uint32_t* __restrict__ img, int ipitch, int w, int h, int npitch,
-                                             const float* __restrict__ wmf_lut, int only_occ)
+__global__ __launch_bounds__(256) void k_wmf_build_list(const int16_t* __restrict__ nnf, int npitch, int w, int h, int only_occ,
+                                                        uint32_t* __restrict__ list, uint32_t* __restrict__ count)
 {
-    __shared__ int   s_fx[WTW * WTW], s_fy[WTW * WTW];
-    __shared__ uint8_t s_ok[WTW * WTW];
-    __shared__ float s_r[WTW * WTW], s_g[WTW * WTW], s_b[WTW * WTW];
-    __shared__ int   s_list[WT * WT];
-    __shared__ int   s_count;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int ox = nnf[(y * npitch + x) * 2], oy = nnf[(y * npitch + x) * 2 + 1];
+    if (only_occ && ox >= 0 && oy >= 0) return;                // refine :213
+    list[atomicAdd(count, 1u)] = ((uint32_t)y << 16) | (uint32_t)x;
+}
+
+__global__ __launch_bounds__(256) void k_wmf_iter(int16_t* __restrict__ nnf_out, const int16_t* __restrict__ nnf_in,
+                                                  const uint32_t* __restrict__ img, int ipitch, int w, int h, int npitch,
+                                                  const float* __restrict__ wmf_lut, int only_occ,
+                                                  const uint32_t* __restrict__ list_in, const uint32_t* __restrict__ count_in,
+                                                  uint32_t* __restrict__ list_out, uint32_t* __restrict__ count_out)
+{
     __shared__ float s_lut[WR + 1];
     __shared__ float s_wgt[4][WN];
-    __shared__ int   s_tfx[4][WN], s_tfy[4][WN];
-    __shared__ uint8_t s_tok[4][WN];
-
-    const int x0 = blockIdx.x * WT, y0 = blockIdx.y * WT;
-    const int tid = threadIdx.y * WT + threadIdx.x;
-    if (tid == 0) s_count = 0;
+    __shared__ int s_fx[4][WN], s_fy[4][WN];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     if (tid <= WR) s_lut[tid] = wmf_lut[tid];
-    for (int t = tid; t < WTW * WTW; t += 256) {
-        const int cy = y0 + t / WTW - WR, cx = x0 + t % WTW - WR;
-        int fx = 0, fy = 0, ok = 0;
-        float r = 0, g = 0, b = 0;
-        if (cx >= 0 && cy >= 0 && cx < w && cy < h) {
-            const int dx = nnf_in[(cy * npitch + cx) * 2], dy = nnf_in[(cy * npitch + cx) * 2 + 1];
-            if (!(dx < 0 || dy < 0)) {                           // "skip invalid disparity", refine :225,238
-                ok = 1;
-                fx = (int)(int16_t)(dx - cx);
-                fy = (int)(int16_t)(dy - cy);
-            }
-            const rgbf c = unpack_rgb(img[cy * ipitch + cx]);
-            r = c.x; g = c.y; b = c.z;
-        }
-        s_fx[t] = fx; s_fy[t] = fy; s_ok[t] = (uint8_t)ok; s_r[t] = r; s_g[t] = g; s_b[t] = b;
-    }
     __syncthreads();
-    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
-    const bool inimg = (x < w && y < h);
-    int ox = 0, oy = 0;
-    if (inimg) {
-        ox = nnf_in[(y * npitch + x) * 2]; oy = nnf_in[(y * npitch + x) * 2 + 1];
-        nnf_out[(y * npitch + x) * 2] = (int16_t)ox;             // default: unchanged
-        nnf_out[(y * npitch + x) * 2 + 1] = (int16_t)oy;
-        const bool skip = only_occ && ox >= 0 && oy >= 0;        // refine :213
-        if (!skip) s_list[atomicAdd(&s_count, 1)] = tid;
-    }
-    __syncthreads();
-    const int count = s_count;
-    const int wv = tid >> 6, lane = tid & 63;
-    for (int base = 0; base < count; base += 4) {
-        const int li = base + wv;
-        const bool have = li < count;
-        int ptid = 0, lx = 0, ly = 0;
-        if (have) {
-            ptid = s_list[li]; lx = ptid & 15; ly = ptid >> 4;
-            const int ci = (ly + WR) * WTW + lx + WR;
-            const rgbf center = {s_r[ci], s_g[ci], s_b[ci]};
-            for (int t = lane; t < WN; t += 64) {
-                const int dy2 = t / 9 - WR, dx2 = t % 9 - WR;
-                const int ti = (ly + WR + dy2) * WTW + lx + WR + dx2;
-                const int ok = s_ok[ti];
-                float wgt = 0.0f;
-                if (ok) {
-                    const rgbf pix = {s_r[ti], s_g[ti], s_b[ti]};
-                    const float delta_r = max_abs_diff(center, pix);
-                    const float coef_r = fast_exp(div_wmf2(-(delta_r * delta_r)));
-                    const float coef_s = s_lut[abs(dx2)] * s_lut[abs(dy2)];
-                    wgt = coef_r * coef_s;                                           // refine :198-204
-                }
-                s_wgt[wv][t] = wgt; s_tfx[wv][t] = s_fx[ti]; s_tfy[wv][t] = s_fy[ti]; s_tok[wv][t] = (uint8_t)ok;
-            }
+    const uint32_t n_items = *count_in;
+    const uint32_t n_waves = gridDim.x * 4;
+    for (uint32_t item = blockIdx.x * 4 + wv; item < n_items; item += n_waves) {
+        const uint32_t e = list_in[item];
+        const int x = (int)(e & 0xffffu), y = (int)((e >> 16) & 0x7fffu);
+        const int pidx = (y * npitch + x) * 2;
+        const int ox = nnf_in[pidx], oy = nnf_in[pidx + 1];
+        if (e & kCopyOnly) {                                    // became valid in the previous launch
+            if (lane == 0) { nnf_out[pidx] = (int16_t)ox; nnf_out[pidx + 1] = (int16_t)oy; }
+            continue;
         }
-        __syncthreads();
-        if (have) {
-            float bestc = FLT_MAX;
-            int besti = 0x7fffffff;
-            for (int c = lane; c < WN; c += 64) {
-                if (!s_tok[wv][c]) continue;
-                const int cfx = s_tfx[wv][c], cfy = s_tfy[wv][c];
-                float costSum = 0.0f, weightSum = 0.0f;
-                for (int t = 0; t < WN; t++) {
-                    if (!s_tok[wv][t]) continue;
-                    const float wgt = s_wgt[wv][t];
-                    costSum += wgt * (float)max(abs(cfx - s_tfx[wv][t]), abs(cfy - s_tfy[wv][t]));
-                    weightSum += wgt;
-                }
-                if (weightSum > 0.0f && costSum < FLT_MAX) {
-                    if (costSum < bestc || (costSum == bestc && c < besti)) { bestc = costSum; besti = c; }
-                }
-            }
-            // lexicographic (cost, index) minimum over the wave = first minimum in candidate order
+        const rgbf center = unpack_rgb(img[y * ipitch + x]);
+        // taps in row-major order (dy outer, dx inner): lanes 0..63 take taps 0..63, lanes 0..16 taps 64..80
+        int nv = 0;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float oc = __shfl_xor(bestc, off, 64);
-                const int oi = __shfl_xor(besti, off, 64);
-                if (oc < bestc || (oc == bestc && oi < besti)) { bestc = oc; besti = oi; }
-            }
-            if (lane == 0 && besti != 0x7fffffff) {
-                const int px = x0 + lx, py = y0 + ly;
-                const int rx = (int)(int16_t)(s_tfx[wv][besti] + px), ry = (int)(int16_t)(s_tfy[wv][besti] + py);
-                if (!(rx < 0 || ry < 0)) {                                            // refine :257
-                    nnf_out[(py * npitch + px) * 2] = (int16_t)rx;
-                    nnf_out[(py * npitch + px) * 2 + 1] = (int16_t)ry;
+        for (int rnd = 0; rnd < 2; rnd++) {
+            const int t = rnd * 64 + lane;
+            bool ok = false;
+            int fx = 0, fy = 0;
+            float wgt = 0.0f;
+            if (t < WN) {
+                const int dy2 = t / 9 - WR, dx2 = t % 9 - WR;
+                const int cy = y + dy2, cx = x + dx2;
+                if (cx >= 0 && cy >= 0 && cx < w && cy < h) {
+                    const int dx = nnf_in[(cy * npitch + cx) * 2], dy = nnf_in[(cy * npitch + cx) * 2 + 1];
+                    if (!(dx < 0 || dy < 0)) {                  // "skip invalid disparity", refine :225,238
+                        ok = true;
+                        fx = (int)(int16_t)(dx - cx);
+                        fy = (int)(int16_t)(dy - cy);
+                        const rgbf pix = unpack_rgb(img[cy * ipitch + cx]);
+                        const float delta_r = max_abs_diff(center, pix);
+                        const float coef_r = fast_exp(div_wmf2(-(delta_r * delta_r)));
+                        const float coef_s = s_lut[abs(dx2)] * s_lut[abs(dy2)];
+                        wgt = coef_r * coef_s;                  // refine :198-204
+                    }
                 }
             }
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const int pos = nv + __popcll(m & ((1ull << lane) - 1ull));
+                s_wgt[wv][pos] = wgt; s_fx[wv][pos] = fx; s_fy[wv][pos] = fy;
+            }
+            nv += __popcll(m);
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float bestc = FLT_MAX;
+        int besti = 0x7fffffff;
+        for (int c = lane; c < nv; c += 64) {
+            const int cfx = s_fx[wv][c], cfy = s_fy[wv][c];
+            float costSum = 0.0f, weightSum = 0.0f;
+            for (int t = 0; t < nv; t++) {
+                const float wgt = s_wgt[wv][t];
+                costSum += wgt * (float)max(abs(cfx - s_fx[wv][t]), abs(cfy - s_fy[wv][t]));
+                weightSum += wgt;
+            }
+            if (weightSum > 0.0f && costSum < FLT_MAX) {
+                if (costSum < bestc || (costSum == bestc && c < besti)) { bestc = costSum; besti = c; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float oc = __shfl_xor(bestc, off, 64);
+            const int oi = __shfl_xor(besti, off, 64);
+            if (oc < bestc || (oc == bestc && oi < besti)) { bestc = oc; besti = oi; }
+        }
+        if (lane == 0) {
+            int rx = ox, ry = oy;
+            if (besti != 0x7fffffff) {
+                const int nx = (int)(int16_t)(s_fx[wv][besti] + x), ny = (int)(int16_t)(s_fy[wv][besti] + y);
+                if (!(nx < 0 || ny < 0)) { rx = nx; ry = ny; }          // refine :257
+            }
+            nnf_out[pidx] = (int16_t)rx;
+            nnf_out[pidx + 1] = (int16_t)ry;
+            const bool again = !(only_occ && rx >= 0 && ry >= 0);
+            list_out[atomicAdd(count_out, 1u)] = (e & 0x7fffffffu) | (again ? 0u : kCopyOnly);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
-void launch_wmf(int16_t* nnf_out, const int16_t* nnf_in, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
-                const float* wmf_lut, int only_occlusion, hipStream_t s)
+
+// Runs num_iter launches, ping-ponging between buf_a (input, holds the NNF) and buf_b.  ws: uint32 workspace of
+// 2*w*h + num_iter + 2 words.  Returns the buffer that holds the result.
+int16_t* launch_wmf(int16_t* buf_a, int16_t* buf_b, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
+                    const float* wmf_lut, int num_iter, int only_occlusion, uint32_t* ws, hipStream_t s)
 {
-    dim3 block(WT, WT), grid((w + WT - 1) / WT, (h + WT - 1) / WT);
-    hipLaunchKernelGGL(k_wmf, grid, block, 0, s, nnf_out, nnf_in, img, ipitch, w, h, nnf_pitch, wmf_lut, only_occlusion);
+    if (num_iter <= 0) return buf_a;
+    uint32_t* list0 = ws;
+    uint32_t* list1 = ws + (size_t)w * h;
+    uint32_t* counts = ws + 2 * (size_t)w * h;
+    (void)hipMemsetAsync(counts, 0, sizeof(uint32_t) * (num_iter + 2), s);
+    (void)hipMemcpyAsync(buf_b, buf_a, (size_t)nnf_pitch * h * 4, hipMemcpyDeviceToDevice, s);
+    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(k_wmf_build_list, grid, block, 0, s, buf_a, nnf_pitch, w, h, only_occlusion, list0, counts);
+    const int pixels = w * h;
+    int nblocks = (pixels + 3) / 4;
+    if (nblocks > 1024) nblocks = 1024;
+    int16_t *in = buf_a, *out = buf_b;
+    for (int i = 0; i < num_iter; i++) {
+        hipLaunchKernelGGL(k_wmf_iter, dim3(nblocks), dim3(256), 0, s, out, in, img, ipitch, w, h, nnf_pitch, wmf_lut, only_occlusion,
+                           (i & 1) ? list1 : list0, counts + i, (i & 1) ? list0 : list1, counts + i + 1);
+        int16_t* t = in; in = out; out = t;
+    }
+    return in;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -225,12 +246,12 @@ __global__ __launch_bounds__(256) void k_fill_holes(int16_t* __restrict__ nnf_ou
         for (int c = x + 1; c < w; c++)  { ndx[1] = nnf_in[(y * npitch + c) * 2]; ndy[1] = nnf_in[(y * npitch + c) * 2 + 1]; if (ndx[1] >= 0 && ndy[1] >= 0) { nx[1] = c; break; } }
         for (int c = y - 1; c >= 0; c--) { ndx[2] = nnf_in[(c * npitch + x) * 2]; ndy[2] = nnf_in[(c * npitch + x) * 2 + 1]; if (ndx[2] >= 0 && ndy[2] >= 0) { ny[2] = c; break; } }
         for (int c = y + 1; c < h; c++)  { ndx[3] = nnf_in[(c * npitch + x) * 2]; ndy[3] = nnf_in[(c * npitch + x) * 2 + 1]; if (ndx[3] >= 0 && ndy[3] >= 0) { ny[3] = c; break; } }
-        const rgbf cur = unpack_rgb(tex_px(img, ipitch, w, h, x, y));
+        const rgbf cur = unpack_rgb(tex_rgba(img, ipitch, w, h, x, y));
         float minPixDiff = FLT_MAX;
         int fx = cx_, fy = cy_;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const rgbf np = unpack_rgb(tex_px(img, ipitch, w, h, nx[i], ny[i]));
+            const rgbf np = unpack_rgb(tex_rgba(img, ipitch, w, h, nx[i], ny[i]));
             const float pd = max_abs_diff(cur, np);
             if (pd < minPixDiff && ndx[i] >= 0 && ndy[i] >= 0) {
                 minPixDiff = pd;

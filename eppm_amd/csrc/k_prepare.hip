@@ -106,7 +106,7 @@ __device__ __forceinline__ float lum_of(uint32_t p)
     return 0.3f * c.x + 0.6f * c.y + 0.1f * c.z;
 }
 
-__global__ __launch_bounds__(256) void k_census(uint8_t* __restrict__ census, int cpitch, uint32_t* __restrict__ packed, int ppitch,
+__global__ __launch_bounds__(256) void k_census(uint8_t* __restrict__ census, int cpitch, float4* __restrict__ texels, int tpitch,
                                                 const uint32_t* __restrict__ img, int ipitch, int w, int h)
 {
     __shared__ float lum[6][66];
@@ -132,27 +132,27 @@ __global__ __launch_bounds__(256) void k_census(uint8_t* __restrict__ census, in
     r += (lum[ly + 1][lx] > c) ? 64u : 0u;
     r += (lum[ly + 1][lx + 1] > c) ? 128u : 0u;
     census[y * cpitch + x] = (uint8_t)r;
-    if (packed) packed[y * ppitch + x] = (img[y * ipitch + x] & 0x00ffffffu) | (r << 24);
+    if (texels) texels[y * tpitch + x] = make_texel(img[y * ipitch + x], r);
 }
 
-void launch_census(uint8_t* census, int cpitch, uint32_t* packed, int ppitch, const uint32_t* img, int ipitch, int w, int h, hipStream_t s)
+void launch_census(uint8_t* census, int cpitch, void* texels, int tpitch, const uint32_t* img, int ipitch, int w, int h, hipStream_t s)
 {
     dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(k_census, grid, block, 0, s, census, cpitch, packed, ppitch, img, ipitch, w, h);
+    hipLaunchKernelGGL(k_census, grid, block, 0, s, census, cpitch, (float4*)texels, tpitch, img, ipitch, w, h);
 }
 
-// packed plane from separately supplied image + census planes (the reference-signature launchers receive them apart)
-__global__ __launch_bounds__(256) void k_pack(uint32_t* __restrict__ packed, int ppitch, const uint32_t* __restrict__ img, int ipitch,
+// texel plane from separately supplied image + census planes (the reference-signature launchers receive them apart)
+__global__ __launch_bounds__(256) void k_pack(float4* __restrict__ texels, int tpitch, const uint32_t* __restrict__ img, int ipitch,
                                               const uint8_t* __restrict__ census, int cpitch, int w, int h)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
-    packed[y * ppitch + x] = (img[y * ipitch + x] & 0x00ffffffu) | ((uint32_t)census[y * cpitch + x] << 24);
+    texels[y * tpitch + x] = make_texel(img[y * ipitch + x], census[y * cpitch + x]);
 }
-void launch_pack(uint32_t* packed, int ppitch, const uint32_t* img, int ipitch, const uint8_t* census, int cpitch, int w, int h, hipStream_t s)
+void launch_pack(void* texels, int tpitch, const uint32_t* img, int ipitch, const uint8_t* census, int cpitch, int w, int h, hipStream_t s)
 {
     dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(k_pack, grid, block, 0, s, packed, ppitch, img, ipitch, census, cpitch, w, h);
+    hipLaunchKernelGGL(k_pack, grid, block, 0, s, (float4*)texels, tpitch, img, ipitch, census, cpitch, w, h);
 }
 
 // RGB (3 B/px, tightly packed rows) -> RGBA with alpha 0 (bao_rgb2rgba, basic/bao_basic_cuda.h:258-267)

@@ -165,3 +165,104 @@ def test_end_to_end_crop(crop, crop_stages):
     e.set_data(crop[0], crop[1])
     u2, v2 = e.compute_flow()
     eq(u2, u, "second run u"); eq(v2, v, "second run v")
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole path at other shapes / parameters
+# ---------------------------------------------------------------------------------------------------
+def _run_both(a, b, **params):
+    import eppm_amd
+    from oracle import oracle as O
+    h, w, _ = a.shape
+    e = eppm_amd.EPPM(params=eppm_amd.Params(**params) if params else None)
+    e.init(a, b, h, w)
+    u, v = e.compute_flow()
+    ou, ov = O.compute_flow(a, b, O.default_params(**params) if params else None)
+    return u, v, ou, ov
+
+
+def test_odd_size_pair(frames):
+    """123 x 157: no dimension is a multiple of 16, level dims are odd (61x78 -> 30x39), so the level-2
+    decimation uses a non-exact ratio (real bilinear weights) and every tile kernel has ragged edges."""
+    a, b = frames
+    u, v, ou, ov = _run_both(a[100:223, 200:357].copy(), b[100:223, 200:357].copy())
+    eq(u, ou, "u 157x123"); eq(v, ov, "v 157x123")
+
+
+def test_patch_radius_17_and_other_parameters(crop):
+    """BASELINE config 5 uses PATCH_R 17 (18x18 samples): the R=17 cooperative-sweep and tiled-refine
+    instantiations; R=5 exercises the generic (non-templated) fallbacks; odd iteration / guess counts."""
+    a, b = crop
+    u, v, ou, ov = _run_both(a[:96, :128].copy(), b[:96, :128].copy(), patch_r=17)
+    eq(u, ou, "u R=17"); eq(v, ov, "v R=17")
+    u, v, ou, ov = _run_both(a[:64, :96].copy(), b[:64, :96].copy(), patch_r=5, num_iter=3, num_guess=5, seg_len=7, wmf_iters=4, search_range=11)
+    eq(u, ou, "u R=5 generic"); eq(v, ov, "v R=5 generic")
+
+
+def test_tiny_and_degenerate_inputs():
+    """Smallest supported size, constant images (every patch cost ties at 0), and identical images."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (16, 20, 3), dtype=np.uint8); b = rng.integers(0, 256, (16, 20, 3), dtype=np.uint8)
+    u, v, ou, ov = _run_both(a, b)
+    eq(u, ou, "u 20x16"); eq(v, ov, "v 20x16")
+    c = np.full((40, 48, 3), 99, np.uint8)
+    u, v, ou, ov = _run_both(c, c)
+    eq(u, ou, "u constant"); eq(v, ov, "v constant")
+    black, white = np.zeros((40, 48, 3), np.uint8), np.full((40, 48, 3), 255, np.uint8)
+    u, v, ou, ov = _run_both(black, white)       # all range weights flush to 0 except identical colours
+    eq(u, ou, "u black/white"); eq(v, ov, "v black/white")
+
+
+def test_bundled_pair_full_size(frames):
+    """BASELINE config 1: frame10/frame11 (640x480), default parameters.  HIP flow == oracle flow bit for bit
+    (EPE 0 <= 1e-3 px), and the oracle's flow matches the committed sha256."""
+    import hashlib, json, os
+    from conftest import GOLDEN
+    a, b = frames
+    u, v, ou, ov = _run_both(a, b)
+    epe = float(np.sqrt((u - ou) ** 2 + (v - ov) ** 2).mean())
+    assert epe <= 1e-3
+    eq(u, ou, "u 640x480"); eq(v, ov, "v 640x480")
+    man = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+    assert hashlib.sha256(u.tobytes() + v.tobytes()).hexdigest() == man["oracle_flow_640x480_sha256"]
+
+
+def test_sintel_shape_properties():
+    """BASELINE config 2 at full size (1024x436): size-independent properties instead of the slow oracle --
+    determinism across runs and contexts, host/device entry points agree, integer translation is recovered."""
+    import eppm_amd
+    from eppm_amd import synth
+    h, w = 436, 1024
+    a, b, gu, gv = synth.make_pair(h, w, seed=1234)
+    e1 = eppm_amd.EPPM(); e1.init(a, b, h, w)
+    u1, v1 = e1.compute_flow()
+    e1.set_data(a, b)
+    u2, v2 = e1.compute_flow()
+    e2 = eppm_amd.EPPM(); e2.init(h, w); e2.set_data(a, b)
+    u3, v3 = e2.compute_flow()
+    eq(u1, u2, "same context twice"); eq(v1, v2, "same context twice")
+    eq(u1, u3, "second context"); eq(v1, v3, "second context")
+    assert np.isfinite(u1).all() and np.abs(u1).max() < 200
+    # a pure translation by (8, -4): the interior flow is exactly that vector almost everywhere
+    sh = np.roll(a, (-4, 8), axis=(0, 1))
+    e2.set_data(a, sh)
+    tu, tv = e2.compute_flow()
+    inner = (slice(40, h - 40), slice(40, w - 40))
+    good = (np.abs(tu[inner] - 8) < 0.5) & (np.abs(tv[inner] + 4) < 0.5)
+    assert good.mean() > 0.97, good.mean()
+
+
+def test_c_class_cli_matches_library(frames, tmp_path):
+    """tools/runeppm (the reference's main.cpp I/O contract through the drop-in C++ class) writes the same
+    .flo as the library called from Python."""
+    import os, subprocess
+    import eppm_amd
+    from conftest import GOLDEN
+    exe = os.path.join(os.path.dirname(eppm_amd.lib_path()), "runeppm")
+    out = str(tmp_path / "flow.flo")
+    subprocess.check_call([exe, os.path.join(GOLDEN, "frame10.ppm"), os.path.join(GOLDEN, "frame11.ppm"), out])
+    fu, fv = eppm_amd.io.load_flo(out)
+    a, b = frames
+    e = eppm_amd.EPPM(); e.init(a, b, 480, 640)
+    u, v = e.compute_flow()
+    eq(fu, u, "CLI u"); eq(fv, v, "CLI v")

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--patch-r", type=int, default=9)
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="pairs in flight per GPU: steps are issued round robin over this many contexts, each on its own HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per k_c2f_refine launch from a separate rocprofv3 --pmc pass (profiles/)")
@@ -62,17 +64,26 @@ def main():
     from eppm_amd import synth
     w, h = args.width, args.height
     params = eppm_amd.Params(patch_r=args.patch_r)
-    eng = eppm_amd.EPPM(device=local_rank, params=params)
-    eng.init(h, w)
+    S = max(1, args.inflight)
+    engs = []
+    for _ in range(S):
+        e = eppm_amd.EPPM(device=local_rank, params=params)
+        e.init(h, w)
+        engs.append(e)
+    eng = engs[0]
 
-    # synthetic pair of this rank, as RGBA planes resident in HBM before the timed region
-    img1, img2, gu, gv = synth.make_pair(h, w, seed=1234 + rank)
+    # synthetic pairs of this rank (one per context), as RGBA planes resident in HBM before the timed region
     def to_dev(img):
         rgba = np.zeros((h, w, 4), np.uint8)
         rgba[..., :3] = img
         return torch.from_numpy(rgba).to(dev)
-    d1, d2 = to_dev(img1), to_dev(img2)
-    d_flow = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
+    inputs = []
+    for j in range(S):
+        img1, img2, gu_j, gv_j = synth.make_pair(h, w, seed=1234 + rank * S + j)
+        if j == 0:
+            gu, gv = gu_j, gv_j
+        inputs.append((to_dev(img1), to_dev(img2), torch.empty((h, w, 2), dtype=torch.float32, device=dev)))
+    d_flow = inputs[0][2]
     pitch = w * 4
 
     def barrier():
@@ -81,20 +92,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        eng.set_data_device(d1.data_ptr(), d2.data_ptr(), pitch)
-        eng.compute_flow_device(d_flow.data_ptr())
+    def step(i):
+        e = engs[i % S]
+        a, b, f = inputs[i % S]
+        e.set_data_device(a.data_ptr(), b.data_ptr(), pitch)
+        e.compute_flow_device(f.data_ptr())
 
-    for _ in range(args.warmup):
-        step()
-    eng.synchronize()
+    def sync_all():
+        for e in engs:
+            e.synchronize()
+
+    for i in range(max(args.warmup, S)):
+        step(i)
+    sync_all()
     eng.enable_stage_timing(True)
     eng.stage_times(clear=True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    eng.synchronize()
+    for i in range(args.steps):
+        step(i)
+    sync_all()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -123,7 +140,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"single {w}x{h} Sintel-shape synthetic pair per step, full 3-level pyramid, patch_r={args.patch_r}, "
                                    f"default defs.h parameters; {world} rank(s), independent pairs",
-                       "pairs_per_step_per_gpu": 1, "width": w, "height": h},
+                       "pairs_per_step_per_gpu": 1, "pairs_in_flight_per_gpu": S, "width": w, "height": h},
             "roofline": {"bound": "hbm", "kernel": "k_c2f_refine (level 0)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic_bytes,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms},

@@ -102,6 +102,18 @@ __device__ __forceinline__ float4 tex_px(const float4* img, int pitch, int w, in
     y = iclamp(y, 0, h - 1);
     return img[(unsigned)(y * pitch + x)];
 }
+// 32-bit byte offset form: global_load_dwordx4 with an SGPR base and one VGPR offset (no 64-bit address math).
+// Planes are < 4 GiB (32767 x 32767 is rejected at eppm_create for 16-byte texels beyond that).
+__device__ __forceinline__ float4 texel_at(const float4* base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ unsigned texel_off(int pitch16, int w, int h, int x, int y)
+{
+    x = iclamp(x, 0, w - 1);
+    y = iclamp(y, 0, h - 1);
+    return __umul24((unsigned)y, (unsigned)pitch16) + ((unsigned)x << 4);
+}
 // same for the plain RGBA planes (guide image of the WMF / hole filling)
 __device__ __forceinline__ uint32_t tex_rgba(const uint32_t* img, int pitch, int w, int h, int x, int y)
 {

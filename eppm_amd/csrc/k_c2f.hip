@@ -131,26 +131,29 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, con
             float a2 = max_abs_diff(c1, p1);
             a2 *= a2;
             const float gsp = L.gsp[ii * S + jj];
-            int X, Yoff[3];
+            unsigned Xb, Yoff[3];                         // byte offsets: column and clamped rows of the three targets
+            const unsigned pitch16 = (unsigned)P.pitch << 4;
             if (PASS == 0) {
-                X = iclamp(cx + j, 0, P.w - 1);                       // cx1 + uu: integers, exact in float
+                Xb = (unsigned)iclamp(cx + j, 0, P.w - 1) << 4;        // cx1 + uu: integers, exact in float
 #pragma unroll
-                for (int n = 0; n < 3; n++) Yoff[n] = iclamp(ccy + n - 1 + i, 0, P.h - 1) * P.pitch;
+                for (int n = 0; n < 3; n++) Yoff[n] = __umul24((unsigned)iclamp(ccy + n - 1 + i, 0, P.h - 1), pitch16);
             } else {
                 const float cx1 = (float)(x + j), cy1 = (float)(y + i);
                 const float cx2 = cx1 + uu + (float)(j)*kc[PASS][0] + (float)(i)*kc[PASS][1];
-                X = iclamp((int)floorf(cx2), 0, P.w - 1);
+                Xb = (unsigned)iclamp((int)floorf(cx2), 0, P.w - 1) << 4;
 #pragma unroll
                 for (int n = 0; n < 3; n++) {
                     const float cy2 = cy1 + vv[n] + (float)(j)*kc[PASS][2] + (float)(i)*kc[PASS][3];
-                    Yoff[n] = iclamp((int)floorf(cy2), 0, P.h - 1) * P.pitch;
+                    Yoff[n] = __umul24((unsigned)iclamp((int)floorf(cy2), 0, P.h - 1), pitch16);
                 }
             }
+            float4 q2[3];                                 // the three gathers are issued back to back, then consumed
+#pragma unroll
+            for (int n = 0; n < 3; n++) q2[n] = texel_at(P.pk2, Yoff[n] + Xb);
 #pragma unroll
             for (int n = 0; n < 3; n++) {
-                const float4 q2 = P.pk2[(unsigned)(Yoff[n] + X)];
-                const rgbf p2 = texel_rgb(q2);
-                const int hamming = __builtin_popcount(k1 ^ __float_as_uint(q2.w));
+                const rgbf p2 = texel_rgb(q2[n]);
+                const int hamming = __builtin_popcount(k1 ^ __float_as_uint(q2[n].w));
                 float cost = max_abs_diff(p1, p2);
                 cost = 1 - fast_exp(div_ad2(-(cost * cost)));
                 cost += L.cn[hamming];

@@ -172,20 +172,36 @@ __device__ __forceinline__ void load_patch_lut(PatchLut& L, const float* __restr
 }
 
 // ---- the patch cost, bao_pmflow_kernel.cu:255-301: sequential i-outer / j-inner accumulation ------
+// The gathers of up to 5 consecutive samples are issued together before their terms are computed (the sums
+// still advance in sample order).
 __device__ __forceinline__ float patch_dist(const Planes& P, const PatchLut& L, int R, int x1, int y1, int x2, int y2)
 {
-    const rgbf c1 = texel_rgb(tex_px(P.pk1, P.pitch, P.w, P.h, x1, y1));
-    const rgbf c2 = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, x2, y2));
+    const int pitch16 = P.pitch << 4;
+    const rgbf c1 = texel_rgb(texel_at(P.pk1, texel_off(pitch16, P.w, P.h, x1, y1)));
+    const rgbf c2 = texel_rgb(texel_at(P.pk2, texel_off(pitch16, P.w, P.h, x2, y2)));
     float cost_sum = 0.0f, weight_sum = 0.0f;
     const int S = R + 1;
     for (int ii = 0; ii < S; ii++) {
         const int i = 2 * ii - R;
-        for (int jj = 0; jj < S; jj++) {
-            const int j = 2 * jj - R;
-            float ct, wt;
-            patch_sample(P, c1, c2, x1 + j, y1 + i, x2 + j, y2 + i, L.gsp[ii * S + jj], L.cn, ct, wt);
-            cost_sum += ct;
-            weight_sum += wt;
+        const unsigned r1 = __umul24((unsigned)iclamp(y1 + i, 0, P.h - 1), (unsigned)pitch16);
+        const unsigned r2 = __umul24((unsigned)iclamp(y2 + i, 0, P.h - 1), (unsigned)pitch16);
+        for (int j0 = 0; j0 < S; j0 += 5) {
+            float4 q1[5], q2[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int j = 2 * min(j0 + k, S - 1) - R;
+                q1[k] = texel_at(P.pk1, r1 + ((unsigned)iclamp(x1 + j, 0, P.w - 1) << 4));
+                q2[k] = texel_at(P.pk2, r2 + ((unsigned)iclamp(x2 + j, 0, P.w - 1) << 4));
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                if (j0 + k < S) {
+                    float ct, wt;
+                    patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.cn, ct, wt);
+                    cost_sum += ct;
+                    weight_sum += wt;
+                }
+            }
         }
     }
     return cost_sum / weight_sum;

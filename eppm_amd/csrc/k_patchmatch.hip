@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
     }
     __syncthreads();   // LUT ready
     const int t0 = r * CH;
+    const int pitch16 = P.pitch << 4;
     for (int s = 0; s < L_; s++) {
         if (active && s < count) {
             const int x = IS_ROW ? i : line, y = IS_ROW ? line : i;
@@ -171,14 +172,25 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
             const rgbf c1 = texel_rgb(tex_px(P.pk1, P.pitch, P.w, P.h, x, y));
             const rgbf c2 = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, px, py));
             float tc[CH], tw[CH];
+            constexpr int GB = (CH < 7) ? CH : 7;           // gathers in flight per lane
 #pragma unroll
-            for (int q = 0; q < CH; q++) {
-                const int t = t0 + q;
-                tc[q] = 0.0f; tw[q] = 0.0f;
-                if (t < NS) {
-                    const int ii = t / S, jj = t % S;
-                    const int di = 2 * ii - R, dj = 2 * jj - R;
-                    patch_sample(P, c1, c2, x + dj, y + di, px + dj, py + di, L.gsp[t], L.cn, tc[q], tw[q]);
+            for (int q0 = 0; q0 < CH; q0 += GB) {
+                float4 q1[GB], q2[GB];
+#pragma unroll
+                for (int k = 0; k < GB; k++) {
+                    const int t = min(t0 + q0 + k, NS - 1);
+                    const int di = 2 * (t / S) - R, dj = 2 * (t % S) - R;
+                    q1[k] = texel_at(P.pk1, texel_off(pitch16, P.w, P.h, x + dj, y + di));
+                    q2[k] = texel_at(P.pk2, texel_off(pitch16, P.w, P.h, px + dj, py + di));
+                }
+#pragma unroll
+                for (int k = 0; k < GB; k++) {
+                    const int q = q0 + k;
+                    if (q < CH) {
+                        const int t = t0 + q;
+                        tc[q] = 0.0f; tw[q] = 0.0f;
+                        if (t < NS) patch_terms(q1[k], q2[k], c1, c2, L.gsp[t], L.cn, tc[q], tw[q]);
+                    }
                 }
             }
             // sequential sums in sample order: lane 0's chunk first, then the partial sums move one lane right

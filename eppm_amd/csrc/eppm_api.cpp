@@ -105,7 +105,8 @@ struct eppm_pm_rng {
     unsigned long long seed = 0;
     uint32_t* init_tab = nullptr;
     uint32_t* iter_tab = nullptr;
-    uint32_t* work[2] = {nullptr, nullptr};
+    uint32_t* work[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [problem][ping-pong]
+    int cur[2] = {0, 0};
     uint32_t* skip_mat = nullptr;
     uint32_t skip_weyl = 0;
     PmRngDev dev() const
@@ -147,13 +148,13 @@ static int rng_create(eppm_pm_rng** out, int w, int h, const eppm_params& p)
     r->skip_weyl = 362437u * (uint32_t)skip;
     HIPCHK(hipMalloc(&r->init_tab, words * 4));
     HIPCHK(hipMalloc(&r->iter_tab, words * 4));
-    HIPCHK(hipMalloc(&r->work[0], words * 4));
-    HIPCHK(hipMalloc(&r->work[1], words * 4));
+    for (int k = 0; k < 2; k++)
+        for (int q = 0; q < 2; q++) HIPCHK(hipMalloc(&r->work[k][q], words * 4));
     HIPCHK(hipMalloc(&r->skip_mat, mat.size() * 4));
     HIPCHK(hipMemcpy(r->init_tab, it.data(), words * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(r->iter_tab, st.data(), words * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(r->work[0], st.data(), words * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(r->work[1], st.data(), words * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(r->work[0][0], st.data(), words * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(r->work[1][0], st.data(), words * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(r->skip_mat, mat.data(), mat.size() * 4, hipMemcpyHostToDevice));
     *out = r;
     return EPPM_OK;
@@ -162,7 +163,9 @@ static int rng_create(eppm_pm_rng** out, int w, int h, const eppm_params& p)
 static void rng_free(eppm_pm_rng* r)
 {
     if (!r) return;
-    (void)hipFree(r->init_tab); (void)hipFree(r->iter_tab); (void)hipFree(r->work[0]); (void)hipFree(r->work[1]);
+    (void)hipFree(r->init_tab); (void)hipFree(r->iter_tab);
+    for (int k = 0; k < 2; k++)
+        for (int q = 0; q < 2; q++) (void)hipFree(r->work[k][q]);
     (void)hipFree(r->skip_mat);
     delete r;
 }
@@ -425,11 +428,22 @@ extern "C" int eppm_set_images_device(eppm_ctx* c, const void* d1, const void* d
 }
 
 // ---- baoCudaPatchMatch (kernel.cu:1760-1826) for one problem or for the forward+backward pair at once ----
-static PmProblem mk_problem(const PlanesH& P, float* cost, int16_t* nnf, int16_t* nnf_alt, uint32_t* work)
+static PmProblem mk_problem(const PlanesH& P, float* cost, int16_t* nnf, int16_t* nnf_alt, eppm_pm_rng* rng, int k)
 {
     PmProblem p;
-    p.P = P; p.cost = cost; p.nnf = nnf; p.nnf_alt = nnf_alt; p.rng_work = work;
+    p.P = P; p.cost = cost; p.nnf = nnf; p.nnf_alt = nnf_alt;
+    p.rng_work = rng ? rng->work[k][rng->cur[k]] : nullptr;
+    p.rng_work_next = rng ? rng->work[k][rng->cur[k] ^ 1] : nullptr;
     return p;
+}
+// one random search on the batch; afterwards the advanced RNG states are the current ones
+static void search(PmBatch& b, eppm_pm_rng* rng, const float* lut, const eppm_params& prm, hipStream_t s)
+{
+    launch_pm_random_search(b, rng->dev(), lut, prm.patch_r, prm.search_range, prm.num_guess, s);
+    for (int k = 0; k < b.n; k++) {
+        std::swap(b.p[k].rng_work, b.p[k].rng_work_next);
+        rng->cur[k] ^= 1;
+    }
 }
 // one directional sweep on the batch; keeps the result in p[k].nnf (swaps the ping-pong pair when needed)
 static void sweep(PmBatch& b, const float* lut, const eppm_params& prm, int dir, hipStream_t s)
@@ -438,13 +452,13 @@ static void sweep(PmBatch& b, const float* lut, const eppm_params& prm, int dir,
         for (int k = 0; k < b.n; k++) std::swap(b.p[k].nnf, b.p[k].nnf_alt);
 }
 // returns with the NNF of problem k in b.p[k].nnf (an even number of sweeps: the caller's buffer)
-static void run_patchmatch(PmBatch& b, const PmRngDev& rng, const float* lut, const eppm_params& prm, hipStream_t s)
+static void run_patchmatch(PmBatch& b, eppm_pm_rng* rng, const float* lut, const eppm_params& prm, hipStream_t s)
 {
-    launch_pm_init_field(b, rng, s);
+    launch_pm_init_field(b, rng->dev(), s);
     launch_pm_cost_field(b, lut, prm.patch_r, s);
     for (int it = 0; it < prm.num_iter; it++) {
         for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s);
-        launch_pm_random_search(b, rng, lut, prm.patch_r, prm.search_range, prm.num_guess, s);
+        search(b, rng, lut, prm, s);
     }
 }
 
@@ -461,9 +475,9 @@ extern "C" int eppm_compute_device(eppm_ctx* c, void* d_flow)
     {
         PmBatch b;
         b.n = 2; b.cpitch = lw; b.npitch = lw;
-        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng->work[0]);     // driver :223
-        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng->work[1]);     // driver :224
-        run_patchmatch(b, c->rng->dev(), c->lut_pm, c->prm, s);
+        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0);     // driver :223
+        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1);     // driver :224
+        run_patchmatch(b, c->rng, c->lut_pm, c->prm, s);
     }
     stage_end(c, c->ev);
 
@@ -684,7 +698,7 @@ extern "C" int eppm_pm_rng_reset(eppm_pm_rng* r)
 {
     if (!r) return set_err(EPPM_ERR_ARG, "NULL rng");
     const size_t bytes = (size_t)r->gx * r->gy * 64 * 6 * 4;
-    HIPCHK(hipMemcpy(r->work[0], r->iter_tab, bytes, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(r->work[0][r->cur[0]], r->iter_tab, bytes, hipMemcpyDeviceToDevice));
     return EPPM_OK;
 }
 extern "C" int eppm_pm_rng_destroy(eppm_pm_rng* r) { rng_free(r); return EPPM_OK; }
@@ -695,7 +709,7 @@ extern "C" int eppm_pm_rng_block_states(eppm_pm_rng* r, uint32_t* dst, size_t ds
     if (dst_words < (size_t)nb * 6) return set_err(EPPM_ERR_ARG, "dst too small");
     HIPCHK(hipDeviceSynchronize());
     // lane 0 of each block sits at the block's sequential stream position
-    HIPCHK(hipMemcpy2D(dst, 24, r->work[0], 64 * 24, 24, nb, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(dst, 24, r->work[0][r->cur[0]], 64 * 24, 24, nb, hipMemcpyDeviceToHost));
     return EPPM_OK;
 }
 extern "C" int eppm_pm_gen_rand_field(eppm_pm_rng* r, eppm_short2* d_nnf, int w, int h, size_t disp_pitch)
@@ -706,7 +720,7 @@ extern "C" int eppm_pm_gen_rand_field(eppm_pm_rng* r, eppm_short2* d_nnf, int w,
     b.n = 1; b.cpitch = w; b.npitch = (int)(disp_pitch / 4);
     PlanesH P0;
     P0.pk1 = P0.pk2 = nullptr; P0.w = w; P0.h = h; P0.pitch = w;
-    b.p[0] = mk_problem(P0, nullptr, (int16_t*)d_nnf, nullptr, r->work[0]);
+    b.p[0] = mk_problem(P0, nullptr, (int16_t*)d_nnf, nullptr, r, 0);
     launch_pm_init_field(b, r->dev(), g_stream);
     return finish();
 }
@@ -719,7 +733,7 @@ extern "C" int eppm_pm_cost_field(float* d_cost, const eppm_short2* d_nnf, const
     b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
     PlanesH P;
     CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
-    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, nullptr, nullptr);
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, nullptr, nullptr, 0);
     launch_pm_cost_field(b, ds->lut_pm, g_prm.patch_r, g_stream);
     return finish();
 }
@@ -734,7 +748,7 @@ extern "C" int eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const ep
     b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
     PlanesH P;
     CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
-    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr);
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0);
     for (int d = 0; d < 4; d++)
         if (dir < 0 || dir == d) sweep(b, ds->lut_pm, g_prm, d, g_stream);
     if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
@@ -751,8 +765,8 @@ extern "C" int eppm_pm_random_search(eppm_pm_rng* r, float* d_cost, eppm_short2*
     b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
     PlanesH P;
     CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
-    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, nullptr, r->work[0]);
-    launch_pm_random_search(b, r->dev(), ds->lut_pm, g_prm.patch_r, g_prm.search_range, g_prm.num_guess, g_stream);
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, nullptr, r, 0);
+    search(b, r, ds->lut_pm, g_prm, g_stream);
     return finish();
 }
 extern "C" int eppm_gauss_filter_rgba(eppm_uchar4* d_out, const eppm_uchar4* d_in, size_t pitch, int h, int w, float sigma, int radius)
@@ -854,8 +868,8 @@ extern "C" void baoCudaPatchMatch(eppm_short2* d_disp_vec, float* d_cost, eppm_u
     PlanesH P;
     g_launch_status = mk_planes(ds, &P, d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch);
     if (g_launch_status != EPPM_OK) return;
-    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r->work[0]);
-    run_patchmatch(b, r->dev(), ds->lut_pm, g_prm, g_stream);
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0);
+    run_patchmatch(b, r, ds->lut_pm, g_prm, g_stream);
     if (b.p[0].nnf != (int16_t*)d_disp_vec) (void)hipMemcpyAsync(d_disp_vec, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream);
     g_launch_status = finish();
 }

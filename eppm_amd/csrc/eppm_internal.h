@@ -39,7 +39,8 @@ struct PmProblem {
     float* cost;
     int16_t* nnf;        // short2, current
     int16_t* nnf_alt;    // short2, ping-pong partner for the sweeps
-    uint32_t* rng_work;  // [nblocks][64][6] XORWOW lane states of the random search
+    uint32_t* rng_work;       // [nblocks][64][6] XORWOW lane states read by the random search
+    uint32_t* rng_work_next;  // ... written by it (ping-pong: four workgroups read each block's state, one advances it)
 };
 struct PmBatch {
     PmProblem p[2];

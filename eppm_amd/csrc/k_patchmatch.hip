@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
             const int x = IS_ROW ? i : line, y = IS_ROW ? line : i;
             const int nidx = y * B.npitch + x, cidx = y * B.cpitch + x;
             const float cur_best = cost[cidx];
+            const int ox = nin[nidx * 2], oy = nin[nidx * 2 + 1];     // the pixel's own match, needed on rejection: fetched with the rest
             if (IS_ROW) px = REVERSE ? max(px - 1, 0) : min(px + 1, P.w - 1);
             else        py = REVERSE ? max(py - 1, 0) : min(py + 1, P.h - 1);
             const rgbf c1 = texel_rgb(tex_px(P.pk1, P.pitch, P.w, P.h, x, y));
@@ -215,7 +216,6 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
                     cost[cidx] = cv;
                 }
             } else {
-                const int ox = nin[nidx * 2], oy = nin[nidx * 2 + 1];
                 if (r == 0 && !second_visit) {
                     nout[nidx * 2] = (int16_t)ox;
                     nout[nidx * 2 + 1] = (int16_t)oy;
@@ -326,78 +326,81 @@ bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int
 // ---------------------------------------------------------------------------------------------------
 // Random search (kernel.cu:1519-1594): G guesses at radii search_range, /2, ... around the pre-search
 // best, evaluated in order with strict <.
-// Random numbers: the block's XORWOW stream, 2x256 draws per guess in row-major pixel order; wave 0
-// produces the 512*G draws of this launch in parallel (lane l owns draws [per_lane*l, per_lane*(l+1)) ),
+// Random numbers: the 16x16 block's XORWOW stream, 2x256 draws per guess in row-major pixel order.  One
+// wave produces the 512*G draws of the launch in parallel (lane l owns draws [per_lane*l, per_lane*(l+1)) ),
 // then jumps its state over the other lanes' draws with the GF(2) skip matrix so that the next launch
 // continues the same stream.
-// Evaluation: all guesses come from the pre-search best, so their costs are independent; thread
-// (slot, pixel) evaluates guesses slot and slot+NSLOT of its pixel, the costs meet in LDS and the pixel's
-// first thread replays the reference's in-order strict-< selection.
+// Evaluation: all guesses come from the pre-search best, so their costs are independent.  A workgroup
+// covers a QUARTER of the reference's 16x16 block (4 rows, 64 pixels): wave k evaluates guess k of those 64
+// pixels, the costs meet in LDS and wave 0 replays the reference's in-order strict-< selection.  The four
+// quarter-workgroups of a block draw the same numbers (cheap); only quarter 0 advances the stored state.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
-                                                           int search_range, int G, int nslot)
+__global__ __launch_bounds__(512) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
+                                                          int search_range, int G)
 {
     __shared__ PatchLut L;
     __shared__ int16_t s_rand[8 * 512];
-    __shared__ float s_cost[8][256];
-    __shared__ int s_guess[8][256];
+    __shared__ float s_cost[8][64];
+    __shared__ int s_guess[8][64];
     const PmProblem& pr = B.p[blockIdx.z];
     const int tid = threadIdx.x;
-    const int block_id = blockIdx.y * rng.gx + blockIdx.x;
+    const int tile_y = blockIdx.y >> 2, quarter = blockIdx.y & 3;
+    const int block_id = tile_y * rng.gx + blockIdx.x;
     load_patch_lut(L, lut, R, tid, blockDim.x);
     if (tid < 64) {
         const size_t so = ((size_t)block_id * 64 + tid) * 6;
         Xorwow st = load_state(pr.rng_work + so);
         const int base = rng.per_lane * tid;
         for (int q = 0; q < rng.per_lane; q++) s_rand[base + q] = (int16_t)xorwow_next(st);   // short(rdn), :1550-1551
-        // jump over the other 63 lanes' draws: v <- v * skip_mat over GF(2); Weyl counter by multiplication
-        const uint32_t v[5] = {st.v0, st.v1, st.v2, st.v3, st.v4};
-        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+        if (quarter == 0) {
+            // jump over the other 63 lanes' draws: v <- v * skip_mat over GF(2); Weyl counter by multiplication
+            const uint32_t v[5] = {st.v0, st.v1, st.v2, st.v3, st.v4};
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
 #pragma unroll
-        for (int wd = 0; wd < 5; wd++) {
-            const uint32_t vw = v[wd];
+            for (int wd = 0; wd < 5; wd++) {
+                const uint32_t vw = v[wd];
 #pragma unroll 8
-            for (int b = 0; b < 32; b++) {
-                const uint32_t* row = rng.skip_mat + (wd * 32 + b) * 5;
-                const uint32_t m = 0u - ((vw >> b) & 1u);
-                a0 ^= m & row[0]; a1 ^= m & row[1]; a2 ^= m & row[2]; a3 ^= m & row[3]; a4 ^= m & row[4];
+                for (int b = 0; b < 32; b++) {
+                    const uint32_t* row = rng.skip_mat + (wd * 32 + b) * 5;
+                    const uint32_t m = 0u - ((vw >> b) & 1u);
+                    a0 ^= m & row[0]; a1 ^= m & row[1]; a2 ^= m & row[2]; a3 ^= m & row[3]; a4 ^= m & row[4];
+                }
             }
+            st.v0 = a0; st.v1 = a1; st.v2 = a2; st.v3 = a3; st.v4 = a4;
+            st.d += rng.skip_weyl;
+            store_state(pr.rng_work_next + so, st);
         }
-        st.v0 = a0; st.v1 = a1; st.v2 = a2; st.v3 = a3; st.v4 = a4;
-        st.d += rng.skip_weyl;
-        store_state(pr.rng_work + so, st);
     }
     __syncthreads();
     const Planes P = to_dev(pr.P);
-    const int pix = tid & 255, slot = tid >> 8;
-    const int x = blockIdx.x * kBlock + (pix & 15), y = blockIdx.y * kBlock + (pix >> 4);
+    const int lane = tid & 63, k = tid >> 6;                     // wave k = guess k
+    const int pix = quarter * 64 + lane;                         // row-major index inside the 16x16 block
+    const int x = blockIdx.x * kBlock + (pix & 15), y = tile_y * kBlock + (pix >> 4);
     const bool inimg = (x < P.w && y < P.h);
     const int nidx = y * B.npitch + x, cidx = y * B.cpitch + x;
     int bx = 0, by = 0;
-    if (inimg) { bx = pr.nnf[nidx * 2]; by = pr.nnf[nidx * 2 + 1]; }
     if (inimg) {
-        for (int k = slot; k < G; k += nslot) {
-            // sampling window of guess k: mag = search_range halved k times while >= 1 (:1564)
-            int mag = search_range;
-            for (int q = 0; q < k; q++) if (mag / 2 >= 1) mag /= 2;
-            const uint32_t rdn1 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix];       // short -> unsigned int, :1558-1559
-            const uint32_t rdn2 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix + 1];
-            const int xmin = max(bx - mag, 0), xmax = min(bx + mag + 1, P.w + 1);
-            const int ymin = max(by - mag, 0), ymax = min(by + mag + 1, P.h + 1);
-            const int gx = (int)(int16_t)((uint32_t)xmin + rdn1 % (uint32_t)(xmax - xmin));
-            const int gy = (int)(int16_t)((uint32_t)ymin + rdn2 % (uint32_t)(ymax - ymin));
-            s_cost[k][pix] = patch_dist(P, L, R, x, y, gx, gy);
-            s_guess[k][pix] = (gx & 0xffff) | (gy << 16);
-        }
+        bx = pr.nnf[nidx * 2]; by = pr.nnf[nidx * 2 + 1];
+        // sampling window of guess k: mag = search_range halved k times while >= 1 (:1564)
+        int mag = search_range;
+        for (int q = 0; q < k; q++) if (mag / 2 >= 1) mag /= 2;
+        const uint32_t rdn1 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix];       // short -> unsigned int, :1558-1559
+        const uint32_t rdn2 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix + 1];
+        const int xmin = max(bx - mag, 0), xmax = min(bx + mag + 1, P.w + 1);
+        const int ymin = max(by - mag, 0), ymax = min(by + mag + 1, P.h + 1);
+        const int gx = (int)(int16_t)((uint32_t)xmin + rdn1 % (uint32_t)(xmax - xmin));
+        const int gy = (int)(int16_t)((uint32_t)ymin + rdn2 % (uint32_t)(ymax - ymin));
+        s_cost[k][lane] = patch_dist(P, L, R, x, y, gx, gy);
+        s_guess[k][lane] = (gx & 0xffff) | (gy << 16);
     }
     __syncthreads();
-    if (slot == 0 && inimg) {
+    if (k == 0 && inimg) {
         float best_cost = pr.cost[cidx];
-        for (int k = 0; k < G; k++) {
-            const float cv = s_cost[k][pix];
+        for (int g = 0; g < G; g++) {
+            const float cv = s_cost[g][lane];
             if (cv < best_cost) {
-                const int g = s_guess[k][pix];
-                bx = (int)(int16_t)(g & 0xffff); by = g >> 16; best_cost = cv;
+                const int e = s_guess[g][lane];
+                bx = (int)(int16_t)(e & 0xffff); by = e >> 16; best_cost = cv;
             }
         }
         pr.nnf[nidx * 2] = (int16_t)bx;
@@ -409,9 +412,8 @@ __global__ __launch_bounds__(1024) void k_pm_random_search(PmBatch B, PmRngDev r
 void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float* lut, int R, int search_range, int num_guess,
                              hipStream_t s)
 {
-    const int nslot = (num_guess + 1) / 2;         // two guesses per thread
-    dim3 grid(rng.gx, rng.gy, b.n), block(256 * nslot);
-    hipLaunchKernelGGL(k_pm_random_search, grid, block, 0, s, b, rng, lut, R, search_range, num_guess, nslot);
+    dim3 grid(rng.gx, rng.gy * 4, b.n), block(64 * num_guess);
+    hipLaunchKernelGGL(k_pm_random_search, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
 }
 
 }  // namespace eppm

@@ -183,7 +183,14 @@ __global__ __launch_bounds__(256) void k_c2f_refine_tiled(PlanesH Ph, float* __r
     const int tid = threadIdx.y * kBlock + threadIdx.x;
     load_patch_lut(L, lut, R, tid, 256);
     const Planes P = to_dev(Ph);
-    const int x0 = blockIdx.x * kBlock, y0 = blockIdx.y * kBlock;
+    // XCD-aware tile order: workgroups are dealt round robin over the 8 XCDs (b % 8), each with its own L2.
+    // Give XCD k the k-th contiguous eighth of the row-major tile list so that neighbouring tiles -- which
+    // share their R-pixel halos and their target windows -- hit the same L2 (speed only, never correctness).
+    const int tiles_x = (P.w + kBlock - 1) / kBlock, tiles = tiles_x * ((P.h + kBlock - 1) / kBlock);
+    const int per_xcd = (tiles + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= tiles) return;
+    const int x0 = (tile % tiles_x) * kBlock, y0 = (tile / tiles_x) * kBlock;
     for (int t = tid; t < TW * TW; t += 256) {
         const int sy = iclamp(y0 + t / TW - R, 0, P.h - 1), sx = iclamp(x0 + t % TW - R, 0, P.w - 1);
         s_src[t] = P.pk1[(unsigned)(sy * P.pitch + sx)];
@@ -229,8 +236,10 @@ __global__ __launch_bounds__(256) void k_c2f_refine_tiled(PlanesH Ph, float* __r
 void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, hipStream_t s)
 {
     dim3 grid((P.w + kBlock - 1) / kBlock, (P.h + kBlock - 1) / kBlock), block(kBlock, kBlock);
-    if (R == 9) hipLaunchKernelGGL((k_c2f_refine_tiled<9>), grid, block, 0, s, P, flow, lut);
-    else if (R == 17) hipLaunchKernelGGL((k_c2f_refine_tiled<17>), grid, block, 0, s, P, flow, lut);
+    const int tiles = grid.x * grid.y;
+    dim3 grid1(((tiles + 7) / 8) * 8);           // 1-D, padded so every XCD gets the same number of slots
+    if (R == 9) hipLaunchKernelGGL((k_c2f_refine_tiled<9>), grid1, block, 0, s, P, flow, lut);
+    else if (R == 17) hipLaunchKernelGGL((k_c2f_refine_tiled<17>), grid1, block, 0, s, P, flow, lut);
     else hipLaunchKernelGGL(k_c2f_refine, grid, block, 0, s, P, flow, lut, R);
 }
 

@@ -4,8 +4,11 @@
 A step = one pass of the hot path (set_data's device part: prefilter + pyramid + census, then
 compute_flow: PatchMatch fwd/bwd at 1/4 res, L-R check, outlier removal, weighted median, hole fill,
 two coarse-to-fine levels, final smoothing) over ONE synthetic 1024x436 pair whose RGBA planes are
-already resident in HBM.  N > 1: one process per GPU, each rank its own pairs (independent pairs, no
-data-path collective: SURVEY 8e); value = pairs of all ranks * W*H / max-over-ranks time.
+already resident in HBM.  Steps are issued round robin over --inflight contexts (default 3), each on its own HIP stream, so the
+quarter-resolution stages of one pair (latency bound: too few pixels to fill 256 CUs) overlap the
+full-resolution stages of another; every step's work runs inside the timed region and the single-pair
+latency is reported next to the throughput.  N > 1: one process per GPU, each rank its own pairs
+(independent pairs, no data-path collective: SURVEY 8e); value = pairs of all ranks * W*H / max-over-ranks time.
 
 Prints one JSON line (see the task contract) with `roofline` (dominant kernel: the level-0 plane-fit
 candidate refine, algorithmic HBM bytes / HIP-event duration) and `cpu_baseline` (the CPU oracle on a
@@ -28,6 +31,10 @@ W, H = 1024, 436               # BASELINE.json configs[1]
 # algorithmic HBM bytes per level-0 pixel of one k_c2f_refine launch: reads flow 8 + img1 4 + img2 4 +
 # census1 1 + census2 1, writes flow 8  
 REFINE_BYTES_PER_PX = 26
+# HBM-side bytes of one level-0 k_c2f_refine_tiled launch at 1024x436 from the PMC passes committed under
+# profiles/r01_c_pmc_{fetch,write}_size.csv: FETCH_SIZE 11475.3 KB (x2: gfx950 tallies the 128-B requests of
+# 16-B-per-lane loads at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE 3488.0 KB
+TRAFFIC_BYTES_1024x436 = (2 * 11475.3 + 3488.0) * 1024
 
 
 def main():
@@ -38,7 +45,7 @@ def main():
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--patch-r", type=int, default=9)
-    ap.add_argument("--inflight", type=int, default=1,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="pairs in flight per GPU: steps are issued round robin over this many contexts, each on its own HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -105,6 +112,15 @@ def main():
     for i in range(max(args.warmup, S)):
         step(i)
     sync_all()
+    # single-pair latency (one context, one stream, nothing else in flight): reported beside the throughput
+    lat = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(0)
+        engs[0].synchronize()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    latency_ms = float(np.median(lat))
     eng.enable_stage_timing(True)
     eng.stage_times(clear=True)
     barrier()
@@ -142,8 +158,10 @@ def main():
                                    f"default defs.h parameters; {world} rank(s), independent pairs",
                        "pairs_per_step_per_gpu": 1, "pairs_in_flight_per_gpu": S, "width": w, "height": h},
             "roofline": {"bound": "hbm", "kernel": "k_c2f_refine (level 0)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic_bytes,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": args.traffic_bytes if args.traffic_bytes is not None else (TRAFFIC_BYTES_1024x436 if (w, h, args.patch_r) == (W, H, 9) else None),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms},
+            "latency_ms_per_pair": latency_ms,
             "stage_ms": stage_ms,
             "epe_vs_synthetic_gt": epe_gt,
         }
@@ -156,17 +174,17 @@ def main():
 
 def cpu_baseline(w, h):
     """The CPU oracle (oracle/, a port of the reference's kernel semantics: the reference has no CPU path)
-    timed on this host on a bounded sample: one pair of a quarter of the workload's pixels."""
+    timed on this host on a bounded sample: the workload's pair once (about 25 s on 8 cores, 6 s on 128)."""
     from oracle import oracle as O
     from eppm_amd import synth
-    sw, sh = w // 2, h // 2
+    sw, sh = w, h
     a, b, _, _ = synth.make_pair(sh, sw, seed=1234)
     O.compute_flow(a[:32, :32].copy(), b[:32, :32].copy())      # build + warm
     t0 = time.perf_counter()
     O.compute_flow(a, b)
     dt = time.perf_counter() - t0
     return {"value": sw * sh / dt / 1e6, "unit": "Mflow-vectors/s", "cores": O.num_threads(), "kind": "port",
-            "sample": f"1 pair {sw}x{sh} (same generator, 1/4 of the workload's pixels), full path, {dt:.1f} s, OpenMP oracle"}
+            "sample": f"1 pair {sw}x{sh} (the workload's own pair, seed 1234), whole path once, {dt:.1f} s, OpenMP oracle"}
 
 
 if __name__ == "__main__":

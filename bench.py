@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--patch-r", type=int, default=9)
     ap.add_argument("--inflight", type=int, default=3,
                     help="pairs in flight per GPU: steps are issued round robin over this many contexts, each on its own HIP stream")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per k_c2f_refine launch from a separate rocprofv3 --pmc pass (profiles/)")
@@ -58,14 +59,23 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if os.environ.get("EPPM_BENCH_SHARE_GPU"):      # test hook: several ranks on one GPU (gloo only)
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        backend = args.dist_backend
+        if backend == "nccl":                        # RCCL: used only for the barrier and the MAX of the wall time
+            try:
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+            except Exception as e:                   # the data path needs no collective: gloo is as good for timing
+                print(f"[bench] nccl init failed ({e}); falling back to gloo", file=sys.stderr)
+                backend = "gloo"
+        if backend == "gloo":
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    tdev = dev if (world > 1 and dist.get_backend() == "nccl") else torch.device("cpu")
 
     import eppm_amd
     from eppm_amd import synth
@@ -131,7 +141,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stages = eng.stage_times(clear=True)

@@ -12,6 +12,13 @@
 #include "eppm_device.cuh"
 #include "eppm_internal.h"
 
+#ifndef EPPM_LPC9
+#define EPPM_LPC9 16      // lanes per sweep chain at patch radius 9 (100 samples): 32 cuts the single-pair latency 4 % but costs throughput with pairs in flight
+#endif
+#ifndef EPPM_LPC17
+#define EPPM_LPC17 64     // ... at patch radius 17 (324 samples)
+#endif
+
 namespace eppm {
 
 __device__ __forceinline__ Planes to_dev(const PlanesH& h)
@@ -110,15 +117,19 @@ void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t
 //      workgroup) and a workgroup barrier follows step 0.
 // cost is updated in place: a pixel's cost is touched only by its visitor(s).
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dpp_row_ror1(float v)
+// lane i receives lane i-1: inside a 16-lane DPP row (row_ror:1) or across the whole wave (wave_shr:1, gfx9)
+template <int LPC>
+__device__ __forceinline__ float dpp_prev_lane(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+    if (LPC == 16) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
-template <int R, bool IS_ROW, bool REVERSE>
+// LPC = lanes per chain (16, 32 or 64)
+template <int R, int LPC, bool IS_ROW, bool REVERSE>
 __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __restrict__ lut, int L_, int nseg, int nseg_pad)
 {
-    constexpr int S = R + 1, NS = S * S, CH = (NS + 15) / 16;
+    constexpr int S = R + 1, NS = S * S, CH = (NS + LPC - 1) / LPC, CPB = 256 / LPC;
     __shared__ PatchLut L;
     load_patch_lut(L, lut, R, threadIdx.x, 256);
     const PmProblem& pr = B.p[blockIdx.y];
@@ -127,8 +138,8 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
     int16_t* __restrict__ nout = pr.nnf_alt;
     float* __restrict__ cost = pr.cost;
     const int len = IS_ROW ? P.w : P.h, lines = IS_ROW ? P.h : P.w;
-    const int grp = threadIdx.x >> 4, r = threadIdx.x & 15;
-    const int chain = blockIdx.x * 16 + grp;
+    const int grp = threadIdx.x / LPC, r = threadIdx.x % LPC;
+    const int chain = blockIdx.x * CPB + grp;
     const int line = chain / nseg_pad, seg = chain % nseg_pad;
     const bool active = (line < lines) && (seg < nseg);
     int start, count, i, step;
@@ -199,13 +210,13 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
             constexpr int NL = (NS + CH - 1) / CH;       // lanes that own samples
 #pragma unroll
             for (int ln = 0; ln < NL; ln++) {
-                if (ln > 0) { ac = dpp_row_ror1(ac); aw = dpp_row_ror1(aw); }
+                if (ln > 0) { ac = dpp_prev_lane<LPC>(ac); aw = dpp_prev_lane<LPC>(aw); }
 #pragma unroll
                 for (int q = 0; q < CH; q++) {
                     if (ln * CH + q < NS) { ac += tc[q]; aw += tw[q]; }
                 }
             }
-            const int src = (threadIdx.x & 48) | (NL - 1);          // lane holding the complete sums (wave-relative)
+            const int src = ((threadIdx.x & 63) / LPC) * LPC + (NL - 1);   // lane holding the complete sums (wave-relative)
             const float cs = __shfl(ac, src, 64), ws = __shfl(aw, src, 64);
             const float cv = cs / ws;
             const bool second_visit = (!REVERSE) && (seg == 0) && (s == L_ - 1) && (nseg > 1);   // pixel L, after segment 1
@@ -287,17 +298,18 @@ __global__ __launch_bounds__(1024) void k_pm_seg_propagate(PmBatch B, const floa
     }
 }
 
-template <int R>
+template <int R, int LPC>
 static void launch_sweep_r(const PmBatch& b, const float* lut, int seg_len, int dir, int nseg, int lines, hipStream_t s)
 {
     const int nseg_pad = (nseg + 1) & ~1;
     const int chains = lines * nseg_pad;
-    dim3 grid((chains + 15) / 16, b.n), block(256);
+    constexpr int CPB = 256 / LPC;
+    dim3 grid((chains + CPB - 1) / CPB, b.n), block(256);
     switch (dir) {
-        case 0: hipLaunchKernelGGL((k_pm_sweep<R, true, false>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
-        case 1: hipLaunchKernelGGL((k_pm_sweep<R, false, false>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
-        case 2: hipLaunchKernelGGL((k_pm_sweep<R, true, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
-        default: hipLaunchKernelGGL((k_pm_sweep<R, false, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
+        case 0: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, false>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
+        case 1: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, false>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
+        case 2: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
+        default: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
     }
 }
 
@@ -307,8 +319,8 @@ bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int
     const bool is_row = (dir == 0 || dir == 2);
     const int len = is_row ? P.w : P.h, lines = is_row ? P.h : P.w;
     const int nseg = (len + seg_len - 1) / seg_len;
-    if (R == 9) { launch_sweep_r<9>(b, lut, seg_len, dir, nseg, lines, s); return true; }
-    if (R == 17) { launch_sweep_r<17>(b, lut, seg_len, dir, nseg, lines, s); return true; }
+    if (R == 9) { launch_sweep_r<9, EPPM_LPC9>(b, lut, seg_len, dir, nseg, lines, s); return true; }
+    if (R == 17) { launch_sweep_r<17, EPPM_LPC17>(b, lut, seg_len, dir, nseg, lines, s); return true; }
     if (nseg > 1024) return false;   // eppm_create / the launchers validate sizes
     int lpb = 256 / nseg;
     if (lpb < 1) lpb = 1;

@@ -177,9 +177,13 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, con
 template <int R>
 __global__ __launch_bounds__(256) void k_c2f_refine_tiled(PlanesH Ph, float* __restrict__ flow, const float* __restrict__ lut)
 {
-    constexpr int TW = kBlock + 2 * R;
+    constexpr int TWU = kBlock + 2 * R;                 // used tile width
+    // row stride padded to a multiple of 16 texels (256 B): a ds_read_b128 wave access is served in groups made
+    // of 8 lanes of one tile row and 8 of the next (MI355X LDS lane groups); with the stride = 0 mod 256 B the two
+    // halves fall on disjoint banks (34-texel rows cost a 2-way conflict on about every read)
+    constexpr int TW = (TWU + 15) / 16 * 16;
     __shared__ PatchLut L;
-    __shared__ float4 s_src[TW * TW];
+    __shared__ float4 s_src[TWU * TW];
     const int tid = threadIdx.y * kBlock + threadIdx.x;
     load_patch_lut(L, lut, R, tid, 256);
     const Planes P = to_dev(Ph);
@@ -191,9 +195,10 @@ __global__ __launch_bounds__(256) void k_c2f_refine_tiled(PlanesH Ph, float* __r
     const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (tile >= tiles) return;
     const int x0 = (tile % tiles_x) * kBlock, y0 = (tile / tiles_x) * kBlock;
-    for (int t = tid; t < TW * TW; t += 256) {
-        const int sy = iclamp(y0 + t / TW - R, 0, P.h - 1), sx = iclamp(x0 + t % TW - R, 0, P.w - 1);
-        s_src[t] = P.pk1[(unsigned)(sy * P.pitch + sx)];
+    for (int t = tid; t < TWU * TWU; t += 256) {
+        const int ry = t / TWU, rx = t % TWU;
+        const int sy = iclamp(y0 + ry - R, 0, P.h - 1), sx = iclamp(x0 + rx - R, 0, P.w - 1);
+        s_src[ry * TW + rx] = P.pk1[(unsigned)(sy * P.pitch + sx)];
     }
     __syncthreads();
     const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;

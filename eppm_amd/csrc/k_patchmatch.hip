@@ -181,6 +181,12 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
             const int ox = nin[nidx * 2], oy = nin[nidx * 2 + 1];     // the pixel's own match, needed on rejection: fetched with the rest
             if (IS_ROW) px = REVERSE ? max(px - 1, 0) : min(px + 1, P.w - 1);
             else        py = REVERSE ? max(py - 1, 0) : min(py + 1, P.h - 1);
+            // A candidate equal to the pixel's current match would reproduce the stored cost bit for bit
+            // (every cost in the plane was produced by this same sum), so "cv < cur_best" is false: the
+            // reference evaluates and rejects it, here the evaluation is skipped.  Converged regions --
+            // neighbours sharing one offset -- make this the common case after the first iterations.
+            float cv = cur_best;
+            if (!(px == ox && py == oy)) {
             const rgbf c1 = texel_rgb(tex_px(P.pk1, P.pitch, P.w, P.h, x, y));
             const rgbf c2 = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, px, py));
             float tc[CH], tw[CH];
@@ -218,7 +224,8 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
             }
             const int src = ((threadIdx.x & 63) / LPC) * LPC + (NL - 1);   // lane holding the complete sums (wave-relative)
             const float cs = __shfl(ac, src, 64), ws = __shfl(aw, src, 64);
-            const float cv = cs / ws;
+            cv = cs / ws;
+            }
             const bool second_visit = (!REVERSE) && (seg == 0) && (s == L_ - 1) && (nseg > 1);   // pixel L, after segment 1
             if (cv < cur_best) {
                 if (r == 0) {
@@ -283,7 +290,8 @@ __global__ __launch_bounds__(1024) void k_pm_seg_propagate(PmBatch B, const floa
             const float cur_best = cost[cidx];
             if (IS_ROW) px = REVERSE ? max(px - 1, 0) : min(px + 1, P.w - 1);
             else        py = REVERSE ? max(py - 1, 0) : min(py + 1, P.h - 1);
-            const float cv = patch_dist(P, L, R, x, y, px, py);
+            const bool same = (px == nnf[nidx * 2]) && (py == nnf[nidx * 2 + 1]);   // would reproduce cur_best: rejected
+            const float cv = same ? cur_best : patch_dist(P, L, R, x, y, px, py);
             if (cv < cur_best) {
                 nnf[nidx * 2] = (int16_t)px;
                 nnf[nidx * 2 + 1] = (int16_t)py;

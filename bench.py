@@ -28,13 +28,13 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 W, H = 1024, 436               # BASELINE.json configs[1]
-# algorithmic HBM bytes per level-0 pixel of one k_c2f_refine launch: reads flow 8 + img1 4 + img2 4 +
-# census1 1 + census2 1, writes flow 8  
+# algorithmic HBM bytes per pixel of one k_c2f_refine launch (the dominant kernel; it runs once at level 1 and
+# once at level 0 per pair): reads flow 8 + img1 4 + img2 4 + census1 1 + census2 1, writes flow 8
 REFINE_BYTES_PER_PX = 26
-# HBM-side bytes of one level-0 k_c2f_refine_tiled launch at 1024x436 from the PMC passes committed under
-# profiles/r01_c_pmc_{fetch,write}_size.csv: FETCH_SIZE 11475.3 KB (x2: gfx950 tallies the 128-B requests of
-# 16-B-per-lane loads at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE 3488.0 KB
-TRAFFIC_BYTES_1024x436 = (2 * 11475.3 + 3488.0) * 1024
+# HBM-side bytes per k_c2f_refine_tiled launch at 1024x436, mean of the level-1 and level-0 launches, from the PMC
+# passes committed under profiles/r01_c_pmc_{fetch,write}_size.csv: FETCH_SIZE 3614.2 / 11475.3 KB (x2: gfx950 tallies
+# the 128-B requests of 16-B-per-lane loads at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE 872.0 / 3488.0 KB
+TRAFFIC_BYTES_1024x436 = ((2 * 3614.2 + 872.0) + (2 * 11475.3 + 3488.0)) / 2 * 1024
 
 
 def main():
@@ -156,9 +156,11 @@ def main():
         for name, ms in stages:
             agg.setdefault(name, []).append(ms)
         stage_ms = {k: float(np.mean(v)) for k, v in agg.items()}
-        dom = "c2f_refine_L0"
-        dom_ms = stage_ms.get(dom, float("nan"))
-        alg_bytes = REFINE_BYTES_PER_PX * w * h
+        # dominant kernel = k_c2f_refine_tiled; per launch = mean over its two launches per pair (levels 1 and 0),
+        # which is what rocprofv3 --stats averages for that kernel name
+        lv = eng.level_dims()
+        dom_ms = (stage_ms.get("c2f_refine_L0", float("nan")) + stage_ms.get("c2f_refine_L1", float("nan"))) / 2
+        alg_bytes = REFINE_BYTES_PER_PX * (lv[0][0] * lv[0][1] + lv[1][0] * lv[1][1]) / 2
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         out = {
             "metric": "Mflow-vectors/sec", "value": world * args.steps * w * h / dt / 1e6, "unit": "Mflow-vectors/s",
@@ -167,7 +169,7 @@ def main():
             "config": {"workload": f"single {w}x{h} Sintel-shape synthetic pair per step, full 3-level pyramid, patch_r={args.patch_r}, "
                                    f"default defs.h parameters; {world} rank(s), independent pairs",
                        "pairs_per_step_per_gpu": 1, "pairs_in_flight_per_gpu": S, "width": w, "height": h},
-            "roofline": {"bound": "hbm", "kernel": "k_c2f_refine (level 0)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_c2f_refine_tiled (mean of its level-1 and level-0 launches)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": args.traffic_bytes if args.traffic_bytes is not None else (TRAFFIC_BYTES_1024x436 if (w, h, args.patch_r) == (W, H, 9) else None),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms},

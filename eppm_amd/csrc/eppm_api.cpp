@@ -51,7 +51,7 @@ extern "C" int eppm_default_params(eppm_params* p)
 {
     if (!p) return set_err(EPPM_ERR_ARG, "eppm_default_params: NULL");
     p->patch_r = 9; p->num_iter = 10; p->search_range = 30; p->num_guess = 6;
-    p->seg_len = 10; p->wmf_iters = 20; p->seed = 1234ULL;
+    p->seg_len = 10; p->wmf_iters = 20; p->seed = 1234ULL; p->propagation = 0;
     return EPPM_OK;
 }
 
@@ -62,6 +62,7 @@ static int check_params(const eppm_params& p)
     if (p.num_guess < 1 || p.num_guess > 8) return set_err(EPPM_ERR_ARG, "num_guess %d out of range [1,8]", p.num_guess);
     if (p.seg_len < 2) return set_err(EPPM_ERR_ARG, "seg_len %d < 2", p.seg_len);
     if (p.search_range < 1) return set_err(EPPM_ERR_ARG, "search_range %d < 1", p.search_range);
+    if (p.propagation != 0 && p.propagation != 1) return set_err(EPPM_ERR_ARG, "propagation %d: 0 (segmented sweeps) or 1 (jump flood)", p.propagation);
     return EPPM_OK;
 }
 
@@ -451,13 +452,22 @@ static void sweep(PmBatch& b, const float* lut, const eppm_params& prm, int dir,
     if (launch_pm_sweep(b, lut, prm.patch_r, prm.seg_len, dir, s))
         for (int k = 0; k < b.n; k++) std::swap(b.p[k].nnf, b.p[k].nnf_alt);
 }
+// baoJumpPropagate: six Jacobi launches (kernel.cu:849-854); an even number of swaps
+static void jump(PmBatch& b, const float* lut, const eppm_params& prm, hipStream_t s)
+{
+    for (int step = 32; step >= 1; step /= 2) {
+        launch_pm_jump(b, lut, prm.patch_r, step, s);
+        for (int k = 0; k < b.n; k++) std::swap(b.p[k].nnf, b.p[k].nnf_alt);
+    }
+}
 // returns with the NNF of problem k in b.p[k].nnf (an even number of sweeps: the caller's buffer)
 static void run_patchmatch(PmBatch& b, eppm_pm_rng* rng, const float* lut, const eppm_params& prm, hipStream_t s)
 {
     launch_pm_init_field(b, rng->dev(), s);
     launch_pm_cost_field(b, lut, prm.patch_r, s);
     for (int it = 0; it < prm.num_iter; it++) {
-        for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s);
+        if (prm.propagation == 1) jump(b, lut, prm, s);
+        else for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s);
         search(b, rng, lut, prm, s);
     }
 }
@@ -612,7 +622,7 @@ struct DevState {
 std::mutex g_mu;
 std::map<int, DevState> g_dev;
 hipStream_t g_stream = nullptr;
-eppm_params g_prm = {9, 10, 30, 6, 10, 20, 1234ULL};
+eppm_params g_prm = {9, 10, 30, 6, 10, 20, 1234ULL, 0};
 int g_launch_status = EPPM_OK;
 
 int dev_state(DevState** out)
@@ -751,6 +761,22 @@ extern "C" int eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const ep
     b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0);
     for (int d = 0; d < 4; d++)
         if (dir < 0 || dir == d) sweep(b, ds->lut_pm, g_prm, d, g_stream);
+    if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
+    return finish();
+}
+extern "C" int eppm_pm_jump_propagate(float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* i1, const eppm_uchar4* i2,
+                                      const unsigned char* c1, const unsigned char* c2, int w, int h, size_t img_pitch,
+                                      size_t cost_pitch, size_t disp_pitch, size_t census_pitch)
+{
+    LAUNCHER_BEGIN_INT;
+    void* tmp = nullptr;
+    CHK(get_scratch(ds, disp_pitch * h, &tmp));
+    PmBatch b;
+    b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
+    PlanesH P;
+    CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0);
+    jump(b, ds->lut_pm, g_prm, g_stream);
     if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
     return finish();
 }

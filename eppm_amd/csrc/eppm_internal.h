@@ -61,6 +61,8 @@ void launch_pm_init_field(const PmBatch& b, const PmRngDev& rng, hipStream_t s);
 void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t s);
 // one directional sweep; returns true when the result is in nnf_alt (caller swaps nnf/nnf_alt)
 bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s);
+// one jump-flood launch (step = neighbour distance); reads nnf, writes nnf_alt (caller swaps)
+void launch_pm_jump(const PmBatch& b, const float* lut, int R, int step, hipStream_t s);
 void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float* lut, int R, int search_range, int num_guess,
                              hipStream_t s);
 

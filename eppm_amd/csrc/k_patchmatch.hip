@@ -344,6 +344,71 @@ bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Jump-flood propagation (d_jump_propagate, kernel.cu:800-841; launcher :843-857, disabled in the reference).
+// Each pixel tries the matches of its neighbours at distance `step` (left, right, up, down), shifted by that
+// distance, in order with strict <; candidates outside the image are skipped.  Jacobi: reads nnf, writes
+// nnf_alt.  No serial chains: workgroup = 64 pixels x 4 candidates, wave k = candidate k, costs meet in
+// LDS and wave 0 replays the in-order selection.  A candidate equal to the pixel's own match is rejected
+// without evaluation (it would reproduce the stored cost).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pm_jump(PmBatch B, const float* __restrict__ lut, int R, int step)
+{
+    __shared__ PatchLut L;
+    __shared__ float s_cost[4][64];
+    __shared__ int s_cand[4][64];
+    const PmProblem& pr = B.p[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, k = tid >> 6;
+    load_patch_lut(L, lut, R, tid, 256);
+    __syncthreads();
+    const Planes P = to_dev(pr.P);
+    const int x = blockIdx.x * kBlock + (lane & 15), y = blockIdx.y * 4 + (lane >> 4);
+    const bool inimg = (x < P.w && y < P.h);
+    const int nidx = y * B.npitch + x, cidx = y * B.cpitch + x;
+    int bx = 0, by = 0;
+    float cv = FLT_MAX;
+    int cand = -1;
+    if (inimg) {
+        bx = pr.nnf[nidx * 2]; by = pr.nnf[nidx * 2 + 1];
+        const int nx = x + ((k == 0) ? -step : (k == 1) ? step : 0);
+        const int ny = y + ((k == 2) ? -step : (k == 3) ? step : 0);
+        if (nx >= 0 && nx < P.w && ny >= 0 && ny < P.h) {
+            int dx = pr.nnf[(ny * B.npitch + nx) * 2], dy = pr.nnf[(ny * B.npitch + nx) * 2 + 1];
+            if (k == 0) dx = (int)(int16_t)(dx - step);
+            else if (k == 1) dx = (int)(int16_t)(dx + step);
+            else if (k == 2) dy = (int)(int16_t)(dy - step);
+            else dy = (int)(int16_t)(dy + step);
+            if (!(dx < 0 || dy < 0 || dx >= P.w || dy >= P.h)) {
+                cand = (dx & 0xffff) | (dy << 16);
+                if (!(dx == bx && dy == by)) cv = patch_dist(P, L, R, x, y, dx, dy);
+                else cand = -1;                                   // equals the current match: never accepted
+            }
+        }
+    }
+    s_cost[k][lane] = cv;
+    s_cand[k][lane] = cand;
+    __syncthreads();
+    if (k == 0 && inimg) {
+        float best_cost = pr.cost[cidx];
+        for (int g = 0; g < 4; g++) {
+            const int e = s_cand[g][lane];
+            if (e == -1) continue;
+            const float c = s_cost[g][lane];
+            if (c < best_cost) { bx = (int)(int16_t)(e & 0xffff); by = e >> 16; best_cost = c; }
+        }
+        pr.nnf_alt[nidx * 2] = (int16_t)bx;
+        pr.nnf_alt[nidx * 2 + 1] = (int16_t)by;
+        pr.cost[cidx] = best_cost;
+    }
+}
+
+void launch_pm_jump(const PmBatch& b, const float* lut, int R, int step, hipStream_t s)
+{
+    const int w = b.p[0].P.w, h = b.p[0].P.h;
+    dim3 grid((w + kBlock - 1) / kBlock, (h + 3) / 4, b.n), block(256);
+    hipLaunchKernelGGL(k_pm_jump, grid, block, 0, s, b, lut, R, step);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Random search (kernel.cu:1519-1594): G guesses at radii search_range, /2, ... around the pre-search
 // best, evaluated in order with strict <.
 // Random numbers: the 16x16 block's XORWOW stream, 2x256 draws per guess in row-major pixel order.  One

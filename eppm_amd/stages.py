@@ -182,6 +182,13 @@ def pm_seg_propagate(cost, nnf, P, direction):
     return c.get(), n.get()
 
 
+def pm_jump_propagate(cost, nnf, P):
+    n, c = Dev(nnf), Dev(cost)
+    check(lib().eppm_pm_jump_propagate(c.ptr, n.ptr, *P.args(), P.w, P.h, _sz(P.i1.pitch), _sz(c.pitch), _sz(n.pitch), _sz(P.c1.pitch)),
+          "pm_jump_propagate")
+    return c.get(), n.get()
+
+
 def pm_random_search(rng, cost, nnf, P):
     n, c = Dev(nnf), Dev(cost)
     check(lib().eppm_pm_random_search(rng.p, c.ptr, n.ptr, *P.args(), P.w, P.h, _sz(P.i1.pitch), _sz(c.pitch), _sz(n.pitch),

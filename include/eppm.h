@@ -55,6 +55,8 @@ typedef struct {
     int seg_len;        /* PROP_SEG_LENGTH 10              bao_pmflow_kernel.cu:979 */
     int wmf_iters;      /* 20                                         driver .cpp:239 */
     unsigned long long seed; /* 1234                        bao_pmflow_kernel.cu:68 */
+    int propagation;    /* 0: segmented scan-line sweeps, baoSegPropagate (live, bao_pmflow_kernel.cu:1812)
+                           1: jump flood, baoJumpPropagate (steps 32..1, :800-857; disabled in the reference :1813) */
 } eppm_params;
 
 typedef struct eppm_ctx eppm_ctx;
@@ -184,6 +186,10 @@ int  eppm_pm_cost_field(float* d_cost, const eppm_short2* d_nnf, const eppm_ucha
 int  eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* d_img1, const eppm_uchar4* d_img2,
         const unsigned char* d_census1, const unsigned char* d_census2, int w, int h, size_t img_pitch,
         size_t cost_pitch, size_t disp_pitch, size_t census_pitch, int dir);
+/* baoJumpPropagate (bao_pmflow_kernel.cu:843-857): six Jacobi launches with step 32,16,8,4,2,1 */
+int  eppm_pm_jump_propagate(float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* d_img1, const eppm_uchar4* d_img2,
+        const unsigned char* d_census1, const unsigned char* d_census2, int w, int h, size_t img_pitch,
+        size_t cost_pitch, size_t disp_pitch, size_t census_pitch);
 int  eppm_pm_random_search(eppm_pm_rng* rng, float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* d_img1,
         const eppm_uchar4* d_img2, const unsigned char* d_census1, const unsigned char* d_census2, int w, int h,
         size_t img_pitch, size_t cost_pitch, size_t disp_pitch, size_t census_pitch);

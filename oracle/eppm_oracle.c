@@ -57,7 +57,7 @@ static inline float fmax2(float a, float b) { return a > b ? a : b; }
 void orc_default_params(orc_params* p)
 {
     p->patch_r = 9; p->num_iter = 10; p->search_range = 30; p->num_guess = 6;
-    p->seg_len = 10; p->wmf_iters = 20; p->seed = 1234ULL; p->dump_stages = 0;
+    p->seg_len = 10; p->wmf_iters = 20; p->seed = 1234ULL; p->dump_stages = 0; p->propagation = 0;
 }
 
 int orc_num_threads(void)
@@ -578,6 +578,43 @@ void orc_seg_propagate_dir(float* cost, orc_short2* nnf, const orc_uchar4* img1,
     }
 }
 
+/* d_jump_propagate + baoJumpPropagate, kernel.cu:800-857 (every call site is commented out in the reference,
+ * :1813; offered as an option because it has no serial chains).  One launch per step size 32..1: each pixel tries
+ * the matches of its four neighbours at distance step, shifted by that distance, in the order left, right, up,
+ * down with strict <; candidates outside the image are skipped.  Jacobi per launch. */
+void orc_jump_propagate(float* cost, orc_short2* nnf, const orc_uchar4* img1, const orc_uchar4* img2,
+                        const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p)
+{
+    float gs[64], cn[9];
+    orc_pm_luts(p->patch_r, gs, cn);
+    init_unorm();
+    orc_short2* in = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
+    for (int step = 32; step >= 1; step /= 2) {
+        memcpy(in, nnf, sizeof(orc_short2) * w * h);
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                orc_short2 best = in[(size_t)y * w + x];
+                float best_cost = cost[(size_t)y * w + x];
+                orc_short2 nb[4];
+                int nx, ny;
+                if ((nx = x - step) >= 0) { nb[0] = in[(size_t)y * w + nx]; nb[0].x = (int16_t)(nb[0].x - step); } else { nb[0].x = -999; nb[0].y = -999; }
+                if ((nx = x + step) < w)  { nb[1] = in[(size_t)y * w + nx]; nb[1].x = (int16_t)(nb[1].x + step); } else { nb[1].x = -999; nb[1].y = -999; }
+                if ((ny = y - step) >= 0) { nb[2] = in[(size_t)ny * w + x]; nb[2].y = (int16_t)(nb[2].y - step); } else { nb[2].x = -999; nb[2].y = -999; }
+                if ((ny = y + step) < h)  { nb[3] = in[(size_t)ny * w + x]; nb[3].y = (int16_t)(nb[3].y + step); } else { nb[3].x = -999; nb[3].y = -999; }
+                for (int k = 0; k < 4; k++) {
+                    orc_short2 d = nb[k];
+                    if (d.x < 0 || d.y < 0 || d.x >= w || d.y >= h) continue;
+                    float cv = orc_patch_dist(img1, img2, c1, c2, w, h, p->patch_r, gs, cn, x, y, d.x, d.y);
+                    if (cv < best_cost) { best = d; best_cost = cv; }
+                }
+                nnf[(size_t)y * w + x] = best;
+                cost[(size_t)y * w + x] = best_cost;
+            }
+    }
+    free(in);
+}
+
 /* :1519-1586 */
 void orc_random_search(orc_xorwow* states, float* cost, orc_short2* nnf, const orc_uchar4* img1, const orc_uchar4* img2,
                        const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p)
@@ -640,7 +677,8 @@ void orc_patchmatch(orc_short2* nnf, float* cost, const orc_uchar4* img1, const 
     orc_cost_field(cost, nnf, img1, img2, c1, c2, w, h, p);
     const int iters = (iters_done < 0) ? p->num_iter : iters_done;
     for (int it = 0; it < iters; it++) {
-        for (int dir = 0; dir < 4; dir++) orc_seg_propagate_dir(cost, nnf, img1, img2, c1, c2, w, h, p, dir);
+        if (p->propagation == 1) orc_jump_propagate(cost, nnf, img1, img2, c1, c2, w, h, p);
+        else for (int dir = 0; dir < 4; dir++) orc_seg_propagate_dir(cost, nnf, img1, img2, c1, c2, w, h, p, dir);
         orc_random_search(states, cost, nnf, img1, img2, c1, c2, w, h, p);
     }
     free(states);

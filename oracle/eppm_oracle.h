@@ -49,6 +49,7 @@ typedef struct {
     int   wmf_iters;      /* 20, driver :239 */
     unsigned long long seed; /* 1234, bao_pmflow_kernel.cu:68 */
     int   dump_stages;    /* oracle-only: keep intermediate planes */
+    int   propagation;    /* 0: baoSegPropagate (live, kernel.cu:1812); 1: baoJumpPropagate (:843-857, disabled there) */
 } orc_params;
 
 void  orc_default_params(orc_params* p);
@@ -90,6 +91,9 @@ void  orc_cost_field(float* cost, const orc_short2* nnf, const orc_uchar4* img1,
 /* dir: 0 row fwd, 1 col fwd, 2 row rev, 3 col rev (launch order of :1167-1181) */
 void  orc_seg_propagate_dir(float* cost, orc_short2* nnf, const orc_uchar4* img1, const orc_uchar4* img2,
                      const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p, int dir);
+/* baoJumpPropagate, kernel.cu:800-857: steps 32,16,8,4,2,1; Jacobi per launch */
+void  orc_jump_propagate(float* cost, orc_short2* nnf, const orc_uchar4* img1, const orc_uchar4* img2,
+                     const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p);
 void  orc_random_search(orc_xorwow* states, float* cost, orc_short2* nnf, const orc_uchar4* img1, const orc_uchar4* img2,
                      const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p);        /* :1519-1586 */
 /* iters_done: stop after that many iterations (<0 = p->num_iter); for per-iteration parity */

@@ -266,3 +266,21 @@ def test_c_class_cli_matches_library(frames, tmp_path):
     e = eppm_amd.EPPM(); e.init(a, b, 480, 640)
     u, v = e.compute_flow()
     eq(fu, u, "CLI u"); eq(fv, v, "CLI v")
+
+
+def test_jump_flood_propagation(S, O, L1, crop):
+    """Optional mode (eppm_params.propagation = 1): the reference's baoJumpPropagate (disabled there, kernel.cu:1813)."""
+    i1, i2, c1, c2 = L1
+    h, w = i1.shape
+    P = S.PlaneSet(i1, i2, c1, c2)
+    onnf, _ = O.gen_rand_field(w, h)
+    ocost = O.cost_field(onnf, i1, i2, c1, c2)
+    cost, nnf = S.pm_jump_propagate(ocost, onnf, P)
+    oc, on = O.jump_propagate(ocost, onnf, i1, i2, c1, c2)
+    eq(nnf, on, "NNF after jump flood"); eq(cost, oc, "cost after jump flood")
+    cost, nnf = S.pm_jump_propagate(cost, nnf, P)              # second round: many candidates equal the own match
+    oc, on = O.jump_propagate(oc, on, i1, i2, c1, c2)
+    eq(nnf, on, "NNF after 2nd jump flood"); eq(cost, oc, "cost after 2nd jump flood")
+    a, b = crop
+    u, v, ou, ov = _run_both(a, b, propagation=1)
+    eq(u, ou, "u jump flood"); eq(v, ov, "v jump flood")

@@ -313,6 +313,8 @@ extern "C" int eppm_create(eppm_ctx** out, int h, int w, int device, const eppm_
     if (!out) return set_err(EPPM_ERR_ARG, "eppm_create: NULL out");
     *out = nullptr;
     if (h < 4 || w < 4 || h > 32767 || w > 32767) return set_err(EPPM_ERR_ARG, "eppm_create: size %dx%d out of range (NNF coordinates are int16)", w, h);
+    if ((unsigned long long)h * (unsigned long long)w * 16ULL >= (1ULL << 32))
+        return set_err(EPPM_ERR_ARG, "eppm_create: size %dx%d out of range (texel planes are addressed with 32-bit byte offsets)", w, h);
     eppm_params p;
     eppm_default_params(&p);
     if (params) p = *params;

@@ -101,7 +101,10 @@ class EPPM:
 
     def plane(self, name, level):
         self._need()
-        h, w = self.level_dims()[level]
+        dims = self.level_dims()
+        if name not in _PLANE_DTYPES or not 0 <= level < len(dims):
+            raise EppmError(f"plane({name!r}, {level}): unknown plane or level")
+        h, w = dims[level]
         a = np.empty((h, w), _PLANE_DTYPES[name])
         check(lib().eppm_get_plane(self._ctx, name.encode(), level, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes)),
               "eppm_get_plane")

@@ -284,3 +284,52 @@ def test_jump_flood_propagation(S, O, L1, crop):
     a, b = crop
     u, v, ou, ov = _run_both(a, b, propagation=1)
     eq(u, ou, "u jump flood"); eq(v, ov, "v jump flood")
+
+
+def test_device_entry_points_and_streams(crop, crop_stages):
+    """eppm_set_images_device / eppm_compute_device (inputs resident in HBM, any pitch) give the same flow as the
+    host-pointer entry points; contexts on separate streams can be in flight together."""
+    import ctypes as C
+    import eppm_amd
+    from eppm_amd import stages as S
+    from oracle import oracle as O
+    a, b = crop
+    h, w = 120, 160
+    st = crop_stages
+    for pitched in (False, True):
+        d1, d2 = S.Dev(O.rgb2rgba(a), pitched=pitched), S.Dev(O.rgb2rgba(b), pitched=pitched)
+        out = S.Dev(shape=(h, w), dtype=eppm_amd.api.float2)
+        engs = [eppm_amd.EPPM() for _ in range(3)]
+        for e in engs:
+            e.init(h, w)
+        for e in engs:                                   # three pairs in flight, one stream each
+            e.set_data_device(d1.ptr.value, d2.ptr.value, d1.pitch)
+            e.compute_flow_device(out.ptr.value if e is engs[0] else None)
+        for e in engs:
+            e.synchronize()
+        f0 = out.get()
+        eq(f0["x"].copy(), st["u"], "device entry u"); eq(f0["y"].copy(), st["v"], "device entry v")
+        for e in engs[1:]:
+            f = e.plane("flow", 0)
+            eq(f["x"].copy(), st["u"], "in-flight context u"); eq(f["y"].copy(), st["v"], "in-flight context v")
+
+
+def test_error_paths_on_gpu():
+    import ctypes as C
+    import eppm_amd
+    L = eppm_amd.lib()
+    e = eppm_amd.EPPM()
+    e.init(64, 64)
+    with pytest.raises(eppm_amd.EppmError):
+        e.compute_flow()                                  # no images yet: EPPM_ERR_STATE
+    with pytest.raises(eppm_amd.EppmError):
+        e.set_data(np.zeros((10, 10, 3), np.uint8), np.zeros((10, 10, 3), np.uint8))
+    with pytest.raises(eppm_amd.EppmError):
+        e.plane("flow", 7)
+    ctx = C.c_void_p()
+    assert L.eppm_create(C.byref(ctx), 64, 64, 99, None) == 2    # no such device: EPPM_ERR_HIP, no exit()
+    e.init(32, 48)                                        # re-init releases the old buffers (the reference leaks them)
+    z = np.zeros((32, 48, 3), np.uint8)
+    e.set_data(z, z)
+    u, v = e.compute_flow()
+    assert u.shape == (32, 48) and np.isfinite(u).all()

@@ -33,10 +33,14 @@ static int set_err(int code, const char* fmt, ...)
     va_end(ap);
     return code;
 }
+// a failed HIP call leaves a sticky "last error"; it is consumed here so that it cannot surface in a later, unrelated call
 #define HIPCHK(expr)                                                                                         \
     do {                                                                                                     \
         hipError_t e_ = (expr);                                                                              \
-        if (e_ != hipSuccess) return set_err(EPPM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        if (e_ != hipSuccess) {                                                                              \
+            (void)hipGetLastError();                                                                         \
+            return set_err(EPPM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        }                                                                                                    \
     } while (0)
 #define CHK(expr)                     \
     do {                              \

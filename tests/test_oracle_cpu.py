@@ -221,3 +221,14 @@ def test_pyr_dims_match_reference_code():
         ah, aw = (C.c_int * 8)(), (C.c_int * 8)()
         n = R.refio_pyr_init_dim(ah, aw, h, w, 3, C.c_float(0.5))
         assert (list(ah)[:n], list(aw)[:n]) == O.pyr_init_dim(h, w)
+
+
+def test_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """Whole oracle path (both propagation modes) under ASan + UBSan on the CPU."""
+    exe = str(tmp_path / "orc_san")
+    subprocess.check_call(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-ffp-contract=off",
+                           "-mavx2", "-mfma", "-I", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "csrc", "oracle_sanitize_driver.c"),
+                           os.path.join(ROOT, "oracle", "eppm_oracle.c"), "-o", exe, "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("ok")

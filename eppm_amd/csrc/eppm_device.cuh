@@ -89,10 +89,40 @@ struct Planes {
     int pitch;              // pixels
 };
 
+// The census byte is stored with every bit replicated four times (bit k -> bits 4k..4k+3), so that
+// popcount(w1 ^ w2) = 4 * Hamming distance = the byte offset into the cn[] table: one instruction less per sample.
+__device__ __forceinline__ uint32_t spread_census(uint32_t c)
+{
+    uint32_t x = c & 0xffu;
+    x = (x | (x << 12)) & 0x000f000fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return x * 15u;
+}
 __device__ __forceinline__ float4 make_texel(uint32_t rgba, uint32_t census)
 {
     const rgbf c = unpack_rgb(rgba);
-    return make_float4(c.x, c.y, c.z, __uint_as_float(census));
+    return make_float4(c.x, c.y, c.z, __uint_as_float(spread_census(census)));
+}
+// cn[] entry for two texels' census words (see spread_census)
+__device__ __forceinline__ float census_cost(const float* __restrict__ cn, uint32_t w1, uint32_t w2)
+{
+    const unsigned off = (unsigned)__builtin_popcount(w1 ^ w2);          // 4 * Hamming distance
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cn) + off);
+}
+// 1 - fast_exp(x) without the flush test: below the cut-off the exponential is < 2^-125, and 1 - tiny rounds to
+// exactly 1.0f, which is what the flushed form gives
+__device__ __forceinline__ float one_minus_fast_exp(float x)
+{
+    const float y = x * 0x1.715476p+0f;
+    const float n = __builtin_rintf(y);
+    const float f = y - n;
+    float p = __builtin_fmaf(0x1.5bba14p-10f, f, 0x1.3cea88p-7f);
+    p = __builtin_fmaf(p, f, 0x1.c6b752p-5f);
+    p = __builtin_fmaf(p, f, 0x1.ebf9bcp-3f);
+    p = __builtin_fmaf(p, f, 0x1.62e42ap-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return 1 - __builtin_ldexpf(p, (int)n);
 }
 __device__ __forceinline__ rgbf texel_rgb(const float4 t) { return rgbf{t.x, t.y, t.z}; }
 
@@ -129,10 +159,9 @@ __device__ __forceinline__ void patch_terms(const float4 q1, const float4 q2, co
 {
     const rgbf p1 = texel_rgb(q1);
     const rgbf p2 = texel_rgb(q2);
-    const int hamming = __builtin_popcount(__float_as_uint(q1.w) ^ __float_as_uint(q2.w));
     float cost = max_abs_diff(p1, p2);
-    cost = 1 - fast_exp(div_ad2(-(cost * cost)));
-    cost += cn[hamming];
+    cost = one_minus_fast_exp(div_ad2(-(cost * cost)));
+    cost += census_cost(cn, __float_as_uint(q1.w), __float_as_uint(q2.w));
     float weight = max_abs_diff(c1, p1);
     weight *= weight;
     float temp = max_abs_diff(c2, p2);

@@ -153,10 +153,9 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, con
 #pragma unroll
             for (int n = 0; n < 3; n++) {
                 const rgbf p2 = texel_rgb(q2[n]);
-                const int hamming = __builtin_popcount(k1 ^ __float_as_uint(q2[n].w));
                 float cost = max_abs_diff(p1, p2);
-                cost = 1 - fast_exp(div_ad2(-(cost * cost)));
-                cost += L.cn[hamming];
+                cost = one_minus_fast_exp(div_ad2(-(cost * cost)));
+                cost += census_cost(L.cn, k1, __float_as_uint(q2[n].w));
                 float temp = max_abs_diff(c2[n], p2);
                 temp *= temp;
                 float weight = fast_exp(div_ad2(-(a2 + temp)));

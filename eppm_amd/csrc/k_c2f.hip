@@ -116,6 +116,7 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, con
     };
     float cs[3] = {0.0f, 0.0f, 0.0f}, ws[3] = {0.0f, 0.0f, 0.0f};
     const float uu = (float)(cx - x);
+    const float wmax = (float)(P.w - 1), hmax = (float)(P.h - 1);
     float vv[3];
 #pragma unroll
     for (int n = 0; n < 3; n++) vv[n] = (float)(ccy + n - 1 - y);
@@ -138,13 +139,14 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, con
 #pragma unroll
                 for (int n = 0; n < 3; n++) Yoff[n] = __umul24((unsigned)iclamp(ccy + n - 1 + i, 0, P.h - 1), pitch16);
             } else {
+                // floor, clamp to the image in the float domain (v_med3_f32: exact, the values are integers), convert
                 const float cx1 = (float)(x + j), cy1 = (float)(y + i);
                 const float cx2 = cx1 + uu + (float)(j)*kc[PASS][0] + (float)(i)*kc[PASS][1];
-                Xb = (unsigned)iclamp((int)floorf(cx2), 0, P.w - 1) << 4;
+                Xb = (unsigned)(int)__builtin_amdgcn_fmed3f(floorf(cx2), 0.0f, wmax) << 4;
 #pragma unroll
                 for (int n = 0; n < 3; n++) {
                     const float cy2 = cy1 + vv[n] + (float)(j)*kc[PASS][2] + (float)(i)*kc[PASS][3];
-                    Yoff[n] = __umul24((unsigned)iclamp((int)floorf(cy2), 0, P.h - 1), pitch16);
+                    Yoff[n] = __umul24((unsigned)(int)__builtin_amdgcn_fmed3f(floorf(cy2), 0.0f, hmax), pitch16);
                 }
             }
             float4 q2[3];                                 // the three gathers are issued back to back, then consumed

@@ -333,3 +333,31 @@ def test_error_paths_on_gpu():
     e.set_data(z, z)
     u, v = e.compute_flow()
     assert u.shape == (32, 48) and np.isfinite(u).all()
+
+
+def test_contexts_on_host_threads(crop, crop_stages):
+    """One context per host thread (SURVEY 8b threading contract): four threads, each its own context, same answer."""
+    import threading
+    import eppm_amd
+    a, b = crop
+    st = crop_stages
+    results, errors = [None] * 4, []
+
+    def work(i):
+        try:
+            e = eppm_amd.EPPM()
+            e.init(120, 160)
+            for _ in range(3):
+                e.set_data(a, b)
+                results[i] = e.compute_flow()
+        except Exception as ex:       # noqa: BLE001
+            errors.append(ex)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for u, v in results:
+        eq(u, st["u"], "thread u"); eq(v, st["v"], "thread v")

@@ -35,6 +35,10 @@ REFINE_BYTES_PER_PX = 26
 # passes committed under profiles/r01_f_pmc_{fetch,write}_size.csv: FETCH_SIZE 3597.2 / 11442.3 KB (x2: gfx950 tallies
 # the 128-B requests of 16-B-per-lane loads at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE 872.0 / 3488.0 KB
 TRAFFIC_BYTES_1024x436 = ((2 * 3597.2 + 872.0) + (2 * 11442.3 + 3488.0)) / 2 * 1024
+# The kernel is bound by vector-ALU issue, not by HBM: SQ_INSTS_VALU per launch (wave64 instructions) from
+# profiles/r01_f_pmc_valu.csv, level-1 / level-0 launch; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 op
+VALU_INSTS_1024x436 = (3.655e8 + 1.449e9) / 2
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
 
 
 def main():
@@ -173,6 +177,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": args.traffic_bytes if args.traffic_bytes is not None else (TRAFFIC_BYTES_1024x436 if (w, h, args.patch_r) == (W, H, 9) else None),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms},
+            "valu_roofline": ({"kernel": "k_c2f_refine_tiled", "wave64_valu_insts_per_launch": VALU_INSTS_1024x436,
+                               "achieved_insts_per_s": VALU_INSTS_1024x436 / (dom_ms * 1e-3), "peak_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
+                               "frac": VALU_INSTS_1024x436 / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S}
+                              if (w, h, args.patch_r) == (W, H, 9) else None),
             "latency_ms_per_pair": latency_ms,
             "stage_ms": stage_ms,
             "epe_vs_synthetic_gt": epe_gt,

@@ -1,4 +1,5 @@
-"""One-off randomized parity sweep: random sizes / parameters / image statistics, HIP vs oracle, bit-exact."""
+"""Randomized parity sweep (run by hand on a GPU box: python tests/fuzz_parity.py SEED N): random sizes, parameters and
+image statistics, HIP vs oracle, bit-exact.  Lives under tests/ because it uses the oracle (test infrastructure)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

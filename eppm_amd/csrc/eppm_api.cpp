@@ -373,7 +373,7 @@ static int prepare_one(eppm_ctx* c, uint32_t** pyr, uint8_t** cen, void** pk, ui
     launch_gauss_rgba(pyr[0], raw, p0, c->H[0], c->W[0], .5f, 2, s);                    // refine :1063-1064
     const float ratio = 0.5f;                                                             // PYR_RATIO
     const float baseSigma = (1 / ratio - 1);
-    const int n = (int)(log(0.25) / (double)logf(ratio));   // C++ float overload in the reference: n = 1, see oracle note
+    const int n = (int)(log(0.25) / (double)logf(ratio));   // C++ float overload in the reference: n = 1
     const float nSigma = baseSigma * n;
     for (int i = 1; i < c->nl; i++) {
         if (i <= n) {
@@ -855,7 +855,7 @@ extern "C" void baoCudaPatchMatchMultiscalePrepare(eppm_uchar4** pImgPyr1, eppm_
     hipStream_t s = g_stream;
     const float ratio = 0.5f;
     const float baseSigma = (1 / ratio - 1);
-    const int n = (int)(log(0.25) / (double)logf(ratio));   // C++ float overload in the reference: n = 1, see oracle note
+    const int n = (int)(log(0.25) / (double)logf(ratio));   // C++ float overload in the reference: n = 1
     const float nSigma = baseSigma * n;
     for (int k = 0; k < 2; k++) {
         uint32_t** pyr = (uint32_t**)(k ? pImgPyr2 : pImgPyr1);

@@ -361,3 +361,27 @@ def test_contexts_on_host_threads(crop, crop_stages):
     assert not errors, errors
     for u, v in results:
         eq(u, st["u"], "thread u"); eq(v, st["v"], "thread v")
+
+
+def test_no_device_memory_leak_over_create_destroy(crop):
+    """init/destroy cycles and repeated set_data/compute_flow leave the free device memory where it was
+    (the reference leaks its buffers when init is called twice, driver .cpp:112-157)."""
+    import torch
+    import eppm_amd
+    a, b = crop
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+    e = eppm_amd.EPPM(); e.init(a, b, 120, 160); e.compute_flow(); e.close()      # warm up allocator pools
+    before = free_bytes()
+    for _ in range(25):
+        e = eppm_amd.EPPM()
+        e.init(120, 160)
+        e.enable_stage_timing(True)
+        for _ in range(2):
+            e.set_data(a, b)
+            e.compute_flow()
+        e.init(96, 128)                       # re-init on a live object
+        e.close()
+    after = free_bytes()
+    assert abs(before - after) < 8 << 20, (before, after)

@@ -46,15 +46,15 @@ __device__ __forceinline__ float fast_exp(float x)
 // ---- x / c for a compile-time constant c, correctly rounded in 3 operations --------------------
 // q0 = x*rc; r = fma(-c,q0,x); q = fma(r,rc,q0).  Equal to the IEEE quotient for every x this path
 // produces; verified exhaustively on the CPU by tests/csrc/verify_divconst.c.
-template <typename T = void>
 __device__ __forceinline__ float div_const(float x, float c, float rc)
 {
     const float q0 = x * rc;
     const float r = __builtin_fmaf(-c, q0, x);
     return __builtin_fmaf(r, rc, q0);
 }
-__device__ __forceinline__ float div_ad2(float x) { return div_const(x, kLambdaAd2, 1.0f / kLambdaAd2); }
-__device__ __forceinline__ float div_wmf2(float x) { return div_const(x, kWmfSigR2, 1.0f / kWmfSigR2); }
+static_assert(kPmSigR2 == kLambdaAd2 && kBlfSigR2 == kWmfSigR2, "one helper per distinct constant");
+__device__ __forceinline__ float div_ad2(float x) { return div_const(x, kLambdaAd2, 1.0f / kLambdaAd2); }   // also PM_SIG_R^2
+__device__ __forceinline__ float div_wmf2(float x) { return div_const(x, kWmfSigR2, 1.0f / kWmfSigR2); }    // also POSTPROC_BLF_SIG_R^2
 
 // unorm8 -> float exactly as c/255.0f (cudaReadModeNormalizedFloat)
 __device__ __forceinline__ float unorm8(float c) { return div_const(c, 255.0f, 1.0f / 255.0f); }

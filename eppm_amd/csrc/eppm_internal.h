@@ -75,7 +75,6 @@ int16_t* launch_wmf(int16_t* buf_a, int16_t* buf_b, const uint32_t* img, int ipi
 void launch_fill_holes(int16_t* nnf_out, const int16_t* nnf_in, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
                        hipStream_t s);
 void launch_nnf2flow(float* flow, int flow_pitch, const int16_t* nnf, int nnf_pitch, int w, int h, hipStream_t s);
-void launch_copy2d(void* dst, size_t dpitch_bytes, const void* src, size_t spitch_bytes, size_t width_bytes, size_t rows, hipStream_t s);
 
 // ---- coarse to fine (k_c2f.hip) ----
 void launch_resize_flow(float* out, int outH, int outW, const float* in, int h, int w, float ratio, float post_scale, hipStream_t s);

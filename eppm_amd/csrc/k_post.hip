@@ -290,9 +290,4 @@ void launch_nnf2flow(float* flow, int flow_pitch, const int16_t* nnf, int nnf_pi
     hipLaunchKernelGGL(k_nnf2flow, grid, block, 0, s, flow, flow_pitch, nnf, nnf_pitch, w, h);
 }
 
-void launch_copy2d(void* dst, size_t dpitch_bytes, const void* src, size_t spitch_bytes, size_t width_bytes, size_t rows, hipStream_t s)
-{
-    (void)hipMemcpy2DAsync(dst, dpitch_bytes, src, spitch_bytes, width_bytes, rows, hipMemcpyDeviceToDevice, s);
-}
-
 }  // namespace eppm

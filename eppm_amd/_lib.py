@@ -11,7 +11,8 @@ class EppmError(RuntimeError):
 
 class CParams(C.Structure):
     _fields_ = [("patch_r", C.c_int), ("num_iter", C.c_int), ("search_range", C.c_int), ("num_guess", C.c_int),
-                ("seg_len", C.c_int), ("wmf_iters", C.c_int), ("seed", C.c_ulonglong), ("propagation", C.c_int)]
+                ("seg_len", C.c_int), ("wmf_iters", C.c_int), ("seed", C.c_ulonglong), ("propagation", C.c_int),
+                ("levels", C.c_int)]
 
 
 _lib = None
@@ -23,12 +24,12 @@ SYMBOLS = [
     "eppm_stage_times", "eppm_clear_stage_times", "eppm_enable_stage_timing", "eppm_last_error", "eppm_version",
     "eppm_device_count", "eppm_set_device", "eppm_malloc_device", "eppm_malloc_pitched", "eppm_free_device",
     "eppm_memcpy_h2d", "eppm_memcpy_d2h", "eppm_memcpy2d_h2d", "eppm_memcpy2d_d2h", "eppm_memset_device",
-    "eppm_device_synchronize", "eppm_set_launcher_stream", "eppm_set_launcher_params", "eppm_launcher_status",
+    "eppm_device_synchronize", "eppm_device_mem_info", "eppm_set_launcher_stream", "eppm_set_launcher_params", "eppm_launcher_status",
     "baoCudaPatchMatchMultiscalePrepare", "baoCudaCensusTransform", "baoCudaPatchMatch", "baoCudaLeftRightCheck",
     "baoCudaOutlierRemoval", "baoCudaWeightedMedianFilter", "baoCudaFillHole", "baoCudaNNF2Flow", "baoCudaBLF_C2F",
     "baoCudaBLFCostFilterRefine", "baoCudaFlowSmoothing",
     "eppm_pm_rng_create", "eppm_pm_rng_reset", "eppm_pm_rng_destroy", "eppm_pm_rng_block_states", "eppm_pm_gen_rand_field",
-    "eppm_pm_cost_field", "eppm_pm_seg_propagate", "eppm_pm_jump_propagate", "eppm_pm_random_search", "eppm_gauss_filter_rgba", "eppm_resize_rgba",
+    "eppm_pm_cost_field", "eppm_pm_seg_propagate", "eppm_pm_jump_propagate", "eppm_pm_parallel_propagate", "eppm_pm_random_search", "eppm_gauss_filter_rgba", "eppm_resize_rgba",
     "eppm_resize_flow", "eppm_probe_fast_exp", "eppm_probe_div_const",
     "eppm_load_ppm", "eppm_ppm_size", "eppm_save_flo", "eppm_load_flo", "eppm_flo_size", "eppm_flow_error",
 ]

@@ -14,7 +14,7 @@ _PLANE_DTYPES = {"img1": uchar4, "img2": uchar4, "census1": np.uint8, "census2":
 
 
 def Params(**kw):
-    """Tunables with the defaults of defs.h:31-76 (patch_r, num_iter, search_range, num_guess, seg_len, wmf_iters, seed, propagation: 0 segmented sweeps / 1 jump flood)."""
+    """Tunables with the defaults of defs.h:31-76 (patch_r, num_iter, search_range, num_guess, seg_len, wmf_iters, seed, propagation: 0 segmented sweeps / 1 jump flood / 2 4-neighbour, levels: pyramid depth)."""
     p = CParams()
     check(lib().eppm_default_params(C.byref(p)), "eppm_default_params")
     for k, v in kw.items():

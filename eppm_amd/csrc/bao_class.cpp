@@ -9,11 +9,35 @@
 #include "../../include/eppm.h"
 
 bao_flow_patchmatch_multiscale_cuda::bao_flow_patchmatch_multiscale_cuda()
-    : m_h(0), m_w(0), m_device(0), m_ctx(NULL), m_stage(NULL), m_u(NULL), m_v(NULL)
+    : m_h(0), m_w(0), m_device(0), m_ctx(NULL), m_params(NULL), m_stage(NULL), m_u(NULL), m_v(NULL)
 {
+    eppm_params* p = (eppm_params*)malloc(sizeof(eppm_params));
+    if (p) eppm_default_params(p);
+    m_params = p;
 }
 
-bao_flow_patchmatch_multiscale_cuda::~bao_flow_patchmatch_multiscale_cuda() { _destroy(); }
+bao_flow_patchmatch_multiscale_cuda::~bao_flow_patchmatch_multiscale_cuda()
+{
+    _destroy();
+    free(m_params);
+}
+
+bool bao_flow_patchmatch_multiscale_cuda::set_option(const char* name, long long value)
+{
+    eppm_params* p = (eppm_params*)m_params;
+    if (!p || !name) return false;
+    if (!strcmp(name, "patch_r")) p->patch_r = (int)value;
+    else if (!strcmp(name, "num_iter")) p->num_iter = (int)value;
+    else if (!strcmp(name, "search_range")) p->search_range = (int)value;
+    else if (!strcmp(name, "num_guess")) p->num_guess = (int)value;
+    else if (!strcmp(name, "seg_len")) p->seg_len = (int)value;
+    else if (!strcmp(name, "wmf_iters")) p->wmf_iters = (int)value;
+    else if (!strcmp(name, "seed")) p->seed = (unsigned long long)value;
+    else if (!strcmp(name, "propagation")) p->propagation = (int)value;
+    else if (!strcmp(name, "levels")) p->levels = (int)value;
+    else return false;
+    return true;
+}
 
 void bao_flow_patchmatch_multiscale_cuda::_destroy()
 {
@@ -35,7 +59,7 @@ void bao_flow_patchmatch_multiscale_cuda::init(int h, int w)
 {
     _destroy();
     m_h = h; m_w = w;
-    if (eppm_create(&m_ctx, h, w, m_device, NULL) != EPPM_OK) {
+    if (eppm_create(&m_ctx, h, w, m_device, (const eppm_params*)m_params) != EPPM_OK) {
         fprintf(stderr, "bao_flow_patchmatch_multiscale_cuda::init: %s\n", eppm_last_error());
         m_ctx = NULL;
         return;
@@ -65,10 +89,13 @@ bool bao_flow_patchmatch_multiscale_cuda::set_data(unsigned char*** img1, unsign
 }
 
 // Middlebury colour wheel (3rdparty/middlebury/colorcode.cpp:30-78, also basic/bao_basic_cuda.cuh:751-829)
-static int g_ncols = 0;
-static int g_wheel[60][3];
-static void setcols(int r, int g, int b, int k) { g_wheel[k][0] = r; g_wheel[k][1] = g; g_wheel[k][2] = b; }
-static void make_wheel()
+struct Wheel {
+    int ncols;
+    int c[60][3];
+    Wheel();
+    void setcols(int r, int g, int b, int k) { c[k][0] = r; c[k][1] = g; c[k][2] = b; }
+};
+Wheel::Wheel()
 {
     const int RY = 15, YG = 6, GC = 4, CB = 11, BM = 13, MR = 6;
     int k = 0;
@@ -78,11 +105,13 @@ static void make_wheel()
     for (int i = 0; i < CB; i++) setcols(0, 255 - 255 * i / CB, 255, k++);
     for (int i = 0; i < BM; i++) setcols(255 * i / BM, 0, 255, k++);
     for (int i = 0; i < MR; i++) setcols(255, 0, 255 - 255 * i / MR, k++);
-    g_ncols = k;
+    ncols = k;
 }
 static void flow_color(float fx, float fy, unsigned char* pix)
 {
-    if (g_ncols == 0) make_wheel();
+    static const Wheel wheel;          // built once, thread-safe (contexts may run on several host threads)
+    const int g_ncols = wheel.ncols;
+    const int (*g_wheel)[3] = wheel.c;
     const float rad = sqrtf(fx * fx + fy * fy);
     const float a = atan2f(-fy, -fx) / (float)M_PI;
     const float fk = (a + 1.0f) / 2.0f * (g_ncols - 1);

@@ -55,7 +55,7 @@ extern "C" int eppm_default_params(eppm_params* p)
 {
     if (!p) return set_err(EPPM_ERR_ARG, "eppm_default_params: NULL");
     p->patch_r = 9; p->num_iter = 10; p->search_range = 30; p->num_guess = 6;
-    p->seg_len = 10; p->wmf_iters = 20; p->seed = 1234ULL; p->propagation = 0;
+    p->seg_len = 10; p->wmf_iters = 20; p->seed = 1234ULL; p->propagation = 0; p->levels = kNumLevels;
     return EPPM_OK;
 }
 
@@ -66,7 +66,8 @@ static int check_params(const eppm_params& p)
     if (p.num_guess < 1 || p.num_guess > 8) return set_err(EPPM_ERR_ARG, "num_guess %d out of range [1,8]", p.num_guess);
     if (p.seg_len < 2) return set_err(EPPM_ERR_ARG, "seg_len %d < 2", p.seg_len);
     if (p.search_range < 1) return set_err(EPPM_ERR_ARG, "search_range %d < 1", p.search_range);
-    if (p.propagation != 0 && p.propagation != 1) return set_err(EPPM_ERR_ARG, "propagation %d: 0 (segmented sweeps) or 1 (jump flood)", p.propagation);
+    if (p.levels < 1 || p.levels > kMaxLevels) return set_err(EPPM_ERR_ARG, "levels %d out of range [1,%d]", p.levels, kMaxLevels);
+    if (p.propagation < 0 || p.propagation > 2) return set_err(EPPM_ERR_ARG, "propagation %d: 0 (segmented sweeps), 1 (jump flood) or 2 (4-neighbour)", p.propagation);
     return EPPM_OK;
 }
 
@@ -178,8 +179,6 @@ static void rng_free(eppm_pm_rng* r)
 // ---------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------
-static const int kMaxLevels = 8;
-static const int kNumLevels = 3;   // PYR_MAX_DEPTH, defs.h:31
 
 struct StageEv { const char* name; hipEvent_t a, b; };
 
@@ -326,7 +325,7 @@ extern "C" int eppm_create(eppm_ctx** out, int h, int w, int device, const eppm_
     HIPCHK(hipSetDevice(device));
     eppm_ctx* c = new eppm_ctx();
     c->device = device; c->prm = p; c->h = h; c->w = w;
-    c->nl = pyr_init_dim(c->H, c->W, h, w, kNumLevels, 0.5f);
+    c->nl = pyr_init_dim(c->H, c->W, h, w, p.levels, 0.5f);
     const int L = c->nl - 1;
     if (c->H[L] < 1 || c->W[L] < 1 || (c->W[L] + p.seg_len - 1) / p.seg_len > 1024 || (c->H[L] + p.seg_len - 1) / p.seg_len > 1024) {
         delete c;
@@ -466,6 +465,15 @@ static void jump(PmBatch& b, const float* lut, const eppm_params& prm, hipStream
         for (int k = 0; k < b.n; k++) std::swap(b.p[k].nnf, b.p[k].nnf_alt);
     }
 }
+// baoParallelPropagate (kernel.cu:790-795): `launches` Jacobi launches; the disabled call site runs ten per
+// iteration (:1804-1809)
+static void neighbor(PmBatch& b, const float* lut, const eppm_params& prm, int launches, hipStream_t s)
+{
+    for (int q = 0; q < launches; q++) {
+        launch_pm_neighbor(b, lut, prm.patch_r, s);
+        for (int k = 0; k < b.n; k++) std::swap(b.p[k].nnf, b.p[k].nnf_alt);
+    }
+}
 // returns with the NNF of problem k in b.p[k].nnf (an even number of sweeps: the caller's buffer)
 static void run_patchmatch(PmBatch& b, eppm_pm_rng* rng, const float* lut, const eppm_params& prm, hipStream_t s)
 {
@@ -473,6 +481,7 @@ static void run_patchmatch(PmBatch& b, eppm_pm_rng* rng, const float* lut, const
     launch_pm_cost_field(b, lut, prm.patch_r, s);
     for (int it = 0; it < prm.num_iter; it++) {
         if (prm.propagation == 1) jump(b, lut, prm, s);
+        else if (prm.propagation == 2) neighbor(b, lut, prm, 10, s);
         else for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s);
         search(b, rng, lut, prm, s);
     }
@@ -612,6 +621,14 @@ extern "C" int eppm_memcpy2d_h2d(void* d, size_t dp, const void* s, size_t sp, s
 extern "C" int eppm_memcpy2d_d2h(void* d, size_t dp, const void* s, size_t sp, size_t wb, size_t rows) { HIPCHK(hipMemcpy2D(d, dp, s, sp, wb, rows, hipMemcpyDeviceToHost)); return EPPM_OK; }
 extern "C" int eppm_memset_device(void* p, int v, size_t n) { HIPCHK(hipMemset(p, v, n)); return EPPM_OK; }
 extern "C" int eppm_device_synchronize(void) { HIPCHK(hipDeviceSynchronize()); return EPPM_OK; }
+extern "C" int eppm_device_mem_info(size_t* free_bytes, size_t* total_bytes)
+{
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return EPPM_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // state of the context-less, reference-signature launchers (the reference keeps the equivalent in
@@ -783,6 +800,22 @@ extern "C" int eppm_pm_jump_propagate(float* d_cost, eppm_short2* d_nnf, const e
     CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
     b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0);
     jump(b, ds->lut_pm, g_prm, g_stream);
+    if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
+    return finish();
+}
+extern "C" int eppm_pm_parallel_propagate(float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* i1, const eppm_uchar4* i2,
+                                          const unsigned char* c1, const unsigned char* c2, int w, int h, size_t img_pitch,
+                                          size_t cost_pitch, size_t disp_pitch, size_t census_pitch)
+{
+    LAUNCHER_BEGIN_INT;
+    void* tmp = nullptr;
+    CHK(get_scratch(ds, disp_pitch * h, &tmp));
+    PmBatch b;
+    b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
+    PlanesH P;
+    CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0);
+    neighbor(b, ds->lut_pm, g_prm, 1, g_stream);
     if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
     return finish();
 }

@@ -11,6 +11,8 @@
 namespace eppm {
 
 // geometry constants shared by host and device code
+constexpr int kMaxLevels = 8;
+constexpr int kNumLevels = 3;        // PYR_MAX_DEPTH, defs.h:31
 constexpr int kBlock = 16;       // BLOCK_DIM_X/Y, bao_pmflow_kernel.cu:42-43
 constexpr int kMaxS = 32;        // samples per patch row: patch_r + 1 <= 32
 constexpr int kWmfRadius = 4;    // defs.h:58
@@ -63,6 +65,8 @@ void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t
 bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s);
 // one jump-flood launch (step = neighbour distance); reads nnf, writes nnf_alt (caller swaps)
 void launch_pm_jump(const PmBatch& b, const float* lut, int R, int step, hipStream_t s);
+// one 4-neighbour propagation launch (d_neighbor_propagate); reads nnf, writes nnf_alt (caller swaps)
+void launch_pm_neighbor(const PmBatch& b, const float* lut, int R, hipStream_t s);
 void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float* lut, int R, int search_range, int num_guess,
                              hipStream_t s);
 

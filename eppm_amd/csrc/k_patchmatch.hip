@@ -350,7 +350,12 @@ bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int
 // nnf_alt.  No serial chains: workgroup = 64 pixels x 4 candidates, wave k = candidate k, costs meet in
 // LDS and wave 0 replays the in-order selection.  A candidate equal to the pixel's own match is rejected
 // without evaluation (it would reproduce the stored cost).
+//
+// NEIGHBOR = true is d_neighbor_propagate (kernel.cu:720-787; ten launches per iteration at the disabled call
+// site :1804-1809): distance 1, order upper, lower, left, right, the neighbour's match is copied UNSHIFTED
+// and unchecked, and a neighbour outside the image is the clamped border pixel.
 // ---------------------------------------------------------------------------------------------------
+template <bool NEIGHBOR>
 __global__ __launch_bounds__(256) void k_pm_jump(PmBatch B, const float* __restrict__ lut, int R, int step)
 {
     __shared__ PatchLut L;
@@ -369,9 +374,18 @@ __global__ __launch_bounds__(256) void k_pm_jump(PmBatch B, const float* __restr
     int cand = -1;
     if (inimg) {
         bx = pr.nnf[nidx * 2]; by = pr.nnf[nidx * 2 + 1];
+        if (NEIGHBOR) {
+            const int nx = iclamp(x + ((k == 2) ? -1 : (k == 3) ? 1 : 0), 0, P.w - 1);
+            const int ny = iclamp(y + ((k == 0) ? -1 : (k == 1) ? 1 : 0), 0, P.h - 1);
+            const int dx = pr.nnf[(ny * B.npitch + nx) * 2], dy = pr.nnf[(ny * B.npitch + nx) * 2 + 1];
+            if (!(dx == bx && dy == by)) {
+                cand = (dx & 0xffff) | (dy << 16);
+                cv = patch_dist(P, L, R, x, y, dx, dy);
+            }
+        }
         const int nx = x + ((k == 0) ? -step : (k == 1) ? step : 0);
         const int ny = y + ((k == 2) ? -step : (k == 3) ? step : 0);
-        if (nx >= 0 && nx < P.w && ny >= 0 && ny < P.h) {
+        if (!NEIGHBOR && nx >= 0 && nx < P.w && ny >= 0 && ny < P.h) {
             int dx = pr.nnf[(ny * B.npitch + nx) * 2], dy = pr.nnf[(ny * B.npitch + nx) * 2 + 1];
             if (k == 0) dx = (int)(int16_t)(dx - step);
             else if (k == 1) dx = (int)(int16_t)(dx + step);
@@ -405,7 +419,14 @@ void launch_pm_jump(const PmBatch& b, const float* lut, int R, int step, hipStre
 {
     const int w = b.p[0].P.w, h = b.p[0].P.h;
     dim3 grid((w + kBlock - 1) / kBlock, (h + 3) / 4, b.n), block(256);
-    hipLaunchKernelGGL(k_pm_jump, grid, block, 0, s, b, lut, R, step);
+    hipLaunchKernelGGL(k_pm_jump<false>, grid, block, 0, s, b, lut, R, step);
+}
+
+void launch_pm_neighbor(const PmBatch& b, const float* lut, int R, hipStream_t s)
+{
+    const int w = b.p[0].P.w, h = b.p[0].P.h;
+    dim3 grid((w + kBlock - 1) / kBlock, (h + 3) / 4, b.n), block(256);
+    hipLaunchKernelGGL(k_pm_jump<true>, grid, block, 0, s, b, lut, R, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------

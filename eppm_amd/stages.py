@@ -189,6 +189,14 @@ def pm_jump_propagate(cost, nnf, P):
     return c.get(), n.get()
 
 
+def pm_parallel_propagate(cost, nnf, P):
+    """One launch of the 4-neighbour propagation (baoParallelPropagate, bao_pmflow_kernel.cu:720-795)."""
+    n, c = Dev(nnf), Dev(cost)
+    check(lib().eppm_pm_parallel_propagate(c.ptr, n.ptr, *P.args(), P.w, P.h, _sz(P.i1.pitch), _sz(c.pitch), _sz(n.pitch),
+                                           _sz(P.c1.pitch)), "pm_parallel_propagate")
+    return c.get(), n.get()
+
+
 def pm_random_search(rng, cost, nnf, P):
     n, c = Dev(nnf), Dev(cost)
     check(lib().eppm_pm_random_search(rng.p, c.ptr, n.ptr, *P.args(), P.w, P.h, _sz(P.i1.pitch), _sz(c.pitch), _sz(n.pitch),

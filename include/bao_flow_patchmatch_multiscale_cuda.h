@@ -31,8 +31,12 @@ public:
     bool set_data(unsigned char***img1,unsigned char***img2); //always true in the reference (driver .cpp:159-168); false here only on error
     void compute_flow(float**disp1_x,float**disp1_y,unsigned char***color_flow=NULL);
 
-    // additions (not in the reference): device selection before init(), access to the C handle
+    // additions (not in the reference): device selection and run-time values of the defs.h constants, both
+    // before init(); access to the C handle
     void set_device(int device) { m_device = device; }
+    // name = a field of eppm_params (include/eppm.h): "patch_r", "num_iter", "search_range", "num_guess",
+    // "seg_len", "wmf_iters", "seed", "propagation", "levels".  false: unknown name.
+    bool set_option(const char* name, long long value);
     eppm_ctx* handle() const { return m_ctx; }
 
 private:
@@ -43,6 +47,7 @@ private:
     int m_w;
     int m_device;
     eppm_ctx* m_ctx;
+    void* m_params;           // eppm_params*
     unsigned char* m_stage;   // contiguous RGB staging for the row-pointer inputs
     float* m_u;
     float* m_v;

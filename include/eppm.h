@@ -56,7 +56,9 @@ typedef struct {
     int wmf_iters;      /* 20                                         driver .cpp:239 */
     unsigned long long seed; /* 1234                        bao_pmflow_kernel.cu:68 */
     int propagation;    /* 0: segmented scan-line sweeps, baoSegPropagate (live, bao_pmflow_kernel.cu:1812)
-                           1: jump flood, baoJumpPropagate (steps 32..1, :800-857; disabled in the reference :1813) */
+                           1: jump flood, baoJumpPropagate (steps 32..1, :800-857; disabled in the reference :1813)
+                           2: 4-neighbour propagation, 10x baoParallelPropagate (:720-795; disabled at :1804-1809) */
+    int levels;         /* PYR_MAX_DEPTH 3 (1..8): pyramid depth; PatchMatch runs at level levels-1   defs.h:31 */
 } eppm_params;
 
 typedef struct eppm_ctx eppm_ctx;
@@ -118,6 +120,8 @@ int  eppm_memcpy2d_h2d(void* dst, size_t dpitch, const void* src, size_t spitch,
 int  eppm_memcpy2d_d2h(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows);
 int  eppm_memset_device(void* p, int value, size_t bytes);
 int  eppm_device_synchronize(void);
+/* free / total memory of the current device (sizing the number of contexts in flight; leak checks) */
+int  eppm_device_mem_info(size_t* free_bytes, size_t* total_bytes);
 /* Stream used by the reference-signature launchers below (default: the null stream). */
 int  eppm_set_launcher_stream(void* hip_stream);
 /* Parameters used by the reference-signature launchers (default: defs.h values). */
@@ -188,6 +192,10 @@ int  eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const eppm_uchar4*
         size_t cost_pitch, size_t disp_pitch, size_t census_pitch, int dir);
 /* baoJumpPropagate (bao_pmflow_kernel.cu:843-857): six Jacobi launches with step 32,16,8,4,2,1 */
 int  eppm_pm_jump_propagate(float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* d_img1, const eppm_uchar4* d_img2,
+        const unsigned char* d_census1, const unsigned char* d_census2, int w, int h, size_t img_pitch,
+        size_t cost_pitch, size_t disp_pitch, size_t census_pitch);
+/* baoParallelPropagate (bao_pmflow_kernel.cu:720-795): ONE Jacobi launch of the 4-neighbour propagation */
+int  eppm_pm_parallel_propagate(float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* d_img1, const eppm_uchar4* d_img2,
         const unsigned char* d_census1, const unsigned char* d_census2, int w, int h, size_t img_pitch,
         size_t cost_pitch, size_t disp_pitch, size_t census_pitch);
 int  eppm_pm_random_search(eppm_pm_rng* rng, float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* d_img1,

@@ -57,7 +57,7 @@ static inline float fmax2(float a, float b) { return a > b ? a : b; }
 void orc_default_params(orc_params* p)
 {
     p->patch_r = 9; p->num_iter = 10; p->search_range = 30; p->num_guess = 6;
-    p->seg_len = 10; p->wmf_iters = 20; p->seed = 1234ULL; p->dump_stages = 0; p->propagation = 0;
+    p->seg_len = 10; p->wmf_iters = 20; p->seed = 1234ULL; p->dump_stages = 0; p->propagation = 0; p->levels = 3;
 }
 
 int orc_num_threads(void)
@@ -615,6 +615,38 @@ void orc_jump_propagate(float* cost, orc_short2* nnf, const orc_uchar4* img1, co
     free(in);
 }
 
+/* d_neighbor_propagate + baoParallelPropagate, kernel.cu:720-795 (disabled there: ten launches per iteration,
+ * :1804-1809).  Each pixel tries the matches of its upper, lower, left, right neighbours UNSHIFTED (the
+ * absolute target is copied, :777-782), in that order with strict <.  Neighbours outside the image are the
+ * clamped border pixel (:735-765).  The original loads the rim only from threads on the edge of a full
+ * 16x16 block, so in a partial block the right/lower neighbour of the last image column/row is unloaded
+ * shared memory; the defined behaviour here is the clamped image neighbour everywhere.  Jacobi per launch. */
+void orc_parallel_propagate(float* cost, orc_short2* nnf, const orc_uchar4* img1, const orc_uchar4* img2,
+                            const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p)
+{
+    float gs[64], cn[9];
+    orc_pm_luts(p->patch_r, gs, cn);
+    init_unorm();
+    orc_short2* in = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
+    memcpy(in, nnf, sizeof(orc_short2) * w * h);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            orc_short2 best = in[(size_t)y * w + x];
+            float best_cost = cost[(size_t)y * w + x];
+            const int uy = y > 0 ? y - 1 : 0, ly = y < h - 1 ? y + 1 : h - 1;
+            const int lx = x > 0 ? x - 1 : 0, rx = x < w - 1 ? x + 1 : w - 1;
+            const orc_short2 nb[4] = { in[(size_t)uy * w + x], in[(size_t)ly * w + x], in[(size_t)y * w + lx], in[(size_t)y * w + rx] };
+            for (int k = 0; k < 4; k++) {
+                float cv = orc_patch_dist(img1, img2, c1, c2, w, h, p->patch_r, gs, cn, x, y, nb[k].x, nb[k].y);
+                if (cv < best_cost) { best = nb[k]; best_cost = cv; }
+            }
+            nnf[(size_t)y * w + x] = best;
+            cost[(size_t)y * w + x] = best_cost;
+        }
+    free(in);
+}
+
 /* :1519-1586 */
 void orc_random_search(orc_xorwow* states, float* cost, orc_short2* nnf, const orc_uchar4* img1, const orc_uchar4* img2,
                        const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p)
@@ -678,6 +710,7 @@ void orc_patchmatch(orc_short2* nnf, float* cost, const orc_uchar4* img1, const 
     const int iters = (iters_done < 0) ? p->num_iter : iters_done;
     for (int it = 0; it < iters; it++) {
         if (p->propagation == 1) orc_jump_propagate(cost, nnf, img1, img2, c1, c2, w, h, p);
+        else if (p->propagation == 2) for (int q = 0; q < 10; q++) orc_parallel_propagate(cost, nnf, img1, img2, c1, c2, w, h, p);
         else for (int dir = 0; dir < 4; dir++) orc_seg_propagate_dir(cost, nnf, img1, img2, c1, c2, w, h, p, dir);
         orc_random_search(states, cost, nnf, img1, img2, c1, c2, w, h, p);
     }
@@ -970,7 +1003,7 @@ static void* dup_mem(const void* p, size_t n) { void* q = malloc(n); memcpy(q, p
 int orc_compute_flow(const uint8_t* rgb1, const uint8_t* rgb2, int h, int w, const orc_params* p,
                      float* u, float* v, orc_dump* dump)
 {
-    const int NL = 3;                                  /* PYR_MAX_DEPTH, defs.h:31 */
+    const int NL = (p->levels >= 1 && p->levels <= 8) ? p->levels : 3;   /* PYR_MAX_DEPTH, defs.h:31 */
     int arrH[8], arrW[8];
     orc_pyr_init_dim(arrH, arrW, h, w, NL, PYR_RATIO); /* driver :116 */
     orc_uchar4 *raw1 = malloc(sizeof(orc_uchar4) * h * w), *raw2 = malloc(sizeof(orc_uchar4) * h * w);
@@ -1032,7 +1065,7 @@ int orc_compute_flow(const uint8_t* rgb1, const uint8_t* rgb2, int h, int w, con
         /* driver :281: WMF on m_disp_vec1_pyramid[l] is dead work, no effect on the flow */
     }
     orc_flow_smoothing(flow[0], img1[0], arrW[0], arrH[0]);                            /* driver :289 */
-    if (dump) dump->flow[0] = dup_mem(flow[0], sizeof(orc_float2) * h * w);
+    if (dump) { free(dump->flow[0]); dump->flow[0] = dup_mem(flow[0], sizeof(orc_float2) * h * w); }   /* levels == 1: replaces the pre-smoothing copy */
     for (size_t i = 0; i < (size_t)h * w; i++) { u[i] = flow[0][i].x; v[i] = flow[0][i].y; }  /* driver :302-306 */
 
     free(nnf1); free(nnf2); free(cost1); free(cost2);

@@ -49,7 +49,8 @@ typedef struct {
     int   wmf_iters;      /* 20, driver :239 */
     unsigned long long seed; /* 1234, bao_pmflow_kernel.cu:68 */
     int   dump_stages;    /* oracle-only: keep intermediate planes */
-    int   propagation;    /* 0: baoSegPropagate (live, kernel.cu:1812); 1: baoJumpPropagate (:843-857, disabled there) */
+    int   propagation;    /* 0: baoSegPropagate (live, kernel.cu:1812); 1: baoJumpPropagate (:843-857, disabled there); 2: 10x baoParallelPropagate (:790-795, disabled at :1804-1809) */
+    int   levels;         /* PYR_MAX_DEPTH 3        defs.h:31; 1..8, PatchMatch runs at level levels-1 */
 } orc_params;
 
 void  orc_default_params(orc_params* p);
@@ -93,6 +94,9 @@ void  orc_seg_propagate_dir(float* cost, orc_short2* nnf, const orc_uchar4* img1
                      const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p, int dir);
 /* baoJumpPropagate, kernel.cu:800-857: steps 32,16,8,4,2,1; Jacobi per launch */
 void  orc_jump_propagate(float* cost, orc_short2* nnf, const orc_uchar4* img1, const orc_uchar4* img2,
+                     const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p);
+/* baoParallelPropagate, kernel.cu:720-795: one launch (the disabled call site runs ten per iteration, :1804-1809) */
+void  orc_parallel_propagate(float* cost, orc_short2* nnf, const orc_uchar4* img1, const orc_uchar4* img2,
                      const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p);
 void  orc_random_search(orc_xorwow* states, float* cost, orc_short2* nnf, const orc_uchar4* img1, const orc_uchar4* img2,
                      const uint8_t* c1, const uint8_t* c2, int w, int h, const orc_params* p);        /* :1519-1586 */

@@ -22,7 +22,7 @@ float2 = np.dtype([("x", "f4"), ("y", "f4")])
 class Params(C.Structure):
     _fields_ = [("patch_r", C.c_int), ("num_iter", C.c_int), ("search_range", C.c_int), ("num_guess", C.c_int),
                 ("seg_len", C.c_int), ("wmf_iters", C.c_int), ("seed", C.c_ulonglong), ("dump_stages", C.c_int),
-                ("propagation", C.c_int)]
+                ("propagation", C.c_int), ("levels", C.c_int)]
 
 
 class Xorwow(C.Structure):
@@ -218,6 +218,14 @@ def jump_propagate(cost, nnf, img1, img2, c1, c2, params=None):
     cost = np.ascontiguousarray(cost).copy()
     nnf = np.ascontiguousarray(nnf).copy()
     lib().orc_jump_propagate(_p(cost), _p(nnf), *_planes(img1, img2, c1, c2), C.byref(params))
+    return cost, nnf
+
+
+def parallel_propagate(cost, nnf, img1, img2, c1, c2, params=None):
+    params = params or default_params()
+    cost = np.ascontiguousarray(cost).copy()
+    nnf = np.ascontiguousarray(nnf).copy()
+    lib().orc_parallel_propagate(_p(cost), _p(nnf), *_planes(img1, img2, c1, c2), C.byref(params))
     return cost, nnf
 
 

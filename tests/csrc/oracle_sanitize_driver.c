@@ -18,12 +18,21 @@ int main(void)
     float* u = malloc(sizeof(float) * h * w);
     float* v = malloc(sizeof(float) * h * w);
     orc_params p;
-    for (int mode = 0; mode < 2; mode++) {
+    for (int mode = 0; mode < 3; mode++) {
         orc_default_params(&p);
         p.propagation = mode;
         p.num_iter = 3;
         orc_dump d;
         if (orc_compute_flow(a, b, h, w, &p, u, v, &d) != 0) return 2;
+        orc_free_dump(&d);
+    }
+    for (int levels = 1; levels <= 4; levels++) {          /* PYR_MAX_DEPTH as a run-time parameter */
+        orc_default_params(&p);
+        p.levels = levels;
+        p.num_iter = 2;
+        orc_dump d;
+        if (orc_compute_flow(a, b, h, w, &p, u, v, &d) != 0) return 3;
+        if (d.n_levels != levels) return 4;
         orc_free_dump(&d);
     }
     double su = 0;

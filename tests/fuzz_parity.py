@@ -25,7 +25,7 @@ for t in range(n):
         a = base; b = np.roll(base, 3, axis=1)
     params = dict(patch_r=int(rng.choice([9, 9, 9, 17, 5, 4])), num_iter=int(rng.integers(1, 5)), num_guess=int(rng.integers(1, 9)),
                   seg_len=int(rng.integers(2, 14)), wmf_iters=int(rng.integers(0, 6)), search_range=int(rng.integers(1, 40)),
-                  seed=int(rng.integers(1, 1 << 40)), propagation=int(rng.integers(0, 2)))
+                  seed=int(rng.integers(1, 1 << 40)), propagation=int(rng.integers(0, 3)), levels=int(rng.integers(1, 5)))
     e = eppm_amd.EPPM(params=eppm_amd.Params(**params))
     e.init(a, b, h, w)
     u, v = e.compute_flow()

@@ -52,7 +52,7 @@ def test_argument_errors_without_gpu():
 
 def test_default_params_are_defs_h():
     p = eppm_amd.Params()
-    assert (p.patch_r, p.num_iter, p.search_range, p.num_guess, p.seg_len, p.wmf_iters, p.seed, p.propagation) == (9, 10, 30, 6, 10, 20, 1234, 0)
+    assert (p.patch_r, p.num_iter, p.search_range, p.num_guess, p.seg_len, p.wmf_iters, p.seed, p.propagation, p.levels) == (9, 10, 30, 6, 10, 20, 1234, 0, 3)
 
 
 def test_flo_roundtrip_and_header(tmp_path):

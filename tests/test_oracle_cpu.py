@@ -224,7 +224,7 @@ def test_pyr_dims_match_reference_code():
 
 
 def test_oracle_under_address_and_ub_sanitizers(tmp_path):
-    """Whole oracle path (both propagation modes) under ASan + UBSan on the CPU."""
+    """Whole oracle path (all three propagation modes) under ASan + UBSan on the CPU."""
     exe = str(tmp_path / "orc_san")
     subprocess.check_call(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-ffp-contract=off",
                            "-mavx2", "-mfma", "-I", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "csrc", "oracle_sanitize_driver.c"),
@@ -232,3 +232,28 @@ def test_oracle_under_address_and_ub_sanitizers(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.startswith("ok")
+
+
+def test_parallel_propagate_rule():
+    """d_neighbor_propagate (kernel.cu:720-787): the four neighbours' matches are tried unshifted in the order
+    upper, lower, left, right with strict <; outside the image the neighbour is the clamped border pixel; Jacobi."""
+    rng = np.random.default_rng(5)
+    h, w = 12, 14
+    rgb1 = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    rgb2 = np.roll(rgb1, 1, axis=1)
+    i1, i2 = O.rgb2rgba(rgb1), O.rgb2rgba(rgb2)
+    c1, c2 = O.census(i1), O.census(i2)
+    nnf = np.zeros((h, w, 2), np.int16)
+    nnf[..., 0] = rng.integers(0, w + 1, (h, w)); nnf[..., 1] = rng.integers(0, h + 1, (h, w))
+    cost = O.cost_field(nnf, i1, i2, c1, c2)
+    oc, on = O.parallel_propagate(cost, nnf, i1, i2, c1, c2)
+    for y in range(h):
+        for x in range(w):
+            best, bc = nnf[y, x].copy(), cost[y, x]
+            for ny, nx in ((max(y - 1, 0), x), (min(y + 1, h - 1), x), (y, max(x - 1, 0)), (y, min(x + 1, w - 1))):
+                d = nnf[ny, nx]
+                cv = O.patch_dist(i1, i2, c1, c2, x, y, int(d[0]), int(d[1]))
+                if cv < bc:
+                    best, bc = d.copy(), cv
+            assert (on[y, x] == best).all() and oc[y, x] == bc, (x, y)
+    assert (oc <= cost).all()

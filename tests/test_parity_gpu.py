@@ -268,6 +268,29 @@ def test_c_class_cli_matches_library(frames, tmp_path):
     eq(fu, u, "CLI u"); eq(fv, v, "CLI v")
 
 
+def test_cli_options(frames, tmp_path):
+    """runeppm --levels/--patch-r/--iters/--propagation/--seed reach the engine (same .flo as the library with those
+    parameters); --size runs a synthetic translated pair and recovers the translation; --pairs/--gpus stream pairs."""
+    import os, re, subprocess
+    import eppm_amd
+    from conftest import GOLDEN
+    exe = os.path.join(os.path.dirname(eppm_amd.lib_path()), "runeppm")
+    out = str(tmp_path / "f.flo")
+    txt = subprocess.check_output([exe, "--levels", "2", "--patch-r", "5", "--iters", "2", "--propagation", "1", "--seed", "77", "--pairs", "2",
+                                   os.path.join(GOLDEN, "frame10.ppm"), os.path.join(GOLDEN, "frame11.ppm"), out], text=True)
+    assert "Mflow-vectors/s" in txt
+    fu, fv = eppm_amd.io.load_flo(out)
+    a, b = frames
+    e = eppm_amd.EPPM(params=eppm_amd.Params(levels=2, patch_r=5, num_iter=2, propagation=1, seed=77)); e.init(a, b, 480, 640)
+    u, v = e.compute_flow()
+    eq(fu, u, "CLI u with options"); eq(fv, v, "CLI v with options")
+    txt = subprocess.check_output([exe, "--size", "320x200", "--pairs", "3", "--out", out], text=True)
+    m = re.search(r"EPE ([0-9.]+) px", txt)
+    assert m and float(m.group(1)) < 0.5, txt
+    assert subprocess.run([exe, "--levels"], capture_output=True).returncode == 2
+    assert subprocess.run([exe, "--levels", "99", "--size", "64x64"], capture_output=True).returncode == 1
+
+
 def test_jump_flood_propagation(S, O, L1, crop):
     """Optional mode (eppm_params.propagation = 1): the reference's baoJumpPropagate (disabled there, kernel.cu:1813)."""
     i1, i2, c1, c2 = L1
@@ -284,6 +307,38 @@ def test_jump_flood_propagation(S, O, L1, crop):
     a, b = crop
     u, v, ou, ov = _run_both(a, b, propagation=1)
     eq(u, ou, "u jump flood"); eq(v, ov, "v jump flood")
+
+
+def test_four_neighbour_propagation(S, O, L1, crop):
+    """Optional mode (eppm_params.propagation = 2): the reference's baoParallelPropagate, ten launches per iteration
+    (disabled there, kernel.cu:1804-1809)."""
+    i1, i2, c1, c2 = L1
+    h, w = i1.shape
+    P = S.PlaneSet(i1, i2, c1, c2)
+    onnf, _ = O.gen_rand_field(w, h)
+    ocost = O.cost_field(onnf, i1, i2, c1, c2)
+    cost, nnf, oc, on = ocost, onnf, ocost, onnf
+    for launch in range(3):                                     # later launches: many candidates equal the own match
+        cost, nnf = S.pm_parallel_propagate(cost, nnf, P)
+        oc, on = O.parallel_propagate(oc, on, i1, i2, c1, c2)
+        eq(nnf, on, "NNF after 4-neighbour launch %d" % launch); eq(cost, oc, "cost after 4-neighbour launch %d" % launch)
+    a, b = crop
+    u, v, ou, ov = _run_both(a, b, propagation=2)
+    eq(u, ou, "u 4-neighbour"); eq(v, ov, "v 4-neighbour")
+
+
+@pytest.mark.parametrize("levels", [1, 2, 4])
+def test_pyramid_depth(crop, levels):
+    """PYR_MAX_DEPTH (defs.h:31) as a run-time parameter: PatchMatch at level levels-1, levels-1 C2F steps.
+    levels = 1 is the single-scale run of BASELINE.json's first configuration."""
+    import eppm_amd
+    a, b = crop
+    u, v, ou, ov = _run_both(a, b, levels=levels, num_iter=3)
+    eq(u, ou, "u levels=%d" % levels); eq(v, ov, "v levels=%d" % levels)
+    e = eppm_amd.EPPM(params=eppm_amd.Params(levels=levels)); e.init(120, 160)
+    assert len(e.level_dims()) == levels
+    with pytest.raises(eppm_amd.EppmError):
+        eppm_amd.EPPM(params=eppm_amd.Params(levels=9)).init(120, 160)
 
 
 def test_device_entry_points_and_streams(crop, crop_stages):
@@ -366,12 +421,15 @@ def test_contexts_on_host_threads(crop, crop_stages):
 def test_no_device_memory_leak_over_create_destroy(crop):
     """init/destroy cycles and repeated set_data/compute_flow leave the free device memory where it was
     (the reference leaks its buffers when init is called twice, driver .cpp:112-157)."""
-    import torch
+    import ctypes as C
     import eppm_amd
+    from eppm_amd._lib import lib, check
     a, b = crop
     def free_bytes():
-        torch.cuda.synchronize()
-        return torch.cuda.mem_get_info()[0]
+        f, t = C.c_size_t(), C.c_size_t()
+        check(lib().eppm_device_synchronize(), "sync")
+        check(lib().eppm_device_mem_info(C.byref(f), C.byref(t)), "mem_info")
+        return f.value
     e = eppm_amd.EPPM(); e.init(a, b, 120, 160); e.compute_flow(); e.close()      # warm up allocator pools
     before = free_bytes()
     for _ in range(25):

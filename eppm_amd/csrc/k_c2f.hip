@@ -102,30 +102,72 @@ __global__ __launch_bounds__(256) void k_c2f_refine(PlanesH Ph, float* __restric
 // gather each (rgb + census).  The passes run 4th to 1st so the reference's nested
 // __min(c1,__min(c2,__min(c3,c4))) becomes a running select with the same NaN behaviour.
 // ---------------------------------------------------------------------------------------------------
-template <int R, int PASS>
-__device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, const float4* __restrict__ s_src, int TW, int tx, int ty,
-                                         int x, int y, int cx, int ccy, const rgbf c1, const rgbf (&c2)[3], float (&run)[3])
+// Affine passes: the target of sample (i,j) is floor(((x+j + uu) + j*A) + i*B) in float (kernel.cu:334-513).
+// x+j+uu = cx+j is an integer M, and for every M an image can produce the float sum rounds so that
+//   floor(...) = M + floor(fl(fl(j*A) + fl(i*B)))
+// (checked exhaustively for -R <= M < 32764 by tests/test_oracle_cpu.py::test_planefit_offsets; the launcher
+// falls back to the generic kernel beyond that).  So the warp of a pass is a table of integer offsets
+// (dx, dy) per sample, built once per workgroup in LDS, and the per-sample float coordinate arithmetic of the
+// reference becomes one integer add.  Along a sample row dy takes at most two consecutive values: the four
+// clamped row offsets a row can need are formed once per row and a per-sample flag picks three of them.
+struct C2fOff { int dx, up; };       // dx = j + x-offset; up = 1 if this sample's dy is the row minimum + 1
+
+template <int R>
+struct C2fTables {
+    static constexpr int S = R + 1;
+    C2fOff off[3][S * S];             // passes 1..3
+    int rowdy[3][S];                  // i + min over the row of the y-offset
+};
+
+template <int R>
+__device__ __forceinline__ void c2f_build_tables(C2fTables<R>& T, int tid)
 {
-    // candidates (cx, ccy-1), (cx, ccy), (cx, ccy+1): one x offset m, the three y offsets n
     constexpr int S = R + 1;
-    constexpr float kc[4][4] = {
-        {0.0f, 0.0f, 0.0f, 0.0f},
+    constexpr float kc[3][4] = {
         {0.177f, -0.011f, -0.003f, 0.301f},
         {0.125f, -0.357f, 0.009f, 0.308f},
         {0.205f, 0.370f, 0.011f, 0.296f},
     };
+    for (int t = tid; t < 3 * S * S; t += 256) {
+        const int p = t / (S * S), ii = (t % (S * S)) / S, jj = t % S;
+        const int i = 2 * ii - R, j = 2 * jj - R;
+        const float fx = (float)(j)*kc[p][0] + (float)(i)*kc[p][1];
+        const float fy = (float)(j)*kc[p][2] + (float)(i)*kc[p][3];
+        T.off[p][ii * S + jj].dx = j + (int)floorf(fx);
+        T.off[p][ii * S + jj].up = i + (int)floorf(fy);       // dy for now
+    }
+    __syncthreads();
+    for (int t = tid; t < 3 * S; t += 256) {
+        const int p = t / S, ii = t % S;
+        int lo = T.off[p][ii * S].up;
+        for (int jj = 1; jj < S; jj++) lo = min(lo, T.off[p][ii * S + jj].up);
+        T.rowdy[p][ii] = lo;
+    }
+    __syncthreads();
+    for (int t = tid; t < 3 * S * S; t += 256) {
+        const int p = t / (S * S), ii = (t % (S * S)) / S;
+        T.off[p][t % (S * S)].up -= T.rowdy[p][ii];           // 0 or 1
+    }
+}
+
+template <int R, int PASS>
+__device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, const C2fTables<R>& T, const float4* __restrict__ s_src,
+                                         int TW, int tx, int ty, int cx, int ccy, const rgbf c1, const rgbf (&c2)[3], float (&run)[3])
+{
+    // candidates (cx, ccy-1), (cx, ccy), (cx, ccy+1): one x offset m, the three y offsets n
+    constexpr int S = R + 1;
     float cs[3] = {0.0f, 0.0f, 0.0f}, ws[3] = {0.0f, 0.0f, 0.0f};
-    const float uu = (float)(cx - x);
-    const float wmax = (float)(P.w - 1), hmax = (float)(P.h - 1);
-    float vv[3];
-#pragma unroll
-    for (int n = 0; n < 3; n++) vv[n] = (float)(ccy + n - 1 - y);
+    const unsigned pitch16 = (unsigned)P.pitch << 4;
 #pragma unroll 1
     for (int ii = 0; ii < S; ii++) {
         const int i = 2 * ii - R;
+        // clamped row offsets of the targets: rows ccy-1+dy .. ccy+1+dy (+1 more where dy steps inside the row)
+        unsigned Rr[4];
+        const int rb = ccy - 1 + ((PASS == 0) ? i : T.rowdy[PASS == 0 ? 0 : PASS - 1][ii]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) Rr[k] = __umul24((unsigned)iclamp(rb + k, 0, P.h - 1), pitch16);
 #pragma unroll 2
         for (int jj = 0; jj < S; jj++) {
-            const int j = 2 * jj - R;
             const float4 q1 = s_src[(ty + 2 * ii) * TW + tx + 2 * jj];
             const rgbf p1 = texel_rgb(q1);
             const uint32_t k1 = __float_as_uint(q1.w);
@@ -133,21 +175,15 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, con
             a2 *= a2;
             const float gsp = L.gsp[ii * S + jj];
             unsigned Xb, Yoff[3];                         // byte offsets: column and clamped rows of the three targets
-            const unsigned pitch16 = (unsigned)P.pitch << 4;
             if (PASS == 0) {
-                Xb = (unsigned)iclamp(cx + j, 0, P.w - 1) << 4;        // cx1 + uu: integers, exact in float
+                Xb = (unsigned)iclamp(cx + 2 * jj - R, 0, P.w - 1) << 4;
 #pragma unroll
-                for (int n = 0; n < 3; n++) Yoff[n] = __umul24((unsigned)iclamp(ccy + n - 1 + i, 0, P.h - 1), pitch16);
+                for (int n = 0; n < 3; n++) Yoff[n] = Rr[n];
             } else {
-                // floor, clamp to the image in the float domain (v_med3_f32: exact, the values are integers), convert
-                const float cx1 = (float)(x + j), cy1 = (float)(y + i);
-                const float cx2 = cx1 + uu + (float)(j)*kc[PASS][0] + (float)(i)*kc[PASS][1];
-                Xb = (unsigned)(int)__builtin_amdgcn_fmed3f(floorf(cx2), 0.0f, wmax) << 4;
+                const C2fOff e = T.off[PASS == 0 ? 0 : PASS - 1][ii * S + jj];
+                Xb = (unsigned)iclamp(cx + e.dx, 0, P.w - 1) << 4;
 #pragma unroll
-                for (int n = 0; n < 3; n++) {
-                    const float cy2 = cy1 + vv[n] + (float)(j)*kc[PASS][2] + (float)(i)*kc[PASS][3];
-                    Yoff[n] = __umul24((unsigned)(int)__builtin_amdgcn_fmed3f(floorf(cy2), 0.0f, hmax), pitch16);
-                }
+                for (int n = 0; n < 3; n++) Yoff[n] = e.up ? Rr[n + 1] : Rr[n];
             }
             float4 q2[3];                                 // the three gathers are issued back to back, then consumed
 #pragma unroll
@@ -184,9 +220,11 @@ __global__ __launch_bounds__(256) void k_c2f_refine_tiled(PlanesH Ph, float* __r
     // halves fall on disjoint banks (34-texel rows cost a 2-way conflict on about every read)
     constexpr int TW = (TWU + 15) / 16 * 16;
     __shared__ PatchLut L;
+    __shared__ C2fTables<R> T;
     __shared__ float4 s_src[TWU * TW];
     const int tid = threadIdx.y * kBlock + threadIdx.x;
     load_patch_lut(L, lut, R, tid, 256);
+    c2f_build_tables<R>(T, tid);
     const Planes P = to_dev(Ph);
     // XCD-aware tile order: workgroups are dealt round robin over the 8 XCDs (b % 8), each with its own L2.
     // Give XCD k the k-th contiguous eighth of the row-major tile list so that neighbouring tiles -- which
@@ -223,10 +261,10 @@ __global__ __launch_bounds__(256) void k_c2f_refine_tiled(PlanesH Ph, float* __r
 #pragma unroll
         for (int n = 0; n < 3; n++) c2[n] = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, cx, ccy + n - 1));
         float run[3];
-        c2f_pass<R, 3>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, cx, ccy, c1, c2, run);
-        c2f_pass<R, 2>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, cx, ccy, c1, c2, run);
-        c2f_pass<R, 1>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, cx, ccy, c1, c2, run);
-        c2f_pass<R, 0>(P, L, s_src, TW, threadIdx.x, threadIdx.y, x, y, cx, ccy, c1, c2, run);
+        c2f_pass<R, 3>(P, L, T, s_src, TW, threadIdx.x, threadIdx.y, cx, ccy, c1, c2, run);
+        c2f_pass<R, 2>(P, L, T, s_src, TW, threadIdx.x, threadIdx.y, cx, ccy, c1, c2, run);
+        c2f_pass<R, 1>(P, L, T, s_src, TW, threadIdx.x, threadIdx.y, cx, ccy, c1, c2, run);
+        c2f_pass<R, 0>(P, L, T, s_src, TW, threadIdx.x, threadIdx.y, cx, ccy, c1, c2, run);
 #pragma unroll
         for (int n = 0; n < 3; n++) {
             const int cy = (int)(int16_t)(ccy + n - 1);
@@ -244,8 +282,9 @@ void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, h
     dim3 grid((P.w + kBlock - 1) / kBlock, (P.h + kBlock - 1) / kBlock), block(kBlock, kBlock);
     const int tiles = grid.x * grid.y;
     dim3 grid1(((tiles + 7) / 8) * 8);           // 1-D, padded so every XCD gets the same number of slots
-    if (R == 9) hipLaunchKernelGGL((k_c2f_refine_tiled<9>), grid1, block, 0, s, P, flow, lut);
-    else if (R == 17) hipLaunchKernelGGL((k_c2f_refine_tiled<17>), grid1, block, 0, s, P, flow, lut);
+    const bool table_ok = (P.w + R < 32764) && (P.h + R < 32764);     // range of the offset-table identity (c2f_pass)
+    if (R == 9 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<9>), grid1, block, 0, s, P, flow, lut);
+    else if (R == 17 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<17>), grid1, block, 0, s, P, flow, lut);
     else hipLaunchKernelGGL(k_c2f_refine, grid, block, 0, s, P, flow, lut, R);
 }
 

@@ -257,3 +257,26 @@ def test_parallel_propagate_rule():
                     best, bc = d.copy(), cv
             assert (on[y, x] == best).all() and oc[y, x] == bc, (x, y)
     assert (oc <= cost).all()
+
+
+def test_planefit_offsets():
+    """The affine passes of the plane-fitting cost (kernel.cu:334-513) sample image 2 at
+    floor(((x+j + uu) + j*A) + i*B) in float.  x+j+uu is an integer M; the HIP refine kernel (k_c2f.hip, c2f_pass)
+    relies on floor(...) == M + floor(fl(fl(j*A) + fl(i*B))) for every M an image can produce, and on the y offset
+    taking at most two consecutive values along a sample row.  Exhaustive over M for both instantiated radii."""
+    f = np.float32
+    kc = [(0.177, -0.011, -0.003, 0.301), (0.125, -0.357, 0.009, 0.308), (0.205, 0.370, 0.011, 0.296)]
+    for R in (9, 17):
+        M = np.arange(-R, 32764, dtype=np.float32)      # the launcher requires w + R < 32764, h + R < 32764
+        for (A, B, C, D) in kc:
+            for a, b in ((A, B), (C, D)):
+                for i in range(-R, R + 1, 2):
+                    row = []
+                    for j in range(-R, R + 1, 2):
+                        ja, ib = f(j) * f(a), f(i) * f(b)
+                        t = ((M + ja).astype(np.float32) + ib).astype(np.float32)
+                        off = int(np.floor(f(ja + ib)))
+                        assert np.array_equal(np.floor(t), M + f(off)), (R, a, b, i, j)
+                        row.append(off)
+                    if (a, b) == (C, D):
+                        assert max(row) - min(row) <= 1, (R, i, row)

@@ -183,13 +183,16 @@ __device__ __forceinline__ void patch_sample(const Planes& P, const rgbf c1, con
 }
 
 // LUTs staged in LDS by every patch kernel: gsp[i*S + j] = gs[|2j-R|]*gs[|2i-R|], cn[0..8]
-struct PatchLut {
-    float gsp[kMaxS * kMaxS];
+template <int MAXS>
+struct PatchLutT {
+    float gsp[MAXS * MAXS];
     float cn[9];
 };
+using PatchLut = PatchLutT<kMaxS>;     // any radius the ABI accepts; kernels instantiated per radius use PatchLutT<R + 1>
 
 // lut_src layout in global memory: gs[0..R] then cn[0..8]
-__device__ __forceinline__ void load_patch_lut(PatchLut& L, const float* __restrict__ lut_src, int R, int tid, int nthreads)
+template <int MAXS>
+__device__ __forceinline__ void load_patch_lut(PatchLutT<MAXS>& L, const float* __restrict__ lut_src, int R, int tid, int nthreads)
 {
     const int S = R + 1;
     for (int t = tid; t < S * S; t += nthreads) {

@@ -6,6 +6,12 @@
 
 namespace eppm {
 
+#ifndef EPPM_C2F_UNROLL
+#define EPPM_C2F_UNROLL 2
+#endif
+#define EPPM_PRAGMA_(x) _Pragma(#x)
+#define EPPM_UNROLL(n) EPPM_PRAGMA_(unroll n)
+
 __device__ __forceinline__ Planes to_dev(const PlanesH& h)
 {
     Planes p;
@@ -151,7 +157,7 @@ __device__ __forceinline__ void c2f_build_tables(C2fTables<R>& T, int tid)
 }
 
 template <int R, int PASS>
-__device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, const C2fTables<R>& T, const float4* __restrict__ s_src,
+__device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLutT<R + 1>& L, const C2fTables<R>& T, const float4* __restrict__ s_src,
                                          int TW, int tx, int ty, int cx, int ccy, const rgbf c1, const rgbf (&c2)[3], float (&run)[3])
 {
     // candidates (cx, ccy-1), (cx, ccy), (cx, ccy+1): one x offset m, the three y offsets n
@@ -166,7 +172,7 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, con
         const int rb = ccy - 1 + ((PASS == 0) ? i : T.rowdy[PASS == 0 ? 0 : PASS - 1][ii]);
 #pragma unroll
         for (int k = 0; k < 4; k++) Rr[k] = __umul24((unsigned)iclamp(rb + k, 0, P.h - 1), pitch16);
-#pragma unroll 2
+EPPM_UNROLL(EPPM_C2F_UNROLL)
         for (int jj = 0; jj < S; jj++) {
             const float4 q1 = s_src[(ty + 2 * ii) * TW + tx + 2 * jj];
             const rgbf p1 = texel_rgb(q1);
@@ -211,15 +217,22 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLut& L, con
     }
 }
 
+// Waves per SIMD the register allocator plans for.  LDS would allow 5 (29 KB per workgroup), but at 4 the 116-VGPR
+// schedule keeps more gathers in flight per wave and is 1.5 % faster than the 92-VGPR one (A/B on one box,
+// tools/gpu_ab.sh); unroll 1 / 5 of the sample loop and 3 waves are slower.
+#ifndef EPPM_C2F_WAVES
+#define EPPM_C2F_WAVES 4
+#endif
+#define EPPM_C2F_OCC __attribute__((amdgpu_waves_per_eu(EPPM_C2F_WAVES, EPPM_C2F_WAVES)))
 template <int R>
-__global__ __launch_bounds__(256) void k_c2f_refine_tiled(PlanesH Ph, float* __restrict__ flow, const float* __restrict__ lut)
+__global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH Ph, float* __restrict__ flow, const float* __restrict__ lut)
 {
     constexpr int TWU = kBlock + 2 * R;                 // used tile width
     // row stride padded to a multiple of 16 texels (256 B): a ds_read_b128 wave access is served in groups made
     // of 8 lanes of one tile row and 8 of the next (MI355X LDS lane groups); with the stride = 0 mod 256 B the two
     // halves fall on disjoint banks (34-texel rows cost a 2-way conflict on about every read)
     constexpr int TW = (TWU + 15) / 16 * 16;
-    __shared__ PatchLut L;
+    __shared__ PatchLutT<R + 1> L;
     __shared__ C2fTables<R> T;
     __shared__ float4 s_src[TWU * TW];
     const int tid = threadIdx.y * kBlock + threadIdx.x;

@@ -223,7 +223,7 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
 #ifndef EPPM_C2F_WAVES
 #define EPPM_C2F_WAVES 4
 #endif
-#define EPPM_C2F_OCC __attribute__((amdgpu_waves_per_eu(EPPM_C2F_WAVES, EPPM_C2F_WAVES)))
+#define EPPM_C2F_OCC __attribute__((amdgpu_waves_per_eu(2, EPPM_C2F_WAVES)))     // (min, max): radius 17 only fits 2
 template <int R>
 __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH Ph, float* __restrict__ flow, const float* __restrict__ lut)
 {

@@ -27,8 +27,9 @@ constexpr float kUnknownFlowThresh = 1e9f;         // defs.h:85 (1e9 is exact in
 constexpr float kUnknownFlow = 1e10f;              // defs.h:90
 
 // ---- __expf restated -------------------------------------------------------------------------
-// y = x*log2e; y < -125 -> 0; n = rint(y); 2^(y-n) by a degree-5 Horner polynomial in fmaf; ldexp.
-// Arguments on this path are always <= 0.  v_mul, v_rndne, v_sub, 5 x v_fma, v_cvt, v_ldexp, v_cmp+cndmask.
+// y = x*log2e; n = rint(y); 2^(y-n) by a degree-5 Horner polynomial in fmaf; ldexp (one correctly rounded
+// scaling: gradual underflow, 0 below 2^-150 -- the reference's ex2.approx is built without .ftz).
+// Arguments on this path are always <= 0 and >= -1e5 ((int)n is in range).  v_mul, v_rndne, v_sub, 5 x v_fma, v_cvt, v_ldexp.
 __device__ __forceinline__ float fast_exp(float x)
 {
     const float y = x * 0x1.715476p+0f;
@@ -39,8 +40,7 @@ __device__ __forceinline__ float fast_exp(float x)
     p = __builtin_fmaf(p, f, 0x1.ebf9bcp-3f);
     p = __builtin_fmaf(p, f, 0x1.62e42ap-1f);
     p = __builtin_fmaf(p, f, 1.0f);
-    const float r = __builtin_ldexpf(p, (int)n);
-    return (y < -125.0f) ? 0.0f : r;
+    return __builtin_ldexpf(p, (int)n);
 }
 
 // ---- x / c for a compile-time constant c, correctly rounded in 3 operations --------------------
@@ -110,20 +110,7 @@ __device__ __forceinline__ float census_cost(const float* __restrict__ cn, uint3
     const unsigned off = (unsigned)__builtin_popcount(w1 ^ w2);          // 4 * Hamming distance
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cn) + off);
 }
-// 1 - fast_exp(x) without the flush test: below the cut-off the exponential is < 2^-125, and 1 - tiny rounds to
-// exactly 1.0f, which is what the flushed form gives
-__device__ __forceinline__ float one_minus_fast_exp(float x)
-{
-    const float y = x * 0x1.715476p+0f;
-    const float n = __builtin_rintf(y);
-    const float f = y - n;
-    float p = __builtin_fmaf(0x1.5bba14p-10f, f, 0x1.3cea88p-7f);
-    p = __builtin_fmaf(p, f, 0x1.c6b752p-5f);
-    p = __builtin_fmaf(p, f, 0x1.ebf9bcp-3f);
-    p = __builtin_fmaf(p, f, 0x1.62e42ap-1f);
-    p = __builtin_fmaf(p, f, 1.0f);
-    return 1 - __builtin_ldexpf(p, (int)n);
-}
+__device__ __forceinline__ float one_minus_fast_exp(float x) { return 1 - fast_exp(x); }
 __device__ __forceinline__ rgbf texel_rgb(const float4 t) { return rgbf{t.x, t.y, t.z}; }
 
 __device__ __forceinline__ float4 tex_px(const float4* img, int pitch, int w, int h, int x, int y)

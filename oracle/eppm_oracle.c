@@ -70,19 +70,21 @@ int orc_num_threads(void)
 }
 
 /* ------------------------------------------------------------------------------------------
- * __expf restated.  CUDA's __expf(x) is ex2.approx.ftz(x * log2(e)) (CUDA C Programming
- * Guide, intrinsic table).  The SFU's ex2.approx is not specified bit for bit, so both the
- * oracle and the HIP kernels use this one float32 formula (max rel. error 1.7e-7, i.e. the
- * same 2-ulp class as ex2.approx):
- *     y = x * log2e;  y < -125 -> 0 (the ".ftz" flush);  n = rint(y);  f = y - n in [-.5,.5];
- *     2^f by a degree-5 polynomial evaluated with fmaf (Horner);  result = ldexp(p, n).
+ * __expf restated.  CUDA's __expf(x) is ex2.approx(x * log2(e)) (libdevice __nv_fast_expf; the
+ * reference is built without -use_fast_math / -ftz, CMakeLists.txt:12-27, so subnormal results
+ * are NOT flushed).  The SFU's ex2.approx is not specified bit for bit, so both the oracle and
+ * the HIP kernels use this one float32 formula (max rel. error 1.7e-7 for normal results, i.e.
+ * the same 2-ulp class as ex2.approx):
+ *     y = x * log2e;  n = rint(y);  f = y - n in [-.5,.5];
+ *     2^f by a degree-5 polynomial evaluated with fmaf (Horner);  result = ldexpf(p, n),
+ * one correctly rounded scaling: gradual underflow below 2^-126, exactly 0 below 2^-150.
  * Used at: bao_pmflow_kernel.cu:285,291; refine :201,759; bao_basic_cuda.cuh:453.
  * ---------------------------------------------------------------------------------------- */
 float orc_fast_exp(float x)
 {
     float y = x * 0x1.715476p+0f;
-    if (y < -125.0f) return 0.0f;
     if (y > 127.0f) y = 127.0f;      /* never reached on this path (all arguments are <= 0) */
+    if (y < -1000.0f) y = -1000.0f;  /* keeps (int)n defined; the result is 0 from y < -150.5 on */
     const float n = rintf(y);
     const float f = y - n;
     float p = fmaf(0x1.5bba14p-10f, f, 0x1.3cea88p-7f);
@@ -90,11 +92,13 @@ float orc_fast_exp(float x)
     p = fmaf(p, f, 0x1.ebf9bcp-3f);
     p = fmaf(p, f, 0x1.62e42ap-1f);
     p = fmaf(p, f, 1.0f);
-    /* ldexpf(p, n): p in [0.70,1.42] and n >= -125, so the product is a normal float and the
-     * multiplication by the exactly representable 2^n is exact */
-    union { uint32_t u; float f; } two_n;
-    two_n.u = (uint32_t)((int)n + 127) << 23;
-    return p * two_n.f;
+    const int ni = (int)n;
+    if (ni >= -126) {                /* 2^n is a normal float: one IEEE multiplication (may round into the subnormals) */
+        union { uint32_t u; float f; } two_n;
+        two_n.u = (uint32_t)(ni + 127) << 23;
+        return p * two_n.f;
+    }
+    return ldexpf(p, ni);
 }
 
 /* unorm8 -> float of cudaReadModeNormalizedFloat: c/255 rounded to nearest */

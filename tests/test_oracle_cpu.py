@@ -59,8 +59,13 @@ def test_fast_exp_accuracy_and_anchors():
     assert (np.abs(y / ref - 1) <= bound).all()
     assert np.max(np.abs(y / ref - 1)[x > -1]) < 4e-7
     assert O.fast_exp([0.0])[0] == 1.0
-    assert O.fast_exp([-100.0])[0] == 0.0            # flushed, exp(-100) < 2^-125
-    assert O.fast_exp([-86.0])[0] > 0.0
+    # no flush (the reference is built without -ftz): gradual underflow, correctly rounded scaling
+    sub = -np.linspace(87.5, 103.5, 4001).astype(np.float32)
+    ys = O.fast_exp(sub).astype(np.float64)
+    assert (ys > 0).all() and (ys < 2.0 ** -126).all()
+    assert (np.abs(ys - np.exp(sub.astype(np.float64)) * (ys / ys)) <= 2.0 ** -149 * 0.5 + np.exp(sub.astype(np.float64)) * 1.3e-5).all()
+    assert O.fast_exp([-100.0])[0] == np.float32(2.0 ** -149 * 27)      # exp(-100) = 26.5 * 2^-149 -> 27 subnormal steps
+    assert O.fast_exp([-104.5])[0] == 0.0 and O.fast_exp([-4000.0])[0] == 0.0
 
 
 def test_luts_follow_the_reference_formulas():

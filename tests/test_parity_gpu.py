@@ -35,7 +35,9 @@ def O():
 
 
 def test_fast_exp_bits(S, O):
-    x = -np.concatenate([np.linspace(0, 120, 20001), np.float32(np.arange(0, 256)) ** 2 / np.float32(255 * 255 * 0.01)]).astype(np.float32)
+    # dense over the gradual-underflow range (results below 2^-126 from x = -87.3, zero from x = -104.3) and far beyond
+    x = -np.concatenate([np.linspace(0, 120, 20001), np.linspace(86, 106, 40001), np.linspace(120, 4000, 2001),
+                         np.float32(np.arange(0, 256)) ** 2 / np.float32(255 * 255 * 0.01)]).astype(np.float32)
     eq(S.probe_fast_exp(x), O.fast_exp(x), "fast_exp")
 
 

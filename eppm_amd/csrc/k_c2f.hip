@@ -219,11 +219,16 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
 
 // Waves per SIMD the register allocator plans for.  LDS would allow 5 (29 KB per workgroup), but at 4 the 116-VGPR
 // schedule keeps more gathers in flight per wave and is 1.5 % faster than the 92-VGPR one (A/B on one box,
-// tools/gpu_ab.sh); unroll 1 / 5 of the sample loop and 3 waves are slower.
+// tools/gpu_ab.sh); unroll 1 / 5 of the sample loop and 3 waves are slower, and so is a software-pipelined loop
+// that issues the gathers of the next sample pair before computing the current one (161 VGPRs, +6 % instructions,
+// +3.5 % time: the kernel waits on VALU issue, not on memory).
 #ifndef EPPM_C2F_WAVES
 #define EPPM_C2F_WAVES 4
 #endif
-#define EPPM_C2F_OCC __attribute__((amdgpu_waves_per_eu(2, EPPM_C2F_WAVES)))     // (min, max): radius 17 only fits 2
+#ifndef EPPM_C2F_WAVES_MIN
+#define EPPM_C2F_WAVES_MIN 2
+#endif
+#define EPPM_C2F_OCC __attribute__((amdgpu_waves_per_eu(EPPM_C2F_WAVES_MIN, EPPM_C2F_WAVES)))     // (min, max): radius 17 only fits 2
 template <int R>
 __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH Ph, float* __restrict__ flow, const float* __restrict__ lut)
 {

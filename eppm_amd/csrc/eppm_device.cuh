@@ -32,6 +32,9 @@ constexpr float kUnknownFlow = 1e10f;              // defs.h:90
 // Arguments on this path are always <= 0 and >= -1e5 ((int)n is in range).  v_mul, v_rndne, v_sub, 5 x v_fma, v_cvt, v_ldexp.
 __device__ __forceinline__ float fast_exp(float x)
 {
+    // v_mul, v_rndne, v_sub, 5 x v_fma, v_cvt, v_ldexp.  (Forming rint(y) with the 1.5*2^23 constant and reading the
+    // exponent from the mantissa bits trades the half-rate v_rndne/v_cvt for three full-rate instructions; measured
+    // 2.5 % slower in the refine kernel: the instruction count is what costs, tools/microbench/valu_rate.hip.)
     const float y = x * 0x1.715476p+0f;
     const float n = __builtin_rintf(y);
     const float f = y - n;
@@ -89,26 +92,22 @@ struct Planes {
     int pitch;              // pixels
 };
 
-// The census byte is stored with every bit replicated four times (bit k -> bits 4k..4k+3), so that
-// popcount(w1 ^ w2) = 4 * Hamming distance = the byte offset into the cn[] table: one instruction less per sample.
-__device__ __forceinline__ uint32_t spread_census(uint32_t c)
-{
-    uint32_t x = c & 0xffu;
-    x = (x | (x << 12)) & 0x000f000fu;
-    x = (x | (x << 6)) & 0x03030303u;
-    x = (x | (x << 3)) & 0x11111111u;
-    return x * 15u;
-}
+// The census byte is stored shifted left by 2, so that w1 ^ w2 is the byte offset of entry (c1 ^ c2) in a
+// 256-entry table cnx[b] = cn[popcount(b)]: xor + LDS read + add (4 VALU cycles fewer per sample than
+// xor + v_bcnt (half rate) + the 9-entry table).
 __device__ __forceinline__ float4 make_texel(uint32_t rgba, uint32_t census)
 {
     const rgbf c = unpack_rgb(rgba);
-    return make_float4(c.x, c.y, c.z, __uint_as_float(spread_census(census)));
+    return make_float4(c.x, c.y, c.z, __uint_as_float((census & 0xffu) << 2));
 }
-// cn[] entry for two texels' census words (see spread_census)
-__device__ __forceinline__ float census_cost(const float* __restrict__ cn, uint32_t w1, uint32_t w2)
+__device__ __forceinline__ float census_cost(const float* __restrict__ cnx, uint32_t w1, uint32_t w2)
 {
-    const unsigned off = (unsigned)__builtin_popcount(w1 ^ w2);          // 4 * Hamming distance
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cn) + off);
+#if defined(EPPM_CENSUS_BCNT)        // experiment hook: popcount + 9 distinct entries (cnx[(1<<k)-1] = cn[k])
+    const unsigned k = (unsigned)__builtin_popcount(w1 ^ w2);
+    return cnx[(1u << k) - 1u];
+#else
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cnx) + (w1 ^ w2));
+#endif
 }
 __device__ __forceinline__ float one_minus_fast_exp(float x) { return 1 - fast_exp(x); }
 __device__ __forceinline__ rgbf texel_rgb(const float4 t) { return rgbf{t.x, t.y, t.z}; }
@@ -142,13 +141,13 @@ __device__ __forceinline__ uint32_t tex_rgba(const uint32_t* img, int pitch, int
 // ---- one sample of the patch cost (bao_pmflow_kernel.cu:275-295), both texels already fetched ------
 // gsp = gs[|j|]*gs[|i|] (the product is formed first in the reference too: "weight *= a*b").
 __device__ __forceinline__ void patch_terms(const float4 q1, const float4 q2, const rgbf c1, const rgbf c2, float gsp,
-                                            const float* __restrict__ cn, float& cost_term, float& weight_term)
+                                            const float* __restrict__ cnx, float& cost_term, float& weight_term)
 {
     const rgbf p1 = texel_rgb(q1);
     const rgbf p2 = texel_rgb(q2);
     float cost = max_abs_diff(p1, p2);
     cost = one_minus_fast_exp(div_ad2(-(cost * cost)));
-    cost += census_cost(cn, __float_as_uint(q1.w), __float_as_uint(q2.w));
+    cost += census_cost(cnx, __float_as_uint(q1.w), __float_as_uint(q2.w));
     float weight = max_abs_diff(c1, p1);
     weight *= weight;
     float temp = max_abs_diff(c2, p2);
@@ -161,19 +160,19 @@ __device__ __forceinline__ void patch_terms(const float4 q1, const float4 q2, co
 }
 
 __device__ __forceinline__ void patch_sample(const Planes& P, const rgbf c1, const rgbf c2, int sx1, int sy1, int sx2,
-                                             int sy2, float gsp, const float* __restrict__ cn, float& cost_term,
+                                             int sy2, float gsp, const float* __restrict__ cnx, float& cost_term,
                                              float& weight_term)
 {
     const float4 q1 = tex_px(P.pk1, P.pitch, P.w, P.h, sx1, sy1);
     const float4 q2 = tex_px(P.pk2, P.pitch, P.w, P.h, sx2, sy2);
-    patch_terms(q1, q2, c1, c2, gsp, cn, cost_term, weight_term);
+    patch_terms(q1, q2, c1, c2, gsp, cnx, cost_term, weight_term);
 }
 
-// LUTs staged in LDS by every patch kernel: gsp[i*S + j] = gs[|2j-R|]*gs[|2i-R|], cn[0..8]
+// LUTs staged in LDS by every patch kernel: gsp[i*S + j] = gs[|2j-R|]*gs[|2i-R|], cnx[b] = cn[popcount(b)]
 template <int MAXS>
 struct PatchLutT {
     float gsp[MAXS * MAXS];
-    float cn[9];
+    float cnx[256];
 };
 using PatchLut = PatchLutT<kMaxS>;     // any radius the ABI accepts; kernels instantiated per radius use PatchLutT<R + 1>
 
@@ -187,7 +186,7 @@ __device__ __forceinline__ void load_patch_lut(PatchLutT<MAXS>& L, const float* 
         const int ai = abs(2 * i - R), aj = abs(2 * j - R);
         L.gsp[i * S + j] = lut_src[aj] * lut_src[ai];
     }
-    for (int t = tid; t < 9; t += nthreads) L.cn[t] = lut_src[R + 1 + t];
+    for (int t = tid; t < 256; t += nthreads) L.cnx[t] = lut_src[R + 1 + __builtin_popcount(t)];
 }
 
 // ---- the patch cost, bao_pmflow_kernel.cu:255-301: sequential i-outer / j-inner accumulation ------
@@ -216,7 +215,7 @@ __device__ __forceinline__ float patch_dist(const Planes& P, const PatchLut& L, 
             for (int k = 0; k < 5; k++) {
                 if (j0 + k < S) {
                     float ct, wt;
-                    patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.cn, ct, wt);
+                    patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.cnx, ct, wt);
                     cost_sum += ct;
                     weight_sum += wt;
                 }
@@ -255,7 +254,7 @@ __device__ __forceinline__ float patch_dist_pass(const Planes& P, const PatchLut
                 cy2 = cy1 + vv + (float)(j)*kc[PASS][2] + (float)(i)*kc[PASS][3];
             }
             float ct, wt;
-            patch_sample(P, c1, c2, x1 + j, y1 + i, (int)floorf(cx2), (int)floorf(cy2), L.gsp[ii * S + jj], L.cn, ct, wt);
+            patch_sample(P, c1, c2, x1 + j, y1 + i, (int)floorf(cx2), (int)floorf(cy2), L.gsp[ii * S + jj], L.cnx, ct, wt);
             cost_sum += ct;
             weight_sum += wt;
         }

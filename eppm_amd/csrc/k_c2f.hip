@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void k_c2f_refine(PlanesH Ph, float* __restric
 // source samples 36 times.  Here the sample loop is outermost within a pass: the source texel comes from
 // an LDS tile (16x16 + R halo, clamped at load), its conversion and its range term a^2 are computed once
 // per sample and shared by the 9 candidates, whose 9 pairs of running sums advance together -- each sum
-// still adds its terms in the reference's i-outer/j-inner order.  Target texels are one packed 4-byte
-// gather each (rgb + census).  The passes run 4th to 1st so the reference's nested
+// still adds its terms in the reference's i-outer/j-inner order.  Target texels are one 16-byte gather each
+// (unorm rgb + census).  The passes run 4th to 1st so the reference's nested
 // __min(c1,__min(c2,__min(c3,c4))) becomes a running select with the same NaN behaviour.
 // ---------------------------------------------------------------------------------------------------
 // Affine passes: the target of sample (i,j) is floor(((x+j + uu) + j*A) + i*B) in float (kernel.cu:334-513).
@@ -113,10 +113,9 @@ __global__ __launch_bounds__(256) void k_c2f_refine(PlanesH Ph, float* __restric
 //   floor(...) = M + floor(fl(fl(j*A) + fl(i*B)))
 // (checked exhaustively for -R <= M < 32764 by tests/test_oracle_cpu.py::test_planefit_offsets; the launcher
 // falls back to the generic kernel beyond that).  So the warp of a pass is a table of integer offsets
-// (dx, dy) per sample, built once per workgroup in LDS, and the per-sample float coordinate arithmetic of the
-// reference becomes one integer add.  Along a sample row dy takes at most two consecutive values: the four
+// (dx, dy) per sample and the per-sample float coordinate arithmetic of the reference becomes one integer add.  Along a sample row dy takes at most two consecutive values: the four
 // clamped row offsets a row can need are formed once per row and a per-sample flag picks three of them.
-struct C2fOff { int dx, up; };       // dx = j + x-offset; up = 1 if this sample's dy is the row minimum + 1
+struct C2fOff { int dx16, up; };     // dx16 = (j + x-offset) * 16 (bytes); up = 1 if this sample's dy is the row minimum + 1
 
 template <int R>
 struct C2fTables {
@@ -125,8 +124,12 @@ struct C2fTables {
     int rowdy[3][S];                  // i + min over the row of the y-offset
 };
 
+// The tables depend only on the radius and on the reference's coefficients: they are compile-time constants in
+// __constant__ memory.  Their index is wave-uniform, so they arrive through the scalar cache (s_load) and cost
+// no vector instruction; `up` steers a scalar branch.
+constexpr int cfloor(float v) { const int t = (int)v; return ((float)t > v) ? t - 1 : t; }
 template <int R>
-__device__ __forceinline__ void c2f_build_tables(C2fTables<R>& T, int tid)
+constexpr C2fTables<R> make_c2f_tables()
 {
     constexpr int S = R + 1;
     constexpr float kc[3][4] = {
@@ -134,42 +137,54 @@ __device__ __forceinline__ void c2f_build_tables(C2fTables<R>& T, int tid)
         {0.125f, -0.357f, 0.009f, 0.308f},
         {0.205f, 0.370f, 0.011f, 0.296f},
     };
-    for (int t = tid; t < 3 * S * S; t += 256) {
-        const int p = t / (S * S), ii = (t % (S * S)) / S, jj = t % S;
-        const int i = 2 * ii - R, j = 2 * jj - R;
-        const float fx = (float)(j)*kc[p][0] + (float)(i)*kc[p][1];
-        const float fy = (float)(j)*kc[p][2] + (float)(i)*kc[p][3];
-        T.off[p][ii * S + jj].dx = j + (int)floorf(fx);
-        T.off[p][ii * S + jj].up = i + (int)floorf(fy);       // dy for now
-    }
-    __syncthreads();
-    for (int t = tid; t < 3 * S; t += 256) {
-        const int p = t / S, ii = t % S;
-        int lo = T.off[p][ii * S].up;
-        for (int jj = 1; jj < S; jj++) lo = min(lo, T.off[p][ii * S + jj].up);
-        T.rowdy[p][ii] = lo;
-    }
-    __syncthreads();
-    for (int t = tid; t < 3 * S * S; t += 256) {
-        const int p = t / (S * S), ii = (t % (S * S)) / S;
-        T.off[p][t % (S * S)].up -= T.rowdy[p][ii];           // 0 or 1
-    }
+    C2fTables<R> T{};
+    for (int p = 0; p < 3; p++)
+        for (int ii = 0; ii < S; ii++) {
+            const int i = 2 * ii - R;
+            int dy[S] = {};
+            int lo = 1 << 30;
+            for (int jj = 0; jj < S; jj++) {
+                const int j = 2 * jj - R;
+                const float fx = (float)(j)*kc[p][0] + (float)(i)*kc[p][1];
+                const float fy = (float)(j)*kc[p][2] + (float)(i)*kc[p][3];
+                T.off[p][ii * S + jj].dx16 = (j + cfloor(fx)) * 16;
+                dy[jj] = i + cfloor(fy);
+                lo = dy[jj] < lo ? dy[jj] : lo;
+            }
+            T.rowdy[p][ii] = lo;
+            for (int jj = 0; jj < S; jj++) T.off[p][ii * S + jj].up = dy[jj] - lo;      // 0 or 1
+        }
+    return T;
+}
+__constant__ C2fTables<9> c2f_tab9 = make_c2f_tables<9>();
+__constant__ C2fTables<17> c2f_tab17 = make_c2f_tables<17>();
+template <int R> __device__ __forceinline__ const C2fTables<R>& c2f_tables();
+template <> __device__ __forceinline__ const C2fTables<9>& c2f_tables<9>() { return c2f_tab9; }
+template <> __device__ __forceinline__ const C2fTables<17>& c2f_tables<17>() { return c2f_tab17; }
+
+// v_med3_i32: one half-rate instruction where min(max()) compiles to two
+__device__ __forceinline__ int med3i(int v, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
 }
 
 template <int R, int PASS>
-__device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLutT<R + 1>& L, const C2fTables<R>& T, const float4* __restrict__ s_src,
-                                         int TW, int tx, int ty, int cx, int ccy, const rgbf c1, const rgbf (&c2)[3], float (&run)[3])
+__device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLutT<R + 1>& L, const float4* __restrict__ s_src,
+                                         int TW, int tx, int ty, int cx16, int wmax16, int ccy, const rgbf c1, const rgbf (&c2)[3], float (&run)[3])
 {
     // candidates (cx, ccy-1), (cx, ccy), (cx, ccy+1): one x offset m, the three y offsets n
     constexpr int S = R + 1;
+    constexpr int TP = (PASS == 0) ? 0 : PASS - 1;
+    const C2fTables<R>& T = c2f_tables<R>();
     float cs[3] = {0.0f, 0.0f, 0.0f}, ws[3] = {0.0f, 0.0f, 0.0f};
     const unsigned pitch16 = (unsigned)P.pitch << 4;
 #pragma unroll 1
     for (int ii = 0; ii < S; ii++) {
-        const int i = 2 * ii - R;
         // clamped row offsets of the targets: rows ccy-1+dy .. ccy+1+dy (+1 more where dy steps inside the row)
         unsigned Rr[4];
-        const int rb = ccy - 1 + ((PASS == 0) ? i : T.rowdy[PASS == 0 ? 0 : PASS - 1][ii]);
+        const int rb = ccy - 1 + ((PASS == 0) ? 2 * ii - R : T.rowdy[TP][ii]);
 #pragma unroll
         for (int k = 0; k < 4; k++) Rr[k] = __umul24((unsigned)iclamp(rb + k, 0, P.h - 1), pitch16);
 EPPM_UNROLL(EPPM_C2F_UNROLL)
@@ -180,26 +195,23 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
             float a2 = max_abs_diff(c1, p1);
             a2 *= a2;
             const float gsp = L.gsp[ii * S + jj];
-            unsigned Xb, Yoff[3];                         // byte offsets: column and clamped rows of the three targets
-            if (PASS == 0) {
-                Xb = (unsigned)iclamp(cx + 2 * jj - R, 0, P.w - 1) << 4;
-#pragma unroll
-                for (int n = 0; n < 3; n++) Yoff[n] = Rr[n];
-            } else {
-                const C2fOff e = T.off[PASS == 0 ? 0 : PASS - 1][ii * S + jj];
-                Xb = (unsigned)iclamp(cx + e.dx, 0, P.w - 1) << 4;
-#pragma unroll
-                for (int n = 0; n < 3; n++) Yoff[n] = e.up ? Rr[n + 1] : Rr[n];
-            }
+            // byte offsets of the three targets: clamped column (in bytes throughout: no shift) + clamped rows
+            const int dx16 = (PASS == 0) ? (2 * jj - R) * 16 : T.off[TP][ii * S + jj].dx16;
+            const unsigned Xb = (unsigned)med3i(cx16 + dx16, 0, wmax16);
             float4 q2[3];                                 // the three gathers are issued back to back, then consumed
+            if (PASS != 0 && T.off[TP][ii * S + jj].up) {         // wave-uniform; compiles to three selects on a scalar condition
 #pragma unroll
-            for (int n = 0; n < 3; n++) q2[n] = texel_at(P.pk2, Yoff[n] + Xb);
+                for (int n = 0; n < 3; n++) q2[n] = texel_at(P.pk2, Rr[n + 1] + Xb);
+            } else {
+#pragma unroll
+                for (int n = 0; n < 3; n++) q2[n] = texel_at(P.pk2, Rr[n] + Xb);
+            }
 #pragma unroll
             for (int n = 0; n < 3; n++) {
                 const rgbf p2 = texel_rgb(q2[n]);
                 float cost = max_abs_diff(p1, p2);
                 cost = one_minus_fast_exp(div_ad2(-(cost * cost)));
-                cost += census_cost(L.cn, k1, __float_as_uint(q2[n].w));
+                cost += census_cost(L.cnx, k1, __float_as_uint(q2[n].w));
                 float temp = max_abs_diff(c2[n], p2);
                 temp *= temp;
                 float weight = fast_exp(div_ad2(-(a2 + temp)));
@@ -238,11 +250,9 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
     // halves fall on disjoint banks (34-texel rows cost a 2-way conflict on about every read)
     constexpr int TW = (TWU + 15) / 16 * 16;
     __shared__ PatchLutT<R + 1> L;
-    __shared__ C2fTables<R> T;
     __shared__ float4 s_src[TWU * TW];
     const int tid = threadIdx.y * kBlock + threadIdx.x;
     load_patch_lut(L, lut, R, tid, 256);
-    c2f_build_tables<R>(T, tid);
     const Planes P = to_dev(Ph);
     // XCD-aware tile order: workgroups are dealt round robin over the 8 XCDs (b % 8), each with its own L2.
     // Give XCD k the k-th contiguous eighth of the row-major tile list so that neighbouring tiles -- which
@@ -279,10 +289,11 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
 #pragma unroll
         for (int n = 0; n < 3; n++) c2[n] = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, cx, ccy + n - 1));
         float run[3];
-        c2f_pass<R, 3>(P, L, T, s_src, TW, threadIdx.x, threadIdx.y, cx, ccy, c1, c2, run);
-        c2f_pass<R, 2>(P, L, T, s_src, TW, threadIdx.x, threadIdx.y, cx, ccy, c1, c2, run);
-        c2f_pass<R, 1>(P, L, T, s_src, TW, threadIdx.x, threadIdx.y, cx, ccy, c1, c2, run);
-        c2f_pass<R, 0>(P, L, T, s_src, TW, threadIdx.x, threadIdx.y, cx, ccy, c1, c2, run);
+        const int cx16 = cx << 4, wmax16 = (P.w - 1) << 4;
+        c2f_pass<R, 3>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+        c2f_pass<R, 2>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+        c2f_pass<R, 1>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+        c2f_pass<R, 0>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
 #pragma unroll
         for (int n = 0; n < 3; n++) {
             const int cy = (int)(int16_t)(ccy + n - 1);

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
                     if (q < CH) {
                         const int t = t0 + q;
                         tc[q] = 0.0f; tw[q] = 0.0f;
-                        if (t < NS) patch_terms(q1[k], q2[k], c1, c2, L.gsp[t], L.cn, tc[q], tw[q]);
+                        if (t < NS) patch_terms(q1[k], q2[k], c1, c2, L.gsp[t], L.cnx, tc[q], tw[q]);
                     }
                 }
             }

@@ -15,6 +15,9 @@
 #ifndef EPPM_LPC9
 #define EPPM_LPC9 16      // lanes per sweep chain at patch radius 9 (100 samples): 32 cuts the single-pair latency 4 % but costs throughput with pairs in flight
 #endif
+#ifndef EPPM_SWEEP_GB
+#define EPPM_SWEEP_GB 7   // sample gathers a sweep lane keeps in flight (per image)
+#endif
 #ifndef EPPM_LPC17
 #define EPPM_LPC17 64     // ... at patch radius 17 (324 samples)
 #endif
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
             const rgbf c1 = texel_rgb(tex_px(P.pk1, P.pitch, P.w, P.h, x, y));
             const rgbf c2 = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, px, py));
             float tc[CH], tw[CH];
-            constexpr int GB = (CH < 7) ? CH : 7;           // gathers in flight per lane
+            constexpr int GB = (CH < EPPM_SWEEP_GB) ? CH : EPPM_SWEEP_GB;           // gathers in flight per lane
 #pragma unroll
             for (int q0 = 0; q0 < CH; q0 += GB) {
                 float4 q1[GB], q2[GB];

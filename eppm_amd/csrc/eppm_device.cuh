@@ -209,7 +209,11 @@ __device__ __forceinline__ float patch_dist(const Planes& P, const PatchLut& L, 
             for (int k = 0; k < 5; k++) {
                 const int j = 2 * min(j0 + k, S - 1) - R;
                 q1[k] = texel_at(P.pk1, r1 + ((unsigned)iclamp(x1 + j, 0, P.w - 1) << 4));
+#ifdef EPPM_PD_NOQ2          // timing experiment only (wrong results): cost of the scattered target gathers
+                q2[k] = make_float4(0.001f * (x2 + j), 0.002f * (y2 + i), 0.5f, 0.0f);
+#else
                 q2[k] = texel_at(P.pk2, r2 + ((unsigned)iclamp(x2 + j, 0, P.w - 1) << 4));
+#endif
             }
 #pragma unroll
             for (int k = 0; k < 5; k++) {

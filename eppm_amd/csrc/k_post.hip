@@ -100,6 +100,7 @@ void launch_outlier(int16_t* nnf_out, float* cost, const int16_t* nnf_in, int w,
 // ---------------------------------------------------------------------------------------------------
 constexpr int WR = kWmfRadius, WN = (2 * WR + 1) * (2 * WR + 1);   // 4, 81
 constexpr uint32_t kCopyOnly = 0x80000000u;
+constexpr uint32_t kWmfBatch = 256;      // list entries a workgroup processes between two appends
 
 __global__ __launch_bounds__(256) void k_wmf_build_list(const int16_t* __restrict__ nnf, int npitch, int w, int h, int only_occ,
                                                         uint32_t* __restrict__ list, uint32_t* __restrict__ count)
@@ -118,90 +119,109 @@ __global__ __launch_bounds__(256) void k_wmf_iter(int16_t* __restrict__ nnf_out,
                                                   uint32_t* __restrict__ list_out, uint32_t* __restrict__ count_out)
 {
     __shared__ float s_lut[WR + 1];
-    __shared__ float s_wgt[4][WN];
-    __shared__ int s_fx[4][WN], s_fy[4][WN];
+    __shared__ float4 s_tap[4][WN];       // {bilateral weight, flow x, flow y, -} of the valid taps, row-major order
+    __shared__ uint32_t s_keep[kWmfBatch], s_nkeep, s_base;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     if (tid <= WR) s_lut[tid] = wmf_lut[tid];
-    __syncthreads();
+    // A workgroup owns a contiguous chunk of the list and works through it in batches; the entries that stay on
+    // the list are collected in LDS and appended with ONE global atomic per batch (one returning atomic per
+    // item on the single counter made the first launches atomic-bound: 17 k items took 208 us).
     const uint32_t n_items = *count_in;
-    const uint32_t n_waves = gridDim.x * 4;
-    for (uint32_t item = blockIdx.x * 4 + wv; item < n_items; item += n_waves) {
-        const uint32_t e = list_in[item];
-        const int x = (int)(e & 0xffffu), y = (int)((e >> 16) & 0x7fffu);
-        const int pidx = (y * npitch + x) * 2;
-        const int ox = nnf_in[pidx], oy = nnf_in[pidx + 1];
-        if (e & kCopyOnly) {                                    // became valid in the previous launch
-            if (lane == 0) { nnf_out[pidx] = (int16_t)ox; nnf_out[pidx + 1] = (int16_t)oy; }
-            continue;
-        }
-        const rgbf center = unpack_rgb(img[y * ipitch + x]);
-        // taps in row-major order (dy outer, dx inner): lanes 0..63 take taps 0..63, lanes 0..16 taps 64..80
-        int nv = 0;
-#pragma unroll
-        for (int rnd = 0; rnd < 2; rnd++) {
-            const int t = rnd * 64 + lane;
-            bool ok = false;
-            int fx = 0, fy = 0;
-            float wgt = 0.0f;
-            if (t < WN) {
-                const int dy2 = t / 9 - WR, dx2 = t % 9 - WR;
-                const int cy = y + dy2, cx = x + dx2;
-                if (cx >= 0 && cy >= 0 && cx < w && cy < h) {
-                    const int dx = nnf_in[(cy * npitch + cx) * 2], dy = nnf_in[(cy * npitch + cx) * 2 + 1];
-                    if (!(dx < 0 || dy < 0)) {                  // "skip invalid disparity", refine :225,238
-                        ok = true;
-                        fx = (int)(int16_t)(dx - cx);
-                        fy = (int)(int16_t)(dy - cy);
-                        const rgbf pix = unpack_rgb(img[cy * ipitch + cx]);
-                        const float delta_r = max_abs_diff(center, pix);
-                        const float coef_r = fast_exp(div_wmf2(-(delta_r * delta_r)));
-                        const float coef_s = s_lut[abs(dx2)] * s_lut[abs(dy2)];
-                        wgt = coef_r * coef_s;                  // refine :198-204
+    const uint32_t per_wg = (n_items + gridDim.x - 1) / gridDim.x;
+    const uint32_t beg = blockIdx.x * per_wg, end = (beg + per_wg < n_items) ? beg + per_wg : n_items;
+    for (uint32_t b0 = beg; b0 < end; b0 += kWmfBatch) {
+        const uint32_t b1 = (b0 + kWmfBatch < end) ? b0 + kWmfBatch : end;
+        if (tid == 0) s_nkeep = 0;
+        __syncthreads();
+        for (uint32_t item = b0 + wv; item < b1; item += 4) {
+            const uint32_t e = list_in[item];
+            const int x = (int)(e & 0xffffu), y = (int)((e >> 16) & 0x7fffu);
+            const int pidx = (y * npitch + x) * 2;
+            const int ox = nnf_in[pidx], oy = nnf_in[pidx + 1];
+            if (e & kCopyOnly) {                                    // became valid in the previous launch
+                if (lane == 0) { nnf_out[pidx] = (int16_t)ox; nnf_out[pidx + 1] = (int16_t)oy; }
+                continue;
+            }
+            const rgbf center = unpack_rgb(img[y * ipitch + x]);
+            // taps in row-major order (dy outer, dx inner): lanes 0..63 take taps 0..63, lanes 0..16 taps 64..80
+            int nv = 0;
+    #pragma unroll
+            for (int rnd = 0; rnd < 2; rnd++) {
+                const int t = rnd * 64 + lane;
+                bool ok = false;
+                int fx = 0, fy = 0;
+                float wgt = 0.0f;
+                if (t < WN) {
+                    const int dy2 = t / 9 - WR, dx2 = t % 9 - WR;
+                    const int cy = y + dy2, cx = x + dx2;
+                    if (cx >= 0 && cy >= 0 && cx < w && cy < h) {
+                        const int dx = nnf_in[(cy * npitch + cx) * 2], dy = nnf_in[(cy * npitch + cx) * 2 + 1];
+                        if (!(dx < 0 || dy < 0)) {                  // "skip invalid disparity", refine :225,238
+                            ok = true;
+                            fx = (int)(int16_t)(dx - cx);
+                            fy = (int)(int16_t)(dy - cy);
+                            const rgbf pix = unpack_rgb(img[cy * ipitch + cx]);
+                            const float delta_r = max_abs_diff(center, pix);
+                            const float coef_r = fast_exp(div_wmf2(-(delta_r * delta_r)));
+                            const float coef_s = s_lut[abs(dx2)] * s_lut[abs(dy2)];
+                            wgt = coef_r * coef_s;                  // refine :198-204
+                        }
                     }
                 }
+                const unsigned long long m = __ballot(ok);
+                if (ok) {
+                    const int pos = nv + __popcll(m & ((1ull << lane) - 1ull));
+                    s_tap[wv][pos] = make_float4(wgt, (float)fx, (float)fy, 0.0f);     // |flow| < 2^16: exact in float
+                }
+                nv += __popcll(m);
             }
-            const unsigned long long m = __ballot(ok);
-            if (ok) {
-                const int pos = nv + __popcll(m & ((1ull << lane) - 1ull));
-                s_wgt[wv][pos] = wgt; s_fx[wv][pos] = fx; s_fy[wv][pos] = fy;
-            }
-            nv += __popcll(m);
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        float bestc = FLT_MAX;
-        int besti = 0x7fffffff;
-        for (int c = lane; c < nv; c += 64) {
-            const int cfx = s_fx[wv][c], cfy = s_fy[wv][c];
-            float costSum = 0.0f, weightSum = 0.0f;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // Candidates lane and lane + 64 advance together through ONE pass over the taps (each tap is read once and
+            // broadcast).  The flow differences are formed in float -- exact, so (float)max(|dx|,|dy|) is the reference's
+            // value -- and weightSum, the same sequential sum for every candidate, is formed once.
+            const bool has0 = lane < nv, has1 = lane + 64 < nv;
+            const float4 e0 = has0 ? s_tap[wv][lane] : make_float4(0, 0, 0, 0);
+            const float4 e1 = has1 ? s_tap[wv][lane + 64] : make_float4(0, 0, 0, 0);
+            float cs0 = 0.0f, cs1 = 0.0f, weightSum = 0.0f;
+    #pragma unroll 4
             for (int t = 0; t < nv; t++) {
-                const float wgt = s_wgt[wv][t];
-                costSum += wgt * (float)max(abs(cfx - s_fx[wv][t]), abs(cfy - s_fy[wv][t]));
-                weightSum += wgt;
+                const float4 tp = s_tap[wv][t];
+                cs0 += tp.x * fmaxf(fabsf(e0.y - tp.y), fabsf(e0.z - tp.z));
+                cs1 += tp.x * fmaxf(fabsf(e1.y - tp.y), fabsf(e1.z - tp.z));
+                weightSum += tp.x;
             }
-            if (weightSum > 0.0f && costSum < FLT_MAX) {
-                if (costSum < bestc || (costSum == bestc && c < besti)) { bestc = costSum; besti = c; }
+            float bestc = FLT_MAX;
+            int besti = 0x7fffffff;
+            if (weightSum > 0.0f) {
+                if (has0 && cs0 < FLT_MAX) { bestc = cs0; besti = lane; }
+                if (has1 && cs1 < FLT_MAX && cs1 < bestc) { bestc = cs1; besti = lane + 64; }      // strict <: the lower index wins ties
             }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float oc = __shfl_xor(bestc, off, 64);
-            const int oi = __shfl_xor(besti, off, 64);
-            if (oc < bestc || (oc == bestc && oi < besti)) { bestc = oc; besti = oi; }
-        }
-        if (lane == 0) {
-            int rx = ox, ry = oy;
-            if (besti != 0x7fffffff) {
-                const int nx = (int)(int16_t)(s_fx[wv][besti] + x), ny = (int)(int16_t)(s_fy[wv][besti] + y);
-                if (!(nx < 0 || ny < 0)) { rx = nx; ry = ny; }          // refine :257
+    #pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float oc = __shfl_xor(bestc, off, 64);
+                const int oi = __shfl_xor(besti, off, 64);
+                if (oc < bestc || (oc == bestc && oi < besti)) { bestc = oc; besti = oi; }
             }
-            nnf_out[pidx] = (int16_t)rx;
-            nnf_out[pidx + 1] = (int16_t)ry;
-            const bool again = !(only_occ && rx >= 0 && ry >= 0);
-            list_out[atomicAdd(count_out, 1u)] = (e & 0x7fffffffu) | (again ? 0u : kCopyOnly);
+            if (lane == 0) {
+                int rx = ox, ry = oy;
+                if (besti != 0x7fffffff) {
+                    const int nx = (int)(int16_t)((int)s_tap[wv][besti].y + x), ny = (int)(int16_t)((int)s_tap[wv][besti].z + y);
+                    if (!(nx < 0 || ny < 0)) { rx = nx; ry = ny; }          // refine :257
+                }
+                nnf_out[pidx] = (int16_t)rx;
+                nnf_out[pidx + 1] = (int16_t)ry;
+                const bool again = !(only_occ && rx >= 0 && ry >= 0);
+                s_keep[atomicAdd(&s_nkeep, 1u)] = (e & 0x7fffffffu) | (again ? 0u : kCopyOnly);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __syncthreads();
+        if (tid == 0) s_base = atomicAdd(count_out, s_nkeep);
+        __syncthreads();
+        for (uint32_t i = tid; i < s_nkeep; i += 256) list_out[s_base + i] = s_keep[i];
+        __syncthreads();
     }
 }
 
@@ -219,10 +239,14 @@ int16_t* launch_wmf(int16_t* buf_a, int16_t* buf_b, const uint32_t* img, int ipi
     dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
     hipLaunchKernelGGL(k_wmf_build_list, grid, block, 0, s, buf_a, nnf_pitch, w, h, only_occlusion, list0, counts);
     const int pixels = w * h;
-    int nblocks = (pixels + 3) / 4;
-    if (nblocks > 1024) nblocks = 1024;
+    int nblocks0 = (pixels + 3) / 4;
+    if (nblocks0 > 1024) nblocks0 = 1024;
     int16_t *in = buf_a, *out = buf_b;
     for (int i = 0; i < num_iter; i++) {
+        // occlusion-only lists shrink fast (most pixels are filled by the first launches): later launches get a
+        // smaller grid so that a (nearly) empty launch costs a launch, not 1024 workgroups reading the counter
+        int nblocks = nblocks0;
+        if (only_occlusion) nblocks = (nblocks0 >> i) > 64 ? (nblocks0 >> i) : (nblocks0 < 64 ? nblocks0 : 64);
         hipLaunchKernelGGL(k_wmf_iter, dim3(nblocks), dim3(256), 0, s, out, in, img, ipitch, w, h, nnf_pitch, wmf_lut, only_occlusion,
                            (i & 1) ? list1 : list0, counts + i, (i & 1) ? list0 : list1, counts + i + 1);
         int16_t* t = in; in = out; out = t;

@@ -1,6 +1,8 @@
 // k_c2f.hip -- coarse-to-fine step (reference: basic/bao_basic_cuda.cuh:511-537 float2 bilinear resize,
 // :135-142 scalar multiply; bao_pmflow_kernel.cu:2005-2041 plane-fitting candidate refine;
 // bao_pmflow_refine_kernel.cu:756-799 joint-bilateral flow smoothing).
+#include <type_traits>
+
 #include "eppm_device.cuh"
 #include "eppm_internal.h"
 
@@ -318,64 +320,104 @@ void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, h
 }
 
 // ---------------------------------------------------------------------------------------------------
-// refine :764-799: 21x21 joint bilateral filter of the flow guided by image 1 (Jacobi).  32x8 output
-// tile; flow + unorm guide colours of the (32+20)x(8+20) halo tile staged once in LDS.
+// refine :764-799: 21x21 joint bilateral filter of the flow guided by image 1 (Jacobi).
+//
+// 32x16 output tile, 256 threads: a lane filters TWO vertically adjacent pixels, so each tap row it reads from
+// LDS serves both (rows 0..20 the upper pixel, 1..21 the lower one) -- one pixel per lane reads 21 B of LDS per
+// tap and is LDS-bandwidth bound.  The (32+20)x(16+20) halo tile holds {r, g, b, flow x} and {flow y} per texel.
+// Taps the reference skips (outside the image, or unknown flow, refine :781) are stored with r = 100: their range
+// distance is ~100, the exponent -2.5e7 and fast_exp returns exactly 0, so they add 0 * flow = 0 and 0 to the
+// sums -- no validity flag, no divergent branch (unknown flows are the finite marker 1e10, never inf).
 // ---------------------------------------------------------------------------------------------------
-constexpr int BT_W = 32, BT_H = 8, BR = kBlfRadius, BTW = BT_W + 2 * BR, BTH = BT_H + 2 * BR;
+constexpr int BT_W = 32, BT_H = 16, BR = kBlfRadius, BTW = BT_W + 2 * BR, BTH = BT_H + 2 * BR;
 
 __global__ __launch_bounds__(256) void k_flow_blf(float* __restrict__ out, const float* __restrict__ in,
                                                   const uint32_t* __restrict__ img, int ipitch, int w, int h, int fpitch,
                                                   const float* __restrict__ blf_lut)
 {
-    __shared__ float s_fx[BTH * BTW], s_fy[BTH * BTW], s_r[BTH * BTW], s_g[BTH * BTW], s_b[BTH * BTW];
-    __shared__ uint8_t s_ok[BTH * BTW];
+    __shared__ float4 s_t[BTH * BTW];          // r, g, b (unorm), flow x
+    __shared__ float s_fy[BTH * BTW];
     __shared__ float s_lut[BR + 1];
     const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
     const int tid = threadIdx.y * BT_W + threadIdx.x;
     if (tid <= BR) s_lut[tid] = blf_lut[tid];
     for (int t = tid; t < BTW * BTH; t += 256) {
         const int cy = y0 + t / BTW - BR, cx = x0 + t % BTW - BR;
-        float fx = 0, fy = 0, r = 0, g = 0, b = 0;
-        int ok = 0;
+        float4 e = make_float4(100.0f, 0.0f, 0.0f, 0.0f);
+        float fy = 0.0f;
         if (cx >= 0 && cy >= 0 && cx < w && cy < h) {
-            fx = in[(cy * fpitch + cx) * 2];
+            e.w = in[(cy * fpitch + cx) * 2];
             fy = in[(cy * fpitch + cx) * 2 + 1];
-            ok = !(fx > kUnknownFlowThresh || fy > kUnknownFlowThresh);     // refine :781
-            const rgbf c = unpack_rgb(img[cy * ipitch + cx]);
-            r = c.x; g = c.y; b = c.z;
+            if (!(e.w > kUnknownFlowThresh || fy > kUnknownFlowThresh)) {     // refine :781
+                const rgbf c = unpack_rgb(img[cy * ipitch + cx]);
+                e.x = c.x; e.y = c.y; e.z = c.z;
+            }
         }
-        s_fx[t] = fx; s_fy[t] = fy; s_r[t] = r; s_g[t] = g; s_b[t] = b; s_ok[t] = (uint8_t)ok;
+        s_t[t] = e;
+        s_fy[t] = fy;
     }
     __syncthreads();
-    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
-    if (x >= w || y >= h) return;
-    const int ci = (threadIdx.y + BR) * BTW + threadIdx.x + BR;
-    const rgbf center = {s_r[ci], s_g[ci], s_b[ci]};
-    float nx = 0.f, ny = 0.f, wsum = 0.f;
-    for (int dy = 0; dy <= 2 * BR; dy++) {
-        const float gy = s_lut[abs(dy - BR)];
+    const int x = x0 + threadIdx.x, ya = y0 + 2 * threadIdx.y;          // pixels (x, ya) and (x, ya + 1)
+    if (x >= w || ya >= h) return;
+    const bool has_b = ya + 1 < h;
+    const rgbf ca = unpack_rgb(img[ya * ipitch + x]);
+    const rgbf cb = unpack_rgb(img[(has_b ? ya + 1 : ya) * ipitch + x]);
+    float nxa = 0.f, nya = 0.f, wa = 0.f, nxb = 0.f, nyb = 0.f, wb = 0.f;
+    const int base = (2 * threadIdx.y) * BTW + threadIdx.x;
+    // tap rows ya-10 .. ya+11: row 0 serves only the upper pixel, row 21 only the lower one, rows 1..20 both
+    auto tap_row = [&](int r, auto use_a, auto use_b) {
+        const float gya = use_a ? s_lut[abs(r - BR)] : 0.0f;
+        const float gyb = use_b ? s_lut[abs(r - 1 - BR)] : 0.0f;
+#pragma unroll 3
         for (int dx = 0; dx <= 2 * BR; dx++) {
-            const int ti = (threadIdx.y + dy) * BTW + threadIdx.x + dx;
-            if (!s_ok[ti]) continue;
-            const rgbf pix = {s_r[ti], s_g[ti], s_b[ti]};
-            const float delta_r = max_abs_diff(center, pix);
-            const float coef_r = fast_exp(div_wmf2(-(delta_r * delta_r)));
-            const float coef_s = s_lut[abs(dx - BR)] * gy;
-            const float wgt = coef_r * coef_s;
-            nx += wgt * s_fx[ti];
-            ny += wgt * s_fy[ti];
-            wsum += wgt;
+            const int ti = base + r * BTW + dx;
+            const float4 tp = s_t[ti];
+            const float tfy = s_fy[ti];
+            const rgbf pix = {tp.x, tp.y, tp.z};
+            const float gx = s_lut[abs(dx - BR)];
+            if (use_a) {
+                const float delta_r = max_abs_diff(ca, pix);
+                const float coef_r = fast_exp(div_wmf2(-(delta_r * delta_r)));
+                const float coef_s = gx * gya;
+                const float wgt = coef_r * coef_s;
+                nxa += wgt * tp.w;
+                nya += wgt * tfy;
+                wa += wgt;
+            }
+            if (use_b) {
+                const float delta_r = max_abs_diff(cb, pix);
+                const float coef_r = fast_exp(div_wmf2(-(delta_r * delta_r)));
+                const float coef_s = gx * gyb;
+                const float wgt = coef_r * coef_s;
+                nxb += wgt * tp.w;
+                nyb += wgt * tfy;
+                wb += wgt;
+            }
         }
+    };
+    tap_row(0, std::true_type{}, std::false_type{});
+#pragma unroll 1
+    for (int r = 1; r <= 2 * BR; r++) tap_row(r, std::true_type{}, std::true_type{});
+    tap_row(2 * BR + 1, std::false_type{}, std::true_type{});
+    {
+        const int ci = base + BR * BTW + BR;
+        float ox = s_t[ci].w, oy = s_fy[ci];
+        if (wa != 0) { ox = nxa / wa; oy = nya / wa; }
+        out[(ya * fpitch + x) * 2] = ox;
+        out[(ya * fpitch + x) * 2 + 1] = oy;
     }
-    float ox = s_fx[ci], oy = s_fy[ci];
-    if (wsum != 0) { ox = nx / wsum; oy = ny / wsum; }
-    out[(y * fpitch + x) * 2] = ox;
-    out[(y * fpitch + x) * 2 + 1] = oy;
+    if (has_b) {
+        const int ci = base + (BR + 1) * BTW + BR;
+        float ox = s_t[ci].w, oy = s_fy[ci];
+        if (wb != 0) { ox = nxb / wb; oy = nyb / wb; }
+        out[((ya + 1) * fpitch + x) * 2] = ox;
+        out[((ya + 1) * fpitch + x) * 2 + 1] = oy;
+    }
 }
 void launch_flow_blf(float* out, const float* in, const uint32_t* img, int ipitch, int w, int h, int flow_pitch,
                      const float* blf_lut, hipStream_t s)
 {
-    dim3 block(BT_W, BT_H), grid((w + BT_W - 1) / BT_W, (h + BT_H - 1) / BT_H);
+    dim3 block(BT_W, BT_H / 2), grid((w + BT_W - 1) / BT_W, (h + BT_H - 1) / BT_H);
     hipLaunchKernelGGL(k_flow_blf, grid, block, 0, s, out, in, img, ipitch, w, h, flow_pitch, blf_lut);
 }
 

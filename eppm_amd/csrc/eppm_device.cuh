@@ -102,12 +102,7 @@ __device__ __forceinline__ float4 make_texel(uint32_t rgba, uint32_t census)
 }
 __device__ __forceinline__ float census_cost(const float* __restrict__ cnx, uint32_t w1, uint32_t w2)
 {
-#if defined(EPPM_CENSUS_BCNT)        // experiment hook: popcount + 9 distinct entries (cnx[(1<<k)-1] = cn[k])
-    const unsigned k = (unsigned)__builtin_popcount(w1 ^ w2);
-    return cnx[(1u << k) - 1u];
-#else
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cnx) + (w1 ^ w2));
-#endif
 }
 __device__ __forceinline__ float one_minus_fast_exp(float x) { return 1 - fast_exp(x); }
 __device__ __forceinline__ rgbf texel_rgb(const float4 t) { return rgbf{t.x, t.y, t.z}; }
@@ -209,11 +204,7 @@ __device__ __forceinline__ float patch_dist(const Planes& P, const PatchLut& L, 
             for (int k = 0; k < 5; k++) {
                 const int j = 2 * min(j0 + k, S - 1) - R;
                 q1[k] = texel_at(P.pk1, r1 + ((unsigned)iclamp(x1 + j, 0, P.w - 1) << 4));
-#ifdef EPPM_PD_NOQ2          // timing experiment only (wrong results): cost of the scattered target gathers
-                q2[k] = make_float4(0.001f * (x2 + j), 0.002f * (y2 + i), 0.5f, 0.0f);
-#else
                 q2[k] = texel_at(P.pk2, r2 + ((unsigned)iclamp(x2 + j, 0, P.w - 1) << 4));
-#endif
             }
 #pragma unroll
             for (int k = 0; k < 5; k++) {

@@ -201,13 +201,8 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
                 for (int k = 0; k < GB; k++) {
                     const int t = min(t0 + q0 + k, NS - 1);
                     const int di = 2 * (t / S) - R, dj = 2 * (t % S) - R;
-#ifdef EPPM_SWEEP_NOMEM      // timing experiment only (wrong results): how much of a step is the gather round trip?
-                    q1[k] = make_float4(0.001f * (x + dj), 0.002f * (y + di), 0.5f, 0.0f);
-                    q2[k] = make_float4(0.001f * (px + dj), 0.002f * (py + di), 0.5f, 0.0f);
-#else
                     q1[k] = texel_at(P.pk1, texel_off(pitch16, P.w, P.h, x + dj, y + di));
                     q2[k] = texel_at(P.pk2, texel_off(pitch16, P.w, P.h, px + dj, py + di));
-#endif
                 }
 #pragma unroll
                 for (int k = 0; k < GB; k++) {

@@ -299,7 +299,7 @@ static int ctx_alloc(eppm_ctx* c)
     HIPCHK(hipMalloc((void**)&c->nnf_tmp2, n * 4));
     HIPCHK(hipMalloc((void**)&c->cost1, n * 4));
     HIPCHK(hipMalloc((void**)&c->cost2, n * 4));
-    HIPCHK(hipMalloc((void**)&c->wmf_ws, (2 * n + c->prm.wmf_iters + 2) * 4));
+    HIPCHK(hipMalloc((void**)&c->wmf_ws, wmf_workspace_words(c->W[L], c->H[L], c->prm.wmf_iters) * 4));
     std::vector<float> v;
     host_pm_lut(c->prm.patch_r, v);  CHK(upload_lut(&c->lut_pm, v));
     host_wmf_lut(v);                 CHK(upload_lut(&c->lut_wmf, v));
@@ -968,7 +968,7 @@ extern "C" void baoCudaWeightedMedianFilter(eppm_short2* d_disp_vec, float* d_co
     g_launch_status = get_scratch(ds, disp_pitch * h, &tmp);
     if (g_launch_status != EPPM_OK) return;
     void* ws = nullptr;
-    g_launch_status = get_scratch(ds, ((size_t)2 * w * h + (num_iter > 0 ? num_iter : 0) + 2) * 4, &ws, 1);
+    g_launch_status = get_scratch(ds, wmf_workspace_words(w, h, num_iter) * 4, &ws, 1);
     if (g_launch_status != EPPM_OK) return;
     int16_t* res = launch_wmf((int16_t*)d_disp_vec, (int16_t*)tmp, (const uint32_t*)d_img, (int)(img_pitch / 4), w, h, (int)(disp_pitch / 4),
                               ds->lut_wmf, num_iter, is_only_occlusion ? 1 : 0, (uint32_t*)ws, g_stream);

@@ -74,6 +74,7 @@ void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float*
 void launch_lr_check(int16_t* nnf1, float* cost1, const int16_t* nnf2, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s);
 void launch_outlier(int16_t* nnf_out, float* cost, const int16_t* nnf_in, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s);
 // all num_iter Jacobi launches; ping-pongs buf_a (input) / buf_b, ws = 2*w*h + num_iter + 2 uint32 words; returns the result buffer
+size_t wmf_workspace_words(int w, int h, int num_iter);
 int16_t* launch_wmf(int16_t* buf_a, int16_t* buf_b, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
                     const float* wmf_lut, int num_iter, int only_occlusion, uint32_t* ws, hipStream_t s);
 void launch_fill_holes(int16_t* nnf_out, const int16_t* nnf_in, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,

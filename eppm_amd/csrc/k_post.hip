@@ -116,8 +116,13 @@ __global__ __launch_bounds__(256) void k_wmf_iter(int16_t* __restrict__ nnf_out,
                                                   const uint32_t* __restrict__ img, int ipitch, int w, int h, int npitch,
                                                   const float* __restrict__ wmf_lut, int only_occ,
                                                   const uint32_t* __restrict__ list_in, const uint32_t* __restrict__ count_in,
-                                                  uint32_t* __restrict__ list_out, uint32_t* __restrict__ count_out)
+                                                  uint32_t* __restrict__ list_out, uint32_t* __restrict__ count_out,
+                                                  const uint32_t* __restrict__ changed_prev, uint32_t* __restrict__ changed_cur)
 {
+    // Occlusion-only mode: if the previous launch filled no pixel, the field is at a fixed point -- the listed pixels
+    // would be recomputed from unchanged neighbourhoods and stay invalid, and both ping-pong buffers already agree.
+    // The remaining launches do nothing (their output count stays 0).
+    if (only_occ && changed_prev && *changed_prev == 0u) return;
     __shared__ float s_lut[WR + 1];
     __shared__ float4 s_tap[4][WN];       // {bilateral weight, flow x, flow y, -} of the valid taps, row-major order
     __shared__ uint32_t s_keep[kWmfBatch], s_nkeep, s_base;
@@ -212,6 +217,7 @@ __global__ __launch_bounds__(256) void k_wmf_iter(int16_t* __restrict__ nnf_out,
                 nnf_out[pidx] = (int16_t)rx;
                 nnf_out[pidx + 1] = (int16_t)ry;
                 const bool again = !(only_occ && rx >= 0 && ry >= 0);
+                if (!again) *changed_cur = 1u;
                 s_keep[atomicAdd(&s_nkeep, 1u)] = (e & 0x7fffffffu) | (again ? 0u : kCopyOnly);
             }
             __builtin_amdgcn_wave_barrier();
@@ -225,8 +231,14 @@ __global__ __launch_bounds__(256) void k_wmf_iter(int16_t* __restrict__ nnf_out,
     }
 }
 
+size_t wmf_workspace_words(int w, int h, int num_iter)
+{
+    return 2 * (size_t)w * h + 2 * (size_t)((num_iter > 0 ? num_iter : 0) + 2);
+}
+
 // Runs num_iter launches, ping-ponging between buf_a (input, holds the NNF) and buf_b.  ws: uint32 workspace of
-// 2*w*h + num_iter + 2 words.  Returns the buffer that holds the result.
+// wmf_workspace_words() words (two lists, per-launch counters and "filled a pixel" flags).  Returns the buffer that
+// holds the result.
 int16_t* launch_wmf(int16_t* buf_a, int16_t* buf_b, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
                     const float* wmf_lut, int num_iter, int only_occlusion, uint32_t* ws, hipStream_t s)
 {
@@ -234,7 +246,8 @@ int16_t* launch_wmf(int16_t* buf_a, int16_t* buf_b, const uint32_t* img, int ipi
     uint32_t* list0 = ws;
     uint32_t* list1 = ws + (size_t)w * h;
     uint32_t* counts = ws + 2 * (size_t)w * h;
-    (void)hipMemsetAsync(counts, 0, sizeof(uint32_t) * (num_iter + 2), s);
+    uint32_t* changed = counts + num_iter + 2;
+    (void)hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2 * (num_iter + 2), s);
     (void)hipMemcpyAsync(buf_b, buf_a, (size_t)nnf_pitch * h * 4, hipMemcpyDeviceToDevice, s);
     dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
     hipLaunchKernelGGL(k_wmf_build_list, grid, block, 0, s, buf_a, nnf_pitch, w, h, only_occlusion, list0, counts);
@@ -248,7 +261,8 @@ int16_t* launch_wmf(int16_t* buf_a, int16_t* buf_b, const uint32_t* img, int ipi
         int nblocks = nblocks0;
         if (only_occlusion) nblocks = (nblocks0 >> i) > 64 ? (nblocks0 >> i) : (nblocks0 < 64 ? nblocks0 : 64);
         hipLaunchKernelGGL(k_wmf_iter, dim3(nblocks), dim3(256), 0, s, out, in, img, ipitch, w, h, nnf_pitch, wmf_lut, only_occlusion,
-                           (i & 1) ? list1 : list0, counts + i, (i & 1) ? list0 : list1, counts + i + 1);
+                           (i & 1) ? list1 : list0, counts + i, (i & 1) ? list0 : list1, counts + i + 1,
+                           i > 0 ? changed + i - 1 : nullptr, changed + i);
         int16_t* t = in; in = out; out = t;
     }
     return in;

@@ -71,6 +71,19 @@ class EPPM:
         check(lib().eppm_compute(self._ctx, u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "eppm_compute")
         return u, v
 
+    def compute_flow_begin(self):
+        """Enqueue compute_flow and its device-to-host copy, return at once (eppm_compute_begin)."""
+        self._need()
+        check(lib().eppm_compute_begin(self._ctx), "eppm_compute_begin")
+
+    def compute_flow_end(self):
+        """Wait for compute_flow_begin; returns (disp1_x, disp1_y)."""
+        self._need()
+        u = np.empty((self.h, self.w), np.float32)
+        v = np.empty((self.h, self.w), np.float32)
+        check(lib().eppm_compute_end(self._ctx, u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "eppm_compute_end")
+        return u, v
+
     # -- device-resident variants (no PCIe in the timed region) ----------------------------
     def set_data_device(self, d_rgba1, d_rgba2, pitch):
         self._need()

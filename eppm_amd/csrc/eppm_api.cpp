@@ -198,6 +198,7 @@ struct eppm_ctx {
     int16_t *nnf1 = nullptr, *nnf2 = nullptr, *nnf_tmp = nullptr, *nnf_tmp2 = nullptr;
     float *cost1 = nullptr, *cost2 = nullptr;
     uint32_t* wmf_ws = nullptr;        // work lists + counters of the weighted median
+    bool flow_pending = false;         // eppm_compute_begin issued, eppm_compute_end not yet
     float *flow[kMaxLevels] = {}, *flow_tmp[kMaxLevels] = {};
     float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
     eppm_pm_rng* rng = nullptr;
@@ -544,15 +545,35 @@ extern "C" int eppm_compute_device(eppm_ctx* c, void* d_flow)
     return EPPM_OK;
 }
 
-extern "C" int eppm_compute(eppm_ctx* c, float* u, float* v)
+// compute_flow split in two so that a host thread can keep several contexts in flight: begin enqueues the whole
+// path and the device-to-host copy into the context's pinned buffer and returns; end waits and de-interleaves.
+extern "C" int eppm_compute_begin(eppm_ctx* c)
 {
-    if (!c || !u || !v) return set_err(EPPM_ERR_ARG, "eppm_compute: NULL argument");
+    if (!c) return set_err(EPPM_ERR_ARG, "eppm_compute_begin: NULL ctx");
     CHK(eppm_compute_device(c, nullptr));
     const size_t n = (size_t)c->h * c->w;
     HIPCHK(hipMemcpyAsync(c->h_flow, c->flow[0], n * 8, hipMemcpyDeviceToHost, c->stream));    // driver :299
+    c->flow_pending = true;
+    return EPPM_OK;
+}
+
+extern "C" int eppm_compute_end(eppm_ctx* c, float* u, float* v)
+{
+    if (!c || !u || !v) return set_err(EPPM_ERR_ARG, "eppm_compute_end: NULL argument");
+    if (!c->flow_pending) return set_err(EPPM_ERR_STATE, "eppm_compute_end without eppm_compute_begin");
+    HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->flow_pending = false;
+    const size_t n = (size_t)c->h * c->w;
     for (size_t i = 0; i < n; i++) { u[i] = c->h_flow[2 * i]; v[i] = c->h_flow[2 * i + 1]; }    // driver :302-306
     return EPPM_OK;
+}
+
+extern "C" int eppm_compute(eppm_ctx* c, float* u, float* v)
+{
+    if (!c || !u || !v) return set_err(EPPM_ERR_ARG, "eppm_compute: NULL argument");
+    CHK(eppm_compute_begin(c));
+    return eppm_compute_end(c, u, v);
 }
 
 extern "C" int eppm_synchronize(eppm_ctx* c)

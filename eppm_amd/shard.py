@@ -17,3 +17,24 @@ def run_pairs(engine, pairs, indices):
         engine.set_data(a, b)
         out[i] = engine.compute_flow()
     return out
+
+
+def run_pairs_pipelined(engines, pairs, indices):
+    """The same through several initialised engines of ONE GPU used round robin by one host thread: while engine k
+    computes pair i, the host stages pair i+1 into engine k+1 and collects pair i-1 -- the PCIe copies and the host-side
+    staging of one pair overlap the kernels of the others.  Returns {i: (u, v)}."""
+    if not engines:
+        raise ValueError("no engines")
+    out, busy = {}, [None] * len(engines)
+    for n, i in enumerate(indices):
+        k = n % len(engines)
+        if busy[k] is not None:
+            out[busy[k]] = engines[k].compute_flow_end()
+        a, b = pairs[i]
+        engines[k].set_data(a, b)
+        engines[k].compute_flow_begin()
+        busy[k] = i
+    for k, i in enumerate(busy):
+        if i is not None:
+            out[i] = engines[k].compute_flow_end()
+    return out

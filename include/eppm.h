@@ -81,6 +81,11 @@ int  eppm_set_images_device(eppm_ctx* ctx, const void* d_rgba1, const void* d_rg
 
 /* compute_flow (driver .cpp:217-306).  u, v: h*w floats each (host). Synchronous. */
 int  eppm_compute(eppm_ctx* ctx, float* u, float* v);
+/* The same in two halves, for a host thread that keeps several contexts in flight (PCIe copies of one pair overlap
+ * the kernels of another): begin enqueues the path and the device-to-host copy and returns at once; end waits for
+ * this context's stream and writes u, v.  eppm_set_images on a context waits for that context's previous work. */
+int  eppm_compute_begin(eppm_ctx* ctx);
+int  eppm_compute_end(eppm_ctx* ctx, float* u, float* v);
 /* Same, asynchronous on the context's stream; the interleaved float2 flow stays in HBM.
  * d_flow may be NULL (result kept in the context; fetch with eppm_get_plane("flow",0)). */
 int  eppm_compute_device(eppm_ctx* ctx, void* d_flow);

@@ -20,6 +20,31 @@ def test_round_robin_partition():
     assert pairs_for_rank(64, 3, 8) == list(range(3, 64, 8))
 
 
+def test_pipelined_runner_bookkeeping():
+    """run_pairs_pipelined on fake engines: every pair comes back once, with the result of ITS inputs, and an engine is
+    never given a new pair before its previous one was collected."""
+    from eppm_amd.shard import run_pairs_pipelined
+
+    class Fake:
+        def __init__(self):
+            self.cur, self.pending, self.log = None, False, []
+        def set_data(self, a, b):
+            assert not self.pending, "set_data while a flow is pending"
+            self.cur = (a, b)
+        def compute_flow_begin(self):
+            self.pending = True
+        def compute_flow_end(self):
+            assert self.pending
+            self.pending = False
+            return (self.cur[0] * 10, self.cur[1] * 10)
+
+    pairs = [(i, -i) for i in range(11)]
+    for k in (1, 2, 3, 5, 16):
+        out = run_pairs_pipelined([Fake() for _ in range(k)], pairs, [0, 2, 3, 4, 7, 8, 9, 10])
+        assert sorted(out) == [0, 2, 3, 4, 7, 8, 9, 10]
+        assert all(out[i] == (10 * i, -10 * i) for i in out)
+
+
 WORKER = textwrap.dedent("""
     import os, sys, time
     sys.path.insert(0, %r)

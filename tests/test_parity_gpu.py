@@ -343,6 +343,28 @@ def test_pyramid_depth(crop, levels):
         eppm_amd.EPPM(params=eppm_amd.Params(levels=9)).init(120, 160)
 
 
+def test_pipelined_host_boundary(crop, crop_stages):
+    """eppm_compute_begin / eppm_compute_end: three contexts kept in flight by one host thread return, for every pair, the
+    flow of the synchronous call; end without begin is an error."""
+    import eppm_amd
+    from eppm_amd import shard
+    a, b = crop
+    st = crop_stages
+    pairs = [(a, b), (b, a), (a, a), (a, b), (b, a), (a, b), (a, b)]
+    ref = eppm_amd.EPPM(); ref.init(120, 160)
+    want = shard.run_pairs(ref, pairs, range(len(pairs)))
+    eq(want[0][0], st["u"], "sync u"); eq(want[0][1], st["v"], "sync v")
+    engs = []
+    for _ in range(3):
+        e = eppm_amd.EPPM(); e.init(120, 160); engs.append(e)
+    got = shard.run_pairs_pipelined(engs, pairs, range(len(pairs)))
+    assert sorted(got) == list(range(len(pairs)))
+    for i in got:
+        eq(got[i][0], want[i][0], "pipelined u %d" % i); eq(got[i][1], want[i][1], "pipelined v %d" % i)
+    with pytest.raises(eppm_amd.EppmError):
+        engs[0].compute_flow_end()
+
+
 def test_device_entry_points_and_streams(crop, crop_stages):
     """eppm_set_images_device / eppm_compute_device (inputs resident in HBM, any pitch) give the same flow as the
     host-pointer entry points; contexts on separate streams can be in flight together."""

@@ -135,6 +135,27 @@ def test_level2_post(S, O, crop_stages):
     eq(S.nnf2flow(n2), O.nnf2flow(on2), "NNF -> flow with invalid pixels")
 
 
+def test_weighted_median_long_lists(S, O):
+    """A front that fills 4 pixels per launch from one valid column: the work list stays tens of thousands of entries
+    long for every launch (several append batches per workgroup once the grids shrink) and every launch fills pixels,
+    then the field reaches its fixed point and the remaining launches exit early."""
+    rng = np.random.default_rng(3)
+    h, w = 200, 256
+    img = O.rgb2rgba(rng.integers(90, 110, (h, w, 3), dtype=np.uint8))          # low contrast: non-zero bilateral weights
+    nnf = np.zeros((h, w), O.short2)
+    nnf["x"][:] = -10000; nnf["y"][:] = -10000
+    ys, xs = np.mgrid[0:h, 0:w]
+    nnf["x"][:, :2] = (xs[:, :2] + rng.integers(0, 4, (h, 2))).astype(np.int16)
+    nnf["y"][:, :2] = (ys[:, :2] + rng.integers(0, 4, (h, 2))).astype(np.int16)
+    for iters in (1, 7, 20):
+        got, want = S.weighted_median(nnf, img, iters, True), O.weighted_median(nnf, img, iters, True)
+        eq(got, want, "front after %d launches" % iters)
+    assert (want["x"] >= 0).sum() > (nnf["x"] >= 0).sum() * 10
+    # fixed point long before the last launch: a field that nothing can fill
+    dead = nnf.copy(); dead["x"][:] = -10000; dead["y"][:] = -10000
+    eq(S.weighted_median(dead, img, 20, True), dead, "nothing to fill")
+
+
 def test_c2f(S, O, crop_stages):
     st = crop_stages
     up = S.resize_flow(st["flow_L2"], st["arrH"][1], st["arrW"][1], 2.0)

@@ -444,9 +444,51 @@ void launch_pm_neighbor(const PmBatch& b, const float* lut, int R, hipStream_t s
 // pixels, the costs meet in LDS and wave 0 replays the reference's in-order strict-< selection.  The four
 // quarter-workgroups of a block draw the same numbers (cheap); only quarter 0 advances the stored state.
 // ---------------------------------------------------------------------------------------------------
+// RT = 9 / 17: the source samples of the workgroup's 16x4 pixels come from an LDS tile (16+2R)x(4+2R), loaded once,
+// clamped at load -- one LDS read per sample instead of a clamped address and a gather; RT = 0: any radius, source
+// samples gathered from the plane.
+template <int RT>
+__device__ __forceinline__ float search_patch_dist(const Planes& P, const PatchLut& L, int R, const float4* __restrict__ s_src, int TW,
+                                                   int tx, int ty, int x1, int y1, int x2, int y2)
+{
+    if (RT == 0) return patch_dist(P, L, R, x1, y1, x2, y2);
+    constexpr int S = RT + 1;
+    const int pitch16 = P.pitch << 4;
+    const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
+    const rgbf c2 = texel_rgb(texel_at(P.pk2, texel_off(pitch16, P.w, P.h, x2, y2)));
+    float cost_sum = 0.0f, weight_sum = 0.0f;
+    for (int ii = 0; ii < S; ii++) {
+        const int i = 2 * ii - RT;
+        const unsigned r2 = __umul24((unsigned)iclamp(y2 + i, 0, P.h - 1), (unsigned)pitch16);
+        const float4* __restrict__ srow = s_src + (ty + 2 * ii) * TW + tx;
+        for (int j0 = 0; j0 < S; j0 += 5) {
+            float4 q1[5], q2[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int jj = min(j0 + k, S - 1);
+                q1[k] = srow[2 * jj];
+                q2[k] = texel_at(P.pk2, r2 + ((unsigned)iclamp(x2 + 2 * jj - RT, 0, P.w - 1) << 4));
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                if (j0 + k < S) {
+                    float ct, wt;
+                    patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.cnx, ct, wt);
+                    cost_sum += ct;
+                    weight_sum += wt;
+                }
+            }
+        }
+    }
+    return cost_sum / weight_sum;
+}
+
+template <int RT>
 __global__ __launch_bounds__(512) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
                                                           int search_range, int G)
 {
+    constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT, TH = (RT == 0) ? 1 : 4 + 2 * RT;
+    __shared__ float4 s_src[TW * TH];
     __shared__ PatchLut L;
     __shared__ int16_t s_rand[8 * 512];
     __shared__ float s_cost[8][64];
@@ -480,8 +522,15 @@ __global__ __launch_bounds__(512) void k_pm_random_search(PmBatch B, PmRngDev rn
             store_state(pr.rng_work_next + so, st);
         }
     }
-    __syncthreads();
     const Planes P = to_dev(pr.P);
+    if (RT != 0) {
+        const int x0 = blockIdx.x * kBlock - RT, y0 = tile_y * kBlock + quarter * 4 - RT;
+        for (int t = tid; t < TW * TH; t += blockDim.x) {
+            const int sy = iclamp(y0 + t / TW, 0, P.h - 1), sx = iclamp(x0 + t % TW, 0, P.w - 1);
+            s_src[t] = P.pk1[(unsigned)(sy * P.pitch + sx)];
+        }
+    }
+    __syncthreads();
     const int lane = tid & 63, k = tid >> 6;                     // wave k = guess k
     const int pix = quarter * 64 + lane;                         // row-major index inside the 16x16 block
     const int x = blockIdx.x * kBlock + (pix & 15), y = tile_y * kBlock + (pix >> 4);
@@ -499,7 +548,7 @@ __global__ __launch_bounds__(512) void k_pm_random_search(PmBatch B, PmRngDev rn
         const int ymin = max(by - mag, 0), ymax = min(by + mag + 1, P.h + 1);
         const int gx = (int)(int16_t)((uint32_t)xmin + rdn1 % (uint32_t)(xmax - xmin));
         const int gy = (int)(int16_t)((uint32_t)ymin + rdn2 % (uint32_t)(ymax - ymin));
-        s_cost[k][lane] = patch_dist(P, L, R, x, y, gx, gy);
+        s_cost[k][lane] = search_patch_dist<RT>(P, L, R, s_src, TW, lane & 15, lane >> 4, x, y, gx, gy);
         s_guess[k][lane] = (gx & 0xffff) | (gy << 16);
     }
     __syncthreads();
@@ -522,7 +571,9 @@ void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float*
                              hipStream_t s)
 {
     dim3 grid(rng.gx, rng.gy * 4, b.n), block(64 * num_guess);
-    hipLaunchKernelGGL(k_pm_random_search, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+    if (R == 9) hipLaunchKernelGGL(k_pm_random_search<9>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+    else if (R == 17) hipLaunchKernelGGL(k_pm_random_search<17>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+    else hipLaunchKernelGGL(k_pm_random_search<0>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
 }
 
 }  // namespace eppm

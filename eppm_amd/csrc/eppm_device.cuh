@@ -2,7 +2,7 @@
 //
 // The float formulas here are the product's own statement of the arithmetic that the CPU oracle
 // (oracle/eppm_oracle.c) restates from the reference; the two are written independently and must
-// agree bit for bit (tests/test_arith_gpu.py).  Everything is compiled with -ffp-contract=off:
+// agree bit for bit (tests/test_parity_gpu.py: test_fast_exp_bits, test_div_const_bits and every stage test).  Everything is compiled with -ffp-contract=off:
 // the only fused operations are the explicit __builtin_fmaf calls below.
 #pragma once
 

@@ -63,6 +63,20 @@ KERNEL(k_add3,     "v_add3_u32 %4, %4, %5, %4\n")
 KERNEL(k_sub_e64,  "v_sub_f32_e64 %0, %1, |%0|\n")
 KERNEL(k_mov,      "v_mov_b32_e32 %0, %1\n")
 
+// packed fp32: two independent IEEE operations per lane in one instruction (64-bit register pairs)
+#define KERNEL_PK(name, asmtext)                                                               \
+    __global__ __launch_bounds__(256) void name(float* out, float a, float b, int n)          \
+    {                                                                                          \
+        double d0 = a + threadIdx.x, d1 = b, d2 = a * b;                                       \
+        for (int it = 0; it < n; it++) {                                                      \
+            asm volatile(R32(asmtext) : "+v"(d0), "+v"(d1), "+v"(d2));                        \
+        }                                                                                      \
+        out[blockIdx.x * 256 + threadIdx.x] = (float)(d0 + d1 + d2);                          \
+    }
+KERNEL_PK(k_pk_add, "v_pk_add_f32 %0, %1, %0\n")
+KERNEL_PK(k_pk_mul, "v_pk_mul_f32 %0, %1, %0\n")
+KERNEL_PK(k_pk_fma, "v_pk_fma_f32 %0, %1, %2, %0\n")
+
 typedef void (*kern_t)(float*, float, float, int);
 
 int main()
@@ -84,6 +98,7 @@ int main()
         {"v_bfe_u32", k_bfe}, {"v_perm_b32", k_perm}, {"v_cmp_lt_f32 vcc", k_cmp}, {"v_cvt_f32_i32", k_cvt_f_i}, {"v_cvt_f32_ubyte0", k_cvt_ub},
         {"v_mad_u32_u24", k_mad24}, {"v_floor_f32", k_floor}, {"v_fract_f32", k_fract}, {"v_mul_lo_u32", k_mul_lo}, {"v_add3_u32", k_add3},
         {"v_sub_f32_e64 |abs|", k_sub_e64}, {"v_mov_b32", k_mov},
+        {"v_pk_add_f32 (2 adds)", k_pk_add}, {"v_pk_mul_f32 (2 muls)", k_pk_mul}, {"v_pk_fma_f32 (2 fmas)", k_pk_fma},
     };
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);

@@ -74,6 +74,13 @@ __device__ __forceinline__ rgbf unpack_rgb(uint32_t p)
 }
 
 __device__ __forceinline__ int iclamp(int v, int lo, int hi) { return min(max(v, lo), hi); }
+// v_med3_i32: one instruction where min(max()) compiles to two (same result for lo <= hi)
+__device__ __forceinline__ int med3i(int v, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
 
 __device__ __forceinline__ float max_abs_diff(const rgbf a, const rgbf b)
 {
@@ -124,6 +131,11 @@ __device__ __forceinline__ unsigned texel_off(int pitch16, int w, int h, int x, 
     x = iclamp(x, 0, w - 1);
     y = iclamp(y, 0, h - 1);
     return __umul24((unsigned)y, (unsigned)pitch16) + ((unsigned)x << 4);
+}
+// the same with the column in byte units (x16 = 16*x, wmax16 = 16*(w-1)): add, 2 x v_med3, v_mad_u32_u24
+__device__ __forceinline__ unsigned texel_off16(int pitch16, int wmax16, int hmax, int x16, int y)
+{
+    return __umul24((unsigned)med3i(y, 0, hmax), (unsigned)pitch16) + (unsigned)med3i(x16, 0, wmax16);
 }
 // same for the plain RGBA planes (guide image of the WMF / hole filling)
 __device__ __forceinline__ uint32_t tex_rgba(const uint32_t* img, int pitch, int w, int h, int x, int y)

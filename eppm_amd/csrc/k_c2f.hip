@@ -164,14 +164,6 @@ template <int R> __device__ __forceinline__ const C2fTables<R>& c2f_tables();
 template <> __device__ __forceinline__ const C2fTables<9>& c2f_tables<9>() { return c2f_tab9; }
 template <> __device__ __forceinline__ const C2fTables<17>& c2f_tables<17>() { return c2f_tab17; }
 
-// v_med3_i32: one half-rate instruction where min(max()) compiles to two
-__device__ __forceinline__ int med3i(int v, int lo, int hi)
-{
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
-    return r;
-}
-
 template <int R, int PASS>
 __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLutT<R + 1>& L, const float4* __restrict__ s_src,
                                          int TW, int tx, int ty, int cx16, int wmax16, int ccy, const rgbf c1, const rgbf (&c2)[3], float (&run)[3])

@@ -175,7 +175,14 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
     }
     __syncthreads();   // LUT ready
     const int t0 = r * CH;
-    const int pitch16 = P.pitch << 4;
+    const int pitch16 = P.pitch << 4, wmax16 = (P.w - 1) << 4;
+    int dj16[CH], di_[CH];                 // this lane's sample offsets (column in bytes): the same at every step
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int t = min(t0 + k, NS - 1);
+        di_[k] = 2 * (t / S) - R;
+        dj16[k] = (2 * (t % S) - R) * 16;
+    }
     for (int s = 0; s < L_; s++) {
         if (active && s < count) {
             const int x = IS_ROW ? i : line, y = IS_ROW ? line : i;
@@ -199,10 +206,8 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
                 float4 q1[GB], q2[GB];
 #pragma unroll
                 for (int k = 0; k < GB; k++) {
-                    const int t = min(t0 + q0 + k, NS - 1);
-                    const int di = 2 * (t / S) - R, dj = 2 * (t % S) - R;
-                    q1[k] = texel_at(P.pk1, texel_off(pitch16, P.w, P.h, x + dj, y + di));
-                    q2[k] = texel_at(P.pk2, texel_off(pitch16, P.w, P.h, px + dj, py + di));
+                    q1[k] = texel_at(P.pk1, texel_off16(pitch16, wmax16, P.h - 1, (x << 4) + dj16[q0 + k], y + di_[q0 + k]));
+                    q2[k] = texel_at(P.pk2, texel_off16(pitch16, wmax16, P.h - 1, (px << 4) + dj16[q0 + k], py + di_[q0 + k]));
                 }
 #pragma unroll
                 for (int k = 0; k < GB; k++) {

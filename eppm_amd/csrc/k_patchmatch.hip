@@ -489,7 +489,7 @@ __device__ __forceinline__ float search_patch_dist(const Planes& P, const PatchL
 }
 
 template <int RT>
-__global__ __launch_bounds__(512) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
+__global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
                                                           int search_range, int G)
 {
     constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT, TH = (RT == 0) ? 1 : 4 + 2 * RT;
@@ -498,6 +498,7 @@ __global__ __launch_bounds__(512) void k_pm_random_search(PmBatch B, PmRngDev rn
     __shared__ int16_t s_rand[8 * 512];
     __shared__ float s_cost[8][64];
     __shared__ int s_guess[8][64];
+    __shared__ uint32_t s_state[64 * 6];
     const PmProblem& pr = B.p[blockIdx.z];
     const int tid = threadIdx.x;
     const int tile_y = blockIdx.y >> 2, quarter = blockIdx.y & 3;
@@ -508,8 +509,24 @@ __global__ __launch_bounds__(512) void k_pm_random_search(PmBatch B, PmRngDev rn
         Xorwow st = load_state(pr.rng_work + so);
         const int base = rng.per_lane * tid;
         for (int q = 0; q < rng.per_lane; q++) s_rand[base + q] = (int16_t)xorwow_next(st);   // short(rdn), :1550-1551
+        if (quarter == 0) store_state(s_state + tid * 6, st);     // advanced by wave G while the guesses are evaluated
+    }
+    const Planes P = to_dev(pr.P);
+    if (RT != 0) {
+        const int x0 = blockIdx.x * kBlock - RT, y0 = tile_y * kBlock + quarter * 4 - RT;
+        for (int t = tid; t < TW * TH; t += blockDim.x) {
+            const int sy = iclamp(y0 + t / TW, 0, P.h - 1), sx = iclamp(x0 + t % TW, 0, P.w - 1);
+            s_src[t] = P.pk1[(unsigned)(sy * P.pitch + sx)];
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, k = tid >> 6;                     // wave k = guess k; wave G advances the RNG states
+    if (k == G) {
         if (quarter == 0) {
-            // jump over the other 63 lanes' draws: v <- v * skip_mat over GF(2); Weyl counter by multiplication
+            // jump over the other 63 lanes' draws: v <- v * skip_mat over GF(2); Weyl counter by multiplication.
+            // Off the critical path: this wave has nothing else to do, the other G waves are evaluating guesses.
+            const size_t so = ((size_t)block_id * 64 + lane) * 6;
+            Xorwow st = load_state(s_state + lane * 6);
             const uint32_t v[5] = {st.v0, st.v1, st.v2, st.v3, st.v4};
             uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
 #pragma unroll
@@ -527,19 +544,9 @@ __global__ __launch_bounds__(512) void k_pm_random_search(PmBatch B, PmRngDev rn
             store_state(pr.rng_work_next + so, st);
         }
     }
-    const Planes P = to_dev(pr.P);
-    if (RT != 0) {
-        const int x0 = blockIdx.x * kBlock - RT, y0 = tile_y * kBlock + quarter * 4 - RT;
-        for (int t = tid; t < TW * TH; t += blockDim.x) {
-            const int sy = iclamp(y0 + t / TW, 0, P.h - 1), sx = iclamp(x0 + t % TW, 0, P.w - 1);
-            s_src[t] = P.pk1[(unsigned)(sy * P.pitch + sx)];
-        }
-    }
-    __syncthreads();
-    const int lane = tid & 63, k = tid >> 6;                     // wave k = guess k
     const int pix = quarter * 64 + lane;                         // row-major index inside the 16x16 block
     const int x = blockIdx.x * kBlock + (pix & 15), y = tile_y * kBlock + (pix >> 4);
-    const bool inimg = (x < P.w && y < P.h);
+    const bool inimg = (k < G) && (x < P.w && y < P.h);
     const int nidx = y * B.npitch + x, cidx = y * B.cpitch + x;
     int bx = 0, by = 0;
     if (inimg) {
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(512) void k_pm_random_search(PmBatch B, PmRngDev rn
 void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float* lut, int R, int search_range, int num_guess,
                              hipStream_t s)
 {
-    dim3 grid(rng.gx, rng.gy * 4, b.n), block(64 * num_guess);
+    dim3 grid(rng.gx, rng.gy * 4, b.n), block(64 * (num_guess + 1));      // + the wave that advances the RNG states
     if (R == 9) hipLaunchKernelGGL(k_pm_random_search<9>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else if (R == 17) hipLaunchKernelGGL(k_pm_random_search<17>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else hipLaunchKernelGGL(k_pm_random_search<0>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);

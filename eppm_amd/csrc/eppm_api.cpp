@@ -200,6 +200,7 @@ struct eppm_ctx {
     uint32_t* wmf_ws = nullptr;        // work lists + counters of the weighted median
     bool flow_pending = false;         // eppm_compute_begin issued, eppm_compute_end not yet
     float *flow[kMaxLevels] = {}, *flow_tmp[kMaxLevels] = {};
+    float* c2f_cost9[kMaxLevels] = {};  // 9 candidate costs per pixel, only for levels whose refine launch is split by column
     float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
     eppm_pm_rng* rng = nullptr;
     uint8_t* d_rgb = nullptr;           // staging for host RGB input
@@ -253,7 +254,7 @@ extern "C" int eppm_destroy(eppm_ctx* c)
     for (int i = 0; i < kMaxLevels; i++) {
         (void)hipFree(c->img1[i]); (void)hipFree(c->img2[i]); (void)hipFree(c->tmpu[i]);
         (void)hipFree(c->cen1[i]); (void)hipFree(c->cen2[i]); (void)hipFree(c->pk1[i]); (void)hipFree(c->pk2[i]);
-        (void)hipFree(c->flow[i]); (void)hipFree(c->flow_tmp[i]);
+        (void)hipFree(c->flow[i]); (void)hipFree(c->flow_tmp[i]); (void)hipFree(c->c2f_cost9[i]);
     }
     (void)hipFree(c->nnf1); (void)hipFree(c->nnf2); (void)hipFree(c->nnf_tmp); (void)hipFree(c->nnf_tmp2);
     (void)hipFree(c->cost1); (void)hipFree(c->cost2); (void)hipFree(c->wmf_ws);
@@ -290,6 +291,7 @@ static int ctx_alloc(eppm_ctx* c)
         const size_t n = (size_t)c->W[i] * c->H[i];
         HIPCHK(hipMalloc((void**)&c->flow[i], n * 8));
         HIPCHK(hipMalloc((void**)&c->flow_tmp[i], n * 8));
+        if (i < c->nl - 1 && c2f_refine_wants_split(c->W[i], c->H[i], c->prm.patch_r)) HIPCHK(hipMalloc((void**)&c->c2f_cost9[i], n * 36));
     }
     if (c->raw_pitch != c->ipitch[0]) return set_err(EPPM_ERR_HIP, "unexpected pitch mismatch");
     const int L = c->nl - 1;
@@ -528,7 +530,7 @@ extern "C" int eppm_compute_device(eppm_ctx* c, void* d_flow)
         launch_resize_flow(c->flow[l], c->H[l], c->W[l], c->flow[l + 1], c->H[l + 1], c->W[l + 1], 2.0f, 2.0f, s);   // refine :1082-1083
         stage_end(c, c->ev);
         stage_begin(c, c->ev, rf_names[l]);
-        launch_c2f_refine(planes(c, l, false), c->flow[l], c->lut_pm, c->prm.patch_r, s);                    // refine :1086
+        launch_c2f_refine(planes(c, l, false), c->flow[l], c->lut_pm, c->prm.patch_r, c->c2f_cost9[l], s);   // refine :1086
         stage_end(c, c->ev);
         stage_begin(c, c->ev, bl_names[l]);
         launch_flow_blf(c->flow_tmp[l], c->flow[l], c->img1[l], (int)(c->ipitch[l] / 4), c->W[l], c->H[l], c->W[l], c->lut_blf, s);  // driver :280
@@ -1024,7 +1026,7 @@ extern "C" void baoCudaBLFCostFilterRefine(eppm_float2* d_flow_vec, eppm_uchar4*
     PlanesH P;
     g_launch_status = mk_planes(ds, &P, d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch);
     if (g_launch_status != EPPM_OK) return;
-    launch_c2f_refine(P, (float*)d_flow_vec, ds->lut_pm, g_prm.patch_r, g_stream);
+    launch_c2f_refine(P, (float*)d_flow_vec, ds->lut_pm, g_prm.patch_r, nullptr, g_stream);
     g_launch_status = finish();
 }
 
@@ -1040,7 +1042,7 @@ extern "C" void baoCudaBLF_C2F(eppm_float2** pFlowPyr, eppm_uchar4** pImgPyr1, e
     PlanesH P;
     g_launch_status = mk_planes(ds, &P, pImgPyr1[l], pImgPyr2[l], pCensusPyr1[l], pCensusPyr2[l], arrW[l], arrH[l], arrPitchUchar4[l], arrPitchUchar1[l]);
     if (g_launch_status != EPPM_OK) return;
-    launch_c2f_refine(P, (float*)pFlowPyr[l], ds->lut_pm, g_prm.patch_r, g_stream);                                                            // refine :1086
+    launch_c2f_refine(P, (float*)pFlowPyr[l], ds->lut_pm, g_prm.patch_r, nullptr, g_stream);                                                          // refine :1086
     g_launch_status = finish();
 }
 

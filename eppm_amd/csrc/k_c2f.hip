@@ -235,8 +235,12 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
 #define EPPM_C2F_WAVES_MIN 2
 #endif
 #define EPPM_C2F_OCC __attribute__((amdgpu_waves_per_eu(EPPM_C2F_WAVES_MIN, EPPM_C2F_WAVES)))     // (min, max): radius 17 only fits 2
-template <int R>
-__global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH Ph, float* __restrict__ flow, const float* __restrict__ lut)
+// SPLIT: a launch with few tiles (level 1 of a 1024x436 pair: 448 tiles = 1.75 waves per SIMD) does not fill the chip
+// and runs latency bound.  Then every candidate column m gets its own workgroup (3x the waves); the 9 costs of a pixel
+// go to a scratch plane and k_c2f_select replays the reference's candidate loop.  Same costs, same selection order.
+template <int R, bool SPLIT>
+__global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH Ph, float* __restrict__ flow, const float* __restrict__ lut,
+                                                                       float* __restrict__ cost9)
 {
     constexpr int TWU = kBlock + 2 * R;                 // used tile width
     // row stride padded to a multiple of 16 texels (256 B): a ds_read_b128 wave access is served in groups made
@@ -253,8 +257,10 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
     // share their R-pixel halos and their target windows -- hit the same L2 (speed only, never correctness).
     const int tiles_x = (P.w + kBlock - 1) / kBlock, tiles = tiles_x * ((P.h + kBlock - 1) / kBlock);
     const int per_xcd = (tiles + 7) / 8;
-    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= tiles) return;
+    const int slot = SPLIT ? (blockIdx.x >> 3) / 3 : (blockIdx.x >> 3);      // the three column workgroups of a tile share an XCD
+    const int m_only = SPLIT ? (blockIdx.x >> 3) % 3 : -1;
+    const int tile = (blockIdx.x & 7) * per_xcd + slot;
+    if (slot >= per_xcd || tile >= tiles) return;
     const int x0 = (tile % tiles_x) * kBlock, y0 = (tile / tiles_x) * kBlock;
     for (int t = tid; t < TWU * TWU; t += 256) {
         const int ry = t / TWU, rx = t % TWU;
@@ -266,8 +272,10 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
     if (x >= P.w || y >= P.h) return;
     const float fvx = flow[(y * P.w + x) * 2], fvy = flow[(y * P.w + x) * 2 + 1];
     if (fvx > kUnknownFlowThresh || fvy > kUnknownFlowThresh) {
-        flow[(y * P.w + x) * 2] = 0.0f;
-        flow[(y * P.w + x) * 2 + 1] = 0.0f;
+        if (!SPLIT) {
+            flow[(y * P.w + x) * 2] = 0.0f;
+            flow[(y * P.w + x) * 2 + 1] = 0.0f;
+        }
         return;
     }
     const int ccx = (int)(int16_t)(f2short(fvx) + x);
@@ -277,6 +285,7 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
     float min_cost = 999999;
 #pragma unroll 1
     for (int m = 0; m < 3; m++) {                    // x offset outer, as the reference's candidate loop (kernel.cu:2028)
+        if (SPLIT && m != m_only) continue;
         const int cx = (int)(int16_t)(ccx + m - 1);
         if (cx < 0 || cx >= P.w) continue;           // every candidate of this column is skipped (:2030)
         rgbf c2[3];
@@ -288,6 +297,11 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
         c2f_pass<R, 2>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
         c2f_pass<R, 1>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
         c2f_pass<R, 0>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+        if (SPLIT) {
+#pragma unroll
+            for (int n = 0; n < 3; n++) cost9[(size_t)(y * P.w + x) * 9 + m * 3 + n] = run[n];
+            continue;
+        }
 #pragma unroll
         for (int n = 0; n < 3; n++) {
             const int cy = (int)(int16_t)(ccy + n - 1);
@@ -296,18 +310,63 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
             if (cv < min_cost) { min_cost = cv; bx = cx; by = cy; }
         }
     }
+    if (SPLIT) return;
     flow[(y * P.w + x) * 2] = (float)(bx - x);
     flow[(y * P.w + x) * 2 + 1] = (float)(by - y);
 }
 
-void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, hipStream_t s)
+// the candidate loop of kernel.cu:2028-2040 over the 9 costs written by the split launch
+__global__ __launch_bounds__(256) void k_c2f_select(float* __restrict__ flow, const float* __restrict__ cost9, int w, int h)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const float fvx = flow[(y * w + x) * 2], fvy = flow[(y * w + x) * 2 + 1];
+    if (fvx > kUnknownFlowThresh || fvy > kUnknownFlowThresh) {
+        flow[(y * w + x) * 2] = 0.0f;
+        flow[(y * w + x) * 2 + 1] = 0.0f;
+        return;
+    }
+    const int ccx = (int)(int16_t)(f2short(fvx) + x);
+    const int ccy = (int)(int16_t)(f2short(fvy) + y);
+    int bx = ccx, by = ccy;
+    float min_cost = 999999;
+    for (int m = 0; m < 3; m++) {
+        const int cx = (int)(int16_t)(ccx + m - 1);
+        if (cx < 0 || cx >= w) continue;
+        for (int n = 0; n < 3; n++) {
+            const int cy = (int)(int16_t)(ccy + n - 1);
+            if (cy < 0 || cy >= h) continue;
+            const float cv = cost9[(size_t)(y * w + x) * 9 + m * 3 + n];
+            if (cv < min_cost) { min_cost = cv; bx = cx; by = cy; }
+        }
+    }
+    flow[(y * w + x) * 2] = (float)(bx - x);
+    flow[(y * w + x) * 2 + 1] = (float)(by - y);
+}
+
+bool c2f_refine_wants_split(int w, int h, int R)
+{
+    const int tiles = ((w + kBlock - 1) / kBlock) * ((h + kBlock - 1) / kBlock);
+    return (R == 9 || R == 17) && tiles * 4 < 3 * 1024;          // fewer than 3 waves per SIMD on 256 CUs
+}
+
+// cost9: scratch of 9 floats per pixel, or NULL (never split)
+void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, float* cost9, hipStream_t s)
 {
     dim3 grid((P.w + kBlock - 1) / kBlock, (P.h + kBlock - 1) / kBlock), block(kBlock, kBlock);
     const int tiles = grid.x * grid.y;
-    dim3 grid1(((tiles + 7) / 8) * 8);           // 1-D, padded so every XCD gets the same number of slots
+    const int per_xcd = (tiles + 7) / 8;
+    dim3 grid1(per_xcd * 8);                     // 1-D, padded so every XCD gets the same number of slots
     const bool table_ok = (P.w + R < 32764) && (P.h + R < 32764);     // range of the offset-table identity (c2f_pass)
-    if (R == 9 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<9>), grid1, block, 0, s, P, flow, lut);
-    else if (R == 17 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<17>), grid1, block, 0, s, P, flow, lut);
+    if (cost9 && table_ok && c2f_refine_wants_split(P.w, P.h, R)) {
+        dim3 grid3(per_xcd * 3 * 8);
+        if (R == 9) hipLaunchKernelGGL((k_c2f_refine_tiled<9, true>), grid3, block, 0, s, P, flow, lut, cost9);
+        else hipLaunchKernelGGL((k_c2f_refine_tiled<17, true>), grid3, block, 0, s, P, flow, lut, cost9);
+        hipLaunchKernelGGL(k_c2f_select, dim3((P.w + 63) / 64, (P.h + 3) / 4), dim3(64, 4), 0, s, flow, cost9, P.w, P.h);
+        return;
+    }
+    if (R == 9 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<9, false>), grid1, block, 0, s, P, flow, lut, (float*)nullptr);
+    else if (R == 17 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<17, false>), grid1, block, 0, s, P, flow, lut, (float*)nullptr);
     else hipLaunchKernelGGL(k_c2f_refine, grid, block, 0, s, P, flow, lut, R);
 }
 

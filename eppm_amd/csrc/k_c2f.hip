@@ -380,12 +380,16 @@ void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, f
 // distance is ~100, the exponent -2.5e7 and fast_exp returns exactly 0, so they add 0 * flow = 0 and 0 to the
 // sums -- no validity flag, no divergent branch (unknown flows are the finite marker 1e10, never inf).
 // ---------------------------------------------------------------------------------------------------
-constexpr int BT_W = 32, BT_H = 16, BR = kBlfRadius, BTW = BT_W + 2 * BR, BTH = BT_H + 2 * BR;
+// PPL = pixels per lane: 2 (32x16 tile) when the launch fills the chip, 1 (32x8 tile, twice the waves) when it does not
+// (level 1 of a 1024x436 pair: 0.85 waves per SIMD at two pixels per lane).
+constexpr int BT_W = 32, BR = kBlfRadius, BTW = BT_W + 2 * BR;
 
+template <int PPL>
 __global__ __launch_bounds__(256) void k_flow_blf(float* __restrict__ out, const float* __restrict__ in,
                                                   const uint32_t* __restrict__ img, int ipitch, int w, int h, int fpitch,
                                                   const float* __restrict__ blf_lut)
 {
+    constexpr int BT_H = 8 * PPL, BTH = BT_H + 2 * BR;
     __shared__ float4 s_t[BTH * BTW];          // r, g, b (unorm), flow x
     __shared__ float s_fy[BTH * BTW];
     __shared__ float s_lut[BR + 1];
@@ -408,13 +412,13 @@ __global__ __launch_bounds__(256) void k_flow_blf(float* __restrict__ out, const
         s_fy[t] = fy;
     }
     __syncthreads();
-    const int x = x0 + threadIdx.x, ya = y0 + 2 * threadIdx.y;          // pixels (x, ya) and (x, ya + 1)
+    const int x = x0 + threadIdx.x, ya = y0 + PPL * threadIdx.y;        // pixels (x, ya) and, PPL = 2, (x, ya + 1)
     if (x >= w || ya >= h) return;
-    const bool has_b = ya + 1 < h;
+    const bool has_b = (PPL == 2) && (ya + 1 < h);
     const rgbf ca = unpack_rgb(img[ya * ipitch + x]);
     const rgbf cb = unpack_rgb(img[(has_b ? ya + 1 : ya) * ipitch + x]);
     float nxa = 0.f, nya = 0.f, wa = 0.f, nxb = 0.f, nyb = 0.f, wb = 0.f;
-    const int base = (2 * threadIdx.y) * BTW + threadIdx.x;
+    const int base = (PPL * threadIdx.y) * BTW + threadIdx.x;
     // tap rows ya-10 .. ya+11: row 0 serves only the upper pixel, row 21 only the lower one, rows 1..20 both
     auto tap_row = [&](int r, auto use_a, auto use_b) {
         const float gya = use_a ? s_lut[abs(r - BR)] : 0.0f;
@@ -446,10 +450,15 @@ __global__ __launch_bounds__(256) void k_flow_blf(float* __restrict__ out, const
             }
         }
     };
-    tap_row(0, std::true_type{}, std::false_type{});
+    if (PPL == 2) {
+        tap_row(0, std::true_type{}, std::false_type{});
 #pragma unroll 1
-    for (int r = 1; r <= 2 * BR; r++) tap_row(r, std::true_type{}, std::true_type{});
-    tap_row(2 * BR + 1, std::false_type{}, std::true_type{});
+        for (int r = 1; r <= 2 * BR; r++) tap_row(r, std::true_type{}, std::true_type{});
+        tap_row(2 * BR + 1, std::false_type{}, std::true_type{});
+    } else {
+#pragma unroll 1
+        for (int r = 0; r <= 2 * BR; r++) tap_row(r, std::true_type{}, std::false_type{});
+    }
     {
         const int ci = base + BR * BTW + BR;
         float ox = s_t[ci].w, oy = s_fy[ci];
@@ -468,8 +477,13 @@ __global__ __launch_bounds__(256) void k_flow_blf(float* __restrict__ out, const
 void launch_flow_blf(float* out, const float* in, const uint32_t* img, int ipitch, int w, int h, int flow_pitch,
                      const float* blf_lut, hipStream_t s)
 {
-    dim3 block(BT_W, BT_H / 2), grid((w + BT_W - 1) / BT_W, (h + BT_H - 1) / BT_H);
-    hipLaunchKernelGGL(k_flow_blf, grid, block, 0, s, out, in, img, ipitch, w, h, flow_pitch, blf_lut);
+    dim3 block(BT_W, 8);
+    const int wgs2 = ((w + BT_W - 1) / BT_W) * ((h + 15) / 16);
+    if (wgs2 * 4 >= 2 * 1024) {                   // at least two waves per SIMD with two pixels per lane
+        hipLaunchKernelGGL(k_flow_blf<2>, dim3((w + BT_W - 1) / BT_W, (h + 15) / 16), block, 0, s, out, in, img, ipitch, w, h, flow_pitch, blf_lut);
+    } else {
+        hipLaunchKernelGGL(k_flow_blf<1>, dim3((w + BT_W - 1) / BT_W, (h + 7) / 8), block, 0, s, out, in, img, ipitch, w, h, flow_pitch, blf_lut);
+    }
 }
 
 }  // namespace eppm

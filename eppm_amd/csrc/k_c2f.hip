@@ -380,8 +380,7 @@ void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, f
 // distance is ~100, the exponent -2.5e7 and fast_exp returns exactly 0, so they add 0 * flow = 0 and 0 to the
 // sums -- no validity flag, no divergent branch (unknown flows are the finite marker 1e10, never inf).
 // ---------------------------------------------------------------------------------------------------
-// PPL = pixels per lane: 2 (32x16 tile) when the launch fills the chip, 1 (32x8 tile, twice the waves) when it does not
-// (level 1 of a 1024x436 pair: 0.85 waves per SIMD at two pixels per lane).
+// PPL = pixels per lane: 2 (32x16 tile) for large launches, 1 (32x8 tile, twice the waves) otherwise, see launch_flow_blf.
 constexpr int BT_W = 32, BR = kBlfRadius, BTW = BT_W + 2 * BR;
 
 template <int PPL>
@@ -479,7 +478,9 @@ void launch_flow_blf(float* out, const float* in, const uint32_t* img, int ipitc
 {
     dim3 block(BT_W, 8);
     const int wgs2 = ((w + BT_W - 1) / BT_W) * ((h + 15) / 16);
-    if (wgs2 * 4 >= 2 * 1024) {                   // at least two waves per SIMD with two pixels per lane
+    // two pixels per lane halve the LDS traffic but double the work quantum: they pay from about 8 workgroups per CU
+    // (1920x1080: 0.96 vs 1.03 ms); below that the finer quantum balances the 256 CUs better (1024x436: 0.25 vs 0.27 ms)
+    if (wgs2 >= 8 * 256) {
         hipLaunchKernelGGL(k_flow_blf<2>, dim3((w + BT_W - 1) / BT_W, (h + 15) / 16), block, 0, s, out, in, img, ipitch, w, h, flow_pitch, blf_lut);
     } else {
         hipLaunchKernelGGL(k_flow_blf<1>, dim3((w + BT_W - 1) / BT_W, (h + 7) / 8), block, 0, s, out, in, img, ipitch, w, h, flow_pitch, blf_lut);

@@ -100,6 +100,9 @@ void launch_outlier(int16_t* nnf_out, float* cost, const int16_t* nnf_in, int w,
 // ---------------------------------------------------------------------------------------------------
 constexpr int WR = kWmfRadius, WN = (2 * WR + 1) * (2 * WR + 1);   // 4, 81
 constexpr uint32_t kCopyOnly = 0x80000000u;
+#ifndef EPPM_WMF_MAX_BLOCKS
+#define EPPM_WMF_MAX_BLOCKS 1024
+#endif
 constexpr uint32_t kWmfBatch = 256;      // list entries a workgroup processes between two appends
 
 __global__ __launch_bounds__(256) void k_wmf_build_list(const int16_t* __restrict__ nnf, int npitch, int w, int h, int only_occ,
@@ -253,7 +256,7 @@ int16_t* launch_wmf(int16_t* buf_a, int16_t* buf_b, const uint32_t* img, int ipi
     hipLaunchKernelGGL(k_wmf_build_list, grid, block, 0, s, buf_a, nnf_pitch, w, h, only_occlusion, list0, counts);
     const int pixels = w * h;
     int nblocks0 = (pixels + 3) / 4;
-    if (nblocks0 > 1024) nblocks0 = 1024;
+    if (nblocks0 > EPPM_WMF_MAX_BLOCKS) nblocks0 = EPPM_WMF_MAX_BLOCKS;
     int16_t *in = buf_a, *out = buf_b;
     for (int i = 0; i < num_iter; i++) {
         // occlusion-only lists shrink fast (most pixels are filled by the first launches): later launches get a

@@ -200,7 +200,7 @@ struct eppm_ctx {
     uint32_t* wmf_ws = nullptr;        // work lists + counters of the weighted median
     bool flow_pending = false;         // eppm_compute_begin issued, eppm_compute_end not yet
     float *flow[kMaxLevels] = {}, *flow_tmp[kMaxLevels] = {};
-    float* c2f_cost9[kMaxLevels] = {};  // 9 candidate costs per pixel, only for levels whose refine launch is split by column
+    float* c2f_cost9[kMaxLevels] = {};  // 9 candidates x 4 passes costs per pixel, only for levels whose refine launch is split
     float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
     eppm_pm_rng* rng = nullptr;
     uint8_t* d_rgb = nullptr;           // staging for host RGB input
@@ -291,7 +291,7 @@ static int ctx_alloc(eppm_ctx* c)
         const size_t n = (size_t)c->W[i] * c->H[i];
         HIPCHK(hipMalloc((void**)&c->flow[i], n * 8));
         HIPCHK(hipMalloc((void**)&c->flow_tmp[i], n * 8));
-        if (i < c->nl - 1 && c2f_refine_wants_split(c->W[i], c->H[i], c->prm.patch_r)) HIPCHK(hipMalloc((void**)&c->c2f_cost9[i], n * 36));
+        if (i < c->nl - 1 && c2f_refine_wants_split(c->W[i], c->H[i], c->prm.patch_r)) HIPCHK(hipMalloc((void**)&c->c2f_cost9[i], n * 36 * 4));
     }
     if (c->raw_pitch != c->ipitch[0]) return set_err(EPPM_ERR_HIP, "unexpected pitch mismatch");
     const int L = c->nl - 1;

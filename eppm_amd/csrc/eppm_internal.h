@@ -85,7 +85,7 @@ void launch_nnf2flow(float* flow, int flow_pitch, const int16_t* nnf, int nnf_pi
 void launch_resize_flow(float* out, int outH, int outW, const float* in, int h, int w, float ratio, float post_scale, hipStream_t s);
 void launch_mul_scalar(float* flow, float scale, int h, int w, hipStream_t s);
 bool c2f_refine_wants_split(int w, int h, int R);
-// cost9: scratch of 9 floats per pixel for launches that c2f_refine_wants_split(), or NULL
+// cost9: scratch of 36 floats per pixel for launches that c2f_refine_wants_split(), or NULL
 void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, float* cost9, hipStream_t s);
 void launch_flow_blf(float* out, const float* in, const uint32_t* img, int ipitch, int w, int h, int flow_pitch,
                      const float* blf_lut, hipStream_t s);

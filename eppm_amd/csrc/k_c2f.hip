@@ -164,7 +164,7 @@ template <int R> __device__ __forceinline__ const C2fTables<R>& c2f_tables();
 template <> __device__ __forceinline__ const C2fTables<9>& c2f_tables<9>() { return c2f_tab9; }
 template <> __device__ __forceinline__ const C2fTables<17>& c2f_tables<17>() { return c2f_tab17; }
 
-template <int R, int PASS>
+template <int R, int PASS, bool RAW = false>
 __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLutT<R + 1>& L, const float4* __restrict__ s_src,
                                          int TW, int tx, int ty, int cx16, int wmax16, int ccy, const rgbf c1, const rgbf (&c2)[3], float (&run)[3])
 {
@@ -219,7 +219,7 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
 #pragma unroll
     for (int n = 0; n < 3; n++) {
         const float c = cs[n] / ws[n];
-        run[n] = (PASS == 3) ? c : ((c < run[n]) ? c : run[n]);
+        run[n] = (RAW || PASS == 3) ? c : ((c < run[n]) ? c : run[n]);
     }
 }
 
@@ -236,9 +236,10 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
 #endif
 #define EPPM_C2F_OCC __attribute__((amdgpu_waves_per_eu(EPPM_C2F_WAVES_MIN, EPPM_C2F_WAVES)))     // (min, max): radius 17 only fits 2
 // SPLIT: a launch with few tiles (level 1 of a 1024x436 pair: 448 tiles = 1.75 waves per SIMD) does not fill the chip
-// and runs latency bound.  Then every candidate column m gets its own workgroup (3x the waves); the 9 costs of a pixel
-// go to a scratch plane and k_c2f_select replays the reference's candidate loop.  Same costs, same selection order.
-template <int R, bool SPLIT>
+// and runs latency bound.  Then a tile is given to 3 workgroups (one candidate column m each) or to 4 (one affine pass
+// each), whichever divides more evenly over the 256 CUs; the costs of a pixel (9 x 4 passes) go to a scratch plane and
+// k_c2f_select replays the reference's nested minimum and candidate loop.  Same costs, same selection order.
+template <int R, int SPLIT>
 __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH Ph, float* __restrict__ flow, const float* __restrict__ lut,
                                                                        float* __restrict__ cost9)
 {
@@ -257,8 +258,9 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
     // share their R-pixel halos and their target windows -- hit the same L2 (speed only, never correctness).
     const int tiles_x = (P.w + kBlock - 1) / kBlock, tiles = tiles_x * ((P.h + kBlock - 1) / kBlock);
     const int per_xcd = (tiles + 7) / 8;
-    const int slot = SPLIT ? (blockIdx.x >> 3) / 3 : (blockIdx.x >> 3);      // the three column workgroups of a tile share an XCD
-    const int m_only = SPLIT ? (blockIdx.x >> 3) % 3 : -1;
+    const int slot = SPLIT ? (blockIdx.x >> 3) / SPLIT : (blockIdx.x >> 3);  // the workgroups of a tile share an XCD
+    const int part = SPLIT ? (blockIdx.x >> 3) % SPLIT : -1;
+    const int m_only = (SPLIT == 3) ? part : -1;
     const int tile = (blockIdx.x & 7) * per_xcd + slot;
     if (slot >= per_xcd || tile >= tiles) return;
     const int x0 = (tile % tiles_x) * kBlock, y0 = (tile / tiles_x) * kBlock;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
     if (x >= P.w || y >= P.h) return;
     const float fvx = flow[(y * P.w + x) * 2], fvy = flow[(y * P.w + x) * 2 + 1];
     if (fvx > kUnknownFlowThresh || fvy > kUnknownFlowThresh) {
-        if (!SPLIT) {
+        if (SPLIT == 0) {
             flow[(y * P.w + x) * 2] = 0.0f;
             flow[(y * P.w + x) * 2 + 1] = 0.0f;
         }
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
     float min_cost = 999999;
 #pragma unroll 1
     for (int m = 0; m < 3; m++) {                    // x offset outer, as the reference's candidate loop (kernel.cu:2028)
-        if (SPLIT && m != m_only) continue;
+        if (SPLIT == 3 && m != m_only) continue;
         const int cx = (int)(int16_t)(ccx + m - 1);
         if (cx < 0 || cx >= P.w) continue;           // every candidate of this column is skipped (:2030)
         rgbf c2[3];
@@ -293,13 +295,22 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
         for (int n = 0; n < 3; n++) c2[n] = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, cx, ccy + n - 1));
         float run[3];
         const int cx16 = cx << 4, wmax16 = (P.w - 1) << 4;
+        if (SPLIT == 4) {                            // this workgroup's pass only, raw cost
+            if (part == 3) c2f_pass<R, 3, true>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+            else if (part == 2) c2f_pass<R, 2, true>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+            else if (part == 1) c2f_pass<R, 1, true>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+            else c2f_pass<R, 0, true>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+#pragma unroll
+            for (int n = 0; n < 3; n++) cost9[(size_t)(y * P.w + x) * 36 + part * 9 + m * 3 + n] = run[n];
+            continue;
+        }
         c2f_pass<R, 3>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
         c2f_pass<R, 2>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
         c2f_pass<R, 1>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
         c2f_pass<R, 0>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
-        if (SPLIT) {
+        if (SPLIT == 3) {
 #pragma unroll
-            for (int n = 0; n < 3; n++) cost9[(size_t)(y * P.w + x) * 9 + m * 3 + n] = run[n];
+            for (int n = 0; n < 3; n++) cost9[(size_t)(y * P.w + x) * 36 + m * 3 + n] = run[n];      // nested minimum already formed
             continue;
         }
 #pragma unroll
@@ -310,12 +321,13 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
             if (cv < min_cost) { min_cost = cv; bx = cx; by = cy; }
         }
     }
-    if (SPLIT) return;
+    if (SPLIT != 0) return;
     flow[(y * P.w + x) * 2] = (float)(bx - x);
     flow[(y * P.w + x) * 2 + 1] = (float)(by - y);
 }
 
 // the candidate loop of kernel.cu:2028-2040 over the 9 costs written by the split launch
+template <int SPLIT>
 __global__ __launch_bounds__(256) void k_c2f_select(float* __restrict__ flow, const float* __restrict__ cost9, int w, int h)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -336,7 +348,14 @@ __global__ __launch_bounds__(256) void k_c2f_select(float* __restrict__ flow, co
         for (int n = 0; n < 3; n++) {
             const int cy = (int)(int16_t)(ccy + n - 1);
             if (cy < 0 || cy >= h) continue;
-            const float cv = cost9[(size_t)(y * w + x) * 9 + m * 3 + n];
+            const float* __restrict__ pc = cost9 + (size_t)(y * w + x) * 36 + m * 3 + n;
+            float cv = pc[0];
+            if (SPLIT == 4) {                    // __min(c1,__min(c2,__min(c3,c4))), kernel.cu:512: passes 4th to 1st
+                cv = pc[27];
+                cv = (pc[18] < cv) ? pc[18] : cv;
+                cv = (pc[9] < cv) ? pc[9] : cv;
+                cv = (pc[0] < cv) ? pc[0] : cv;
+            }
             if (cv < min_cost) { min_cost = cv; bx = cx; by = cy; }
         }
     }
@@ -350,7 +369,7 @@ bool c2f_refine_wants_split(int w, int h, int R)
     return (R == 9 || R == 17) && tiles * 4 < 3 * 1024;          // fewer than 3 waves per SIMD on 256 CUs
 }
 
-// cost9: scratch of 9 floats per pixel, or NULL (never split)
+// cost9: scratch of 36 floats per pixel, or NULL (never split)
 void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, float* cost9, hipStream_t s)
 {
     dim3 grid((P.w + kBlock - 1) / kBlock, (P.h + kBlock - 1) / kBlock), block(kBlock, kBlock);
@@ -359,14 +378,23 @@ void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, f
     dim3 grid1(per_xcd * 8);                     // 1-D, padded so every XCD gets the same number of slots
     const bool table_ok = (P.w + R < 32764) && (P.h + R < 32764);     // range of the offset-table identity (c2f_pass)
     if (cost9 && table_ok && c2f_refine_wants_split(P.w, P.h, R)) {
-        dim3 grid3(per_xcd * 3 * 8);
-        if (R == 9) hipLaunchKernelGGL((k_c2f_refine_tiled<9, true>), grid3, block, 0, s, P, flow, lut, cost9);
-        else hipLaunchKernelGGL((k_c2f_refine_tiled<17, true>), grid3, block, 0, s, P, flow, lut, cost9);
-        hipLaunchKernelGGL(k_c2f_select, dim3((P.w + 63) / 64, (P.h + 3) / 4), dim3(64, 4), 0, s, flow, cost9, P.w, P.h);
+        // 3 or 4 workgroups per tile: the factor whose workgroup count divides more evenly over the 256 CUs
+        auto imbalance = [&](int f) { const int wgs = tiles * f; return (float)((wgs + 255) / 256) * 256.0f / (float)wgs; };
+        const int f = (imbalance(4) < imbalance(3)) ? 4 : 3;
+        dim3 gridf(per_xcd * f * 8), gs((P.w + 63) / 64, (P.h + 3) / 4), bs(64, 4);
+        if (f == 3) {
+            if (R == 9) hipLaunchKernelGGL((k_c2f_refine_tiled<9, 3>), gridf, block, 0, s, P, flow, lut, cost9);
+            else hipLaunchKernelGGL((k_c2f_refine_tiled<17, 3>), gridf, block, 0, s, P, flow, lut, cost9);
+            hipLaunchKernelGGL(k_c2f_select<3>, gs, bs, 0, s, flow, cost9, P.w, P.h);
+        } else {
+            if (R == 9) hipLaunchKernelGGL((k_c2f_refine_tiled<9, 4>), gridf, block, 0, s, P, flow, lut, cost9);
+            else hipLaunchKernelGGL((k_c2f_refine_tiled<17, 4>), gridf, block, 0, s, P, flow, lut, cost9);
+            hipLaunchKernelGGL(k_c2f_select<4>, gs, bs, 0, s, flow, cost9, P.w, P.h);
+        }
         return;
     }
-    if (R == 9 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<9, false>), grid1, block, 0, s, P, flow, lut, (float*)nullptr);
-    else if (R == 17 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<17, false>), grid1, block, 0, s, P, flow, lut, (float*)nullptr);
+    if (R == 9 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<9, 0>), grid1, block, 0, s, P, flow, lut, (float*)nullptr);
+    else if (R == 17 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<17, 0>), grid1, block, 0, s, P, flow, lut, (float*)nullptr);
     else hipLaunchKernelGGL(k_c2f_refine, grid, block, 0, s, P, flow, lut, R);
 }
 

@@ -13,7 +13,7 @@
 #include "eppm_internal.h"
 
 #ifndef EPPM_LPC9
-#define EPPM_LPC9 16      // lanes per sweep chain at patch radius 9 (100 samples): 32 cuts the single-pair latency 4 % but costs throughput with pairs in flight
+#define EPPM_LPC9 16      // lanes per sweep chain at patch radius 9 (100 samples); doubled for launches that cannot fill the chip, see launch_pm_sweep
 #endif
 #ifndef EPPM_SWEEP_GB
 #define EPPM_SWEEP_GB 7   // sample gathers a sweep lane keeps in flight (per image)
@@ -335,7 +335,15 @@ bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int
     const bool is_row = (dir == 0 || dir == 2);
     const int len = is_row ? P.w : P.h, lines = is_row ? P.h : P.w;
     const int nseg = (len + seg_len - 1) / seg_len;
-    if (R == 9) { launch_sweep_r<9, EPPM_LPC9>(b, lut, seg_len, dir, nseg, lines, s); return true; }
+    if (R == 9) {
+        // 16 lanes per chain are the most instruction-efficient; when that leaves fewer than two waves per SIMD (the
+        // quarter-resolution level of a 1024x436 pair: 1.4) the chip is latency bound and 32 lanes per chain shorten
+        // the dependent step (PatchMatch 1.78 -> 1.61 ms, no change in throughput with pairs in flight)
+        const int chains = lines * ((nseg + 1) & ~1) * b.n;
+        if (chains * EPPM_LPC9 / 64 < 2 * 1024) launch_sweep_r<9, 2 * EPPM_LPC9>(b, lut, seg_len, dir, nseg, lines, s);
+        else launch_sweep_r<9, EPPM_LPC9>(b, lut, seg_len, dir, nseg, lines, s);
+        return true;
+    }
     if (R == 17) { launch_sweep_r<17, EPPM_LPC17>(b, lut, seg_len, dir, nseg, lines, s); return true; }
     if (nseg > 1024) return false;   // eppm_create / the launchers validate sizes
     int lpb = 256 / nseg;

@@ -366,7 +366,10 @@ __global__ __launch_bounds__(256) void k_c2f_select(float* __restrict__ flow, co
 bool c2f_refine_wants_split(int w, int h, int R)
 {
     const int tiles = ((w + kBlock - 1) / kBlock) * ((h + kBlock - 1) / kBlock);
-    return (R == 9 || R == 17) && tiles * 4 < 3 * 1024;          // fewer than 3 waves per SIMD on 256 CUs
+#ifndef EPPM_C2F_SPLIT_BELOW_WAVES
+#define EPPM_C2F_SPLIT_BELOW_WAVES (3 * 1024)        // fewer than 3 waves per SIMD on 256 CUs
+#endif
+    return (R == 9 || R == 17) && tiles * 4 < EPPM_C2F_SPLIT_BELOW_WAVES;
 }
 
 // cost9: scratch of 36 floats per pixel, or NULL (never split)

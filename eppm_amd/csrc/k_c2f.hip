@@ -11,6 +11,9 @@ namespace eppm {
 #ifndef EPPM_C2F_UNROLL
 #define EPPM_C2F_UNROLL 2
 #endif
+#ifndef EPPM_BLF_UNROLL
+#define EPPM_BLF_UNROLL 21
+#endif
 #define EPPM_PRAGMA_(x) _Pragma(#x)
 #define EPPM_UNROLL(n) EPPM_PRAGMA_(unroll n)
 
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256) void k_flow_blf(float* __restrict__ out, const
     auto tap_row = [&](int r, auto use_a, auto use_b) {
         const float gya = use_a ? s_lut[abs(r - BR)] : 0.0f;
         const float gyb = use_b ? s_lut[abs(r - 1 - BR)] : 0.0f;
-#pragma unroll 3
+EPPM_UNROLL(EPPM_BLF_UNROLL)
         for (int dx = 0; dx <= 2 * BR; dx++) {
             const int ti = base + r * BTW + dx;
             const float4 tp = s_t[ti];

@@ -378,15 +378,17 @@ static int prepare_one(eppm_ctx* c, uint32_t** pyr, uint8_t** cen, void** pk, ui
     const int n = (int)(log(0.25) / (double)logf(ratio));   // C++ float overload in the reference: n = 1
     const float nSigma = baseSigma * n;
     for (int i = 1; i < c->nl; i++) {
-        if (i <= n) {
-            const float sigma = baseSigma * i;
-            launch_gauss_rgba(tmp[0], pyr[0], p0, c->H[0], c->W[0], sigma, (int)(sigma * 3), s);
-            launch_resize_rgba(pyr[i], (int)(c->ipitch[i] / 4), c->H[i], c->W[i], tmp[0], p0, c->H[0], c->W[0], (float)pow(ratio, i), s);
+        // source level j, blur (sigma, radius), resize ratio r: .cuh:647-663
+        const int j = (i <= n) ? 0 : i - n;
+        const float sigma = (i <= n) ? baseSigma * i : nSigma;
+        const float r = (i <= n) ? (float)pow(ratio, i) : (float)pow(ratio, i) * c->W[0] / c->W[j];
+        const int radius = (int)(sigma * 3);
+        if (gauss_decimate2_ok(c->H[i], c->W[i], c->H[j], c->W[j], r, radius)) {
+            // exact 2:1 step: blur only the pixels the decimation keeps (a quarter of the level)
+            launch_gauss_decimate2(pyr[i], (int)(c->ipitch[i] / 4), c->H[i], c->W[i], pyr[j], (int)(c->ipitch[j] / 4), c->H[j], c->W[j], sigma, radius, s);
         } else {
-            const int j = i - n;
-            launch_gauss_rgba(tmp[j], pyr[j], (int)(c->ipitch[j] / 4), c->H[j], c->W[j], nSigma, (int)(nSigma * 3), s);
-            launch_resize_rgba(pyr[i], (int)(c->ipitch[i] / 4), c->H[i], c->W[i], tmp[j], (int)(c->ipitch[j] / 4), c->H[j], c->W[j],
-                               (float)pow(ratio, i) * c->W[0] / c->W[j], s);
+            launch_gauss_rgba(tmp[j], pyr[j], (int)(c->ipitch[j] / 4), c->H[j], c->W[j], sigma, radius, s);
+            launch_resize_rgba(pyr[i], (int)(c->ipitch[i] / 4), c->H[i], c->W[i], tmp[j], (int)(c->ipitch[j] / 4), c->H[j], c->W[j], r, s);
         }
     }
     for (int i = 0; i < c->nl; i++)

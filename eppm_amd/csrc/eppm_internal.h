@@ -26,6 +26,10 @@ struct PlanesH {            // host-side mirror of eppm::Planes: float4 texel pl
 
 // ---- prepare (k_prepare.hip) ----
 void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s);
+// blur + exact 2:1 decimation in one kernel (only the kept pixels are blurred); use when gauss_decimate2_ok()
+bool gauss_decimate2_ok(int outH, int outW, int h, int w, float ratio, int radius);
+void launch_gauss_decimate2(uint32_t* out, int out_pitch_px, int outH, int outW, const uint32_t* in, int pitch_px, int h, int w,
+                            float sigma, int radius, hipStream_t s);
 void launch_resize_rgba(uint32_t* out, int out_pitch_px, int outH, int outW, const uint32_t* in, int in_pitch_px, int h, int w,
                         float ratio, hipStream_t s);
 // census plane and (optionally, texels != NULL) the float4 texel plane the patch kernels read

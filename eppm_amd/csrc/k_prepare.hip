@@ -59,6 +59,66 @@ void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, i
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Pyramid step blur + decimate (.cuh:647-663) fused for the exact 2:1 case.  At ratio 1/2 the bilinear resize
+// reads one tap with weight 1: output (x,y) = blurred pixel (min(2x+1,w-1), min(2y+1,h-1)).  The reference blurs
+// every pixel of the finer level into a temp plane and keeps a quarter of them; here only the kept pixels are
+// blurred -- the same formula per pixel, so the same bytes.  32x8 outputs per block, source halo in LDS.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gauss_decimate2(uint32_t* __restrict__ out, int out_pitch, int outH, int outW,
+                                                         const uint32_t* __restrict__ in, int pitch, int h, int w, float sigma2, int radius)
+{
+    __shared__ uint32_t tile[(2 * GT_H + 2 * G_MAXR) * (2 * GT_W + 2 * G_MAXR)];
+    __shared__ float wtab[(2 * G_MAXR + 1) * (2 * G_MAXR + 1)];
+    const int tw = 2 * GT_W + 2 * radius, th = 2 * GT_H + 2 * radius;
+    const int x0 = blockIdx.x * GT_W, y0 = blockIdx.y * GT_H;          // output coordinates
+    const int sx0 = 2 * x0 + 1 - radius, sy0 = 2 * y0 + 1 - radius;     // source coordinates of the tile origin
+    const int tid = threadIdx.y * GT_W + threadIdx.x;
+    for (int t = tid; t < tw * th; t += 256) {
+        const int ty = t / tw, tx = t % tw;
+        const int cy = max(0, min(h - 1, sy0 + ty));
+        const int cx = max(0, min(w - 1, sx0 + tx));
+        tile[t] = in[cy * pitch + cx];
+    }
+    const int d = 2 * radius + 1;
+    for (int t = tid; t < d * d; t += 256) {
+        const int dy = t / d - radius, dx = t % d - radius;
+        wtab[t] = fast_exp(-(float)(dy * dy + dx * dx) / sigma2);
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= outW || y >= outH) return;
+    // The kept pixel is min(2x+1, w-1): when the clamp bites (2x+1 = w, possible for the last column of an odd-width
+    // level only if outW were rounded up -- it is floor(w/2), so it never does) the tile position would shift; assert by construction.
+    const int lx = 2 * threadIdx.x, ly = 2 * threadIdx.y;              // tile position of the window origin of (2x+1, 2y+1)
+    float vx = 0, vy = 0, vz = 0, vw = 0, sum = 0;
+    for (int dy = 0; dy < d; dy++)
+        for (int dx = 0; dx < d; dx++) {
+            const float weight = wtab[dy * d + dx];
+            const uint32_t p = tile[(ly + dy) * tw + lx + dx];
+            vx += (float)(p & 0xffu) * weight;
+            vy += (float)((p >> 8) & 0xffu) * weight;
+            vz += (float)((p >> 16) & 0xffu) * weight;
+            vw += (float)(p >> 24) * weight;
+            sum += weight;
+        }
+    vx /= sum; vy /= sum; vz /= sum; vw /= sum;
+    // float -> u8 truncation of the blur, then the resize's own float -> u8 of 1*value + 0*others: the identity
+    out[y * out_pitch + x] = (uint32_t)vx | ((uint32_t)vy << 8) | ((uint32_t)vz << 16) | ((uint32_t)vw << 24);
+}
+
+// valid when the resize ratio is exactly 1/2 and every kept pixel 2x+1, 2y+1 lies inside the finer level
+bool gauss_decimate2_ok(int outH, int outW, int h, int w, float ratio, int radius)
+{
+    return ratio == 0.5f && radius <= G_MAXR && 2 * (outW - 1) + 1 <= w - 1 && 2 * (outH - 1) + 1 <= h - 1;
+}
+void launch_gauss_decimate2(uint32_t* out, int out_pitch_px, int outH, int outW, const uint32_t* in, int pitch_px, int h, int w,
+                            float sigma, int radius, hipStream_t s)
+{
+    dim3 grid((outW + GT_W - 1) / GT_W, (outH + GT_H - 1) / GT_H), block(GT_W, GT_H);
+    hipLaunchKernelGGL(k_gauss_decimate2, grid, block, 0, s, out, out_pitch_px, outH, outW, in, pitch_px, h, w, sigma * sigma * 2, radius);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Bilinear resize, uchar4 (.cuh:565-601), as written: fx=(x+1)/ratio-1, trunc, 4 taps, trunc to u8.
 // For ratio 1/2 and 1/4 the weights are exactly 1,0,0,0 (pixel (2x+1,2y+1) / (4x+3,4y+3)).
 // ---------------------------------------------------------------------------------------------------

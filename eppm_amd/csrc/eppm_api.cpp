@@ -367,12 +367,14 @@ extern "C" int eppm_enable_stage_timing(eppm_ctx* c, int on)
     return EPPM_OK;
 }
 
-// ---- prepare: refine :1060-1071 + .cuh:642-664 ----
-static int prepare_one(eppm_ctx* c, uint32_t** pyr, uint8_t** cen, void** pk, uint32_t** tmp, const uint32_t* raw)
+// ---- prepare: refine :1060-1071 + .cuh:642-664.  The two frames share every launch. ----
+static int prepare(eppm_ctx* c, const uint32_t* raw1, const uint32_t* raw2)
 {
+    stage_begin(c, c->ev_prep, "prepare");
     hipStream_t s = c->stream;
+    uint32_t **p1 = c->img1, **p2 = c->img2, **tmp = c->tmpu;
     const int p0 = (int)(c->ipitch[0] / 4);
-    launch_gauss_rgba(pyr[0], raw, p0, c->H[0], c->W[0], .5f, 2, s);                    // refine :1063-1064
+    launch_gauss_rgba2(p1[0], raw1, p2[0], raw2, p0, c->H[0], c->W[0], .5f, 2, s);    // refine :1063-1064
     const float ratio = 0.5f;                                                             // PYR_RATIO
     const float baseSigma = (1 / ratio - 1);
     const int n = (int)(log(0.25) / (double)logf(ratio));   // C++ float overload in the reference: n = 1
@@ -383,24 +385,29 @@ static int prepare_one(eppm_ctx* c, uint32_t** pyr, uint8_t** cen, void** pk, ui
         const float sigma = (i <= n) ? baseSigma * i : nSigma;
         const float r = (i <= n) ? (float)pow(ratio, i) : (float)pow(ratio, i) * c->W[0] / c->W[j];
         const int radius = (int)(sigma * 3);
+        const int pj = (int)(c->ipitch[j] / 4), pi = (int)(c->ipitch[i] / 4);
         if (gauss_decimate2_ok(c->H[i], c->W[i], c->H[j], c->W[j], r, radius)) {
             // exact 2:1 step: blur only the pixels the decimation keeps (a quarter of the level)
-            launch_gauss_decimate2(pyr[i], (int)(c->ipitch[i] / 4), c->H[i], c->W[i], pyr[j], (int)(c->ipitch[j] / 4), c->H[j], c->W[j], sigma, radius, s);
+            launch_gauss_decimate2(p1[i], p1[j], p2[i], p2[j], 2, pi, c->H[i], c->W[i], pj, c->H[j], c->W[j], sigma, radius, s);
         } else {
-            launch_gauss_rgba(tmp[j], pyr[j], (int)(c->ipitch[j] / 4), c->H[j], c->W[j], sigma, radius, s);
-            launch_resize_rgba(pyr[i], (int)(c->ipitch[i] / 4), c->H[i], c->W[i], tmp[j], (int)(c->ipitch[j] / 4), c->H[j], c->W[j], r, s);
+            for (int k = 0; k < 2; k++) {
+                uint32_t** pyr = k ? p2 : p1;
+                launch_gauss_rgba(tmp[j], pyr[j], pj, c->H[j], c->W[j], sigma, radius, s);
+                launch_resize_rgba(pyr[i], pi, c->H[i], c->W[i], tmp[j], pj, c->H[j], c->W[j], r, s);
+            }
         }
     }
-    for (int i = 0; i < c->nl; i++)
-        launch_census(cen[i], (int)c->cpitch[i], pk[i], c->W[i], pyr[i], (int)(c->ipitch[i] / 4), c->W[i], c->H[i], s);
-    return EPPM_OK;
-}
-
-static int prepare(eppm_ctx* c, const uint32_t* raw1, const uint32_t* raw2)
-{
-    stage_begin(c, c->ev_prep, "prepare");
-    CHK(prepare_one(c, c->img1, c->cen1, c->pk1, c->tmpu, raw1));
-    CHK(prepare_one(c, c->img2, c->cen2, c->pk2, c->tmpu, raw2));
+    CensusBatch cb;
+    cb.n = 0;
+    for (int k = 0; k < 2; k++)
+        for (int i = 0; i < c->nl; i++) {
+            CensusJob& J = cb.job[cb.n++];
+            J.census = k ? c->cen2[i] : c->cen1[i]; J.cpitch = (int)c->cpitch[i];
+            J.texels = k ? c->pk2[i] : c->pk1[i];   J.tpitch = c->W[i];
+            J.img = k ? c->img2[i] : c->img1[i];    J.ipitch = (int)(c->ipitch[i] / 4);
+            J.w = c->W[i]; J.h = c->H[i]; J.first_block = 0;
+        }
+    launch_census_batch(cb, s);
     stage_end(c, c->ev_prep);
     HIPCHK(hipGetLastError());
     c->have_images = true;

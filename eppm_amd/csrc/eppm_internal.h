@@ -28,8 +28,15 @@ struct PlanesH {            // host-side mirror of eppm::Planes: float4 texel pl
 void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s);
 // blur + exact 2:1 decimation in one kernel (only the kept pixels are blurred); use when gauss_decimate2_ok()
 bool gauss_decimate2_ok(int outH, int outW, int h, int w, float ratio, int radius);
-void launch_gauss_decimate2(uint32_t* out, int out_pitch_px, int outH, int outW, const uint32_t* in, int pitch_px, int h, int w,
-                            float sigma, int radius, hipStream_t s);
+void launch_gauss_decimate2(uint32_t* out0, const uint32_t* in0, uint32_t* out1, const uint32_t* in1, int nimg, int out_pitch_px, int outH,
+                            int outW, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s);
+// the same blur on two images of equal geometry in one launch
+void launch_gauss_rgba2(uint32_t* out0, const uint32_t* in0, uint32_t* out1, const uint32_t* in1, int pitch_px, int h, int w, float sigma,
+                        int radius, hipStream_t s);
+// census (+ texel plane) of several planes in one launch
+struct CensusJob { uint8_t* census; int cpitch; void* texels; int tpitch; const uint32_t* img; int ipitch; int w, h; int first_block; };
+struct CensusBatch { int n; CensusJob job[2 * kMaxLevels]; };
+void launch_census_batch(CensusBatch& B, hipStream_t s);
 void launch_resize_rgba(uint32_t* out, int out_pitch_px, int outH, int outW, const uint32_t* in, int in_pitch_px, int h, int w,
                         float ratio, hipStream_t s);
 // census plane and (optionally, texels != NULL) the float4 texel plane the patch kernels read

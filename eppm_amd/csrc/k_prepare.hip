@@ -14,9 +14,13 @@ namespace eppm {
 // ---------------------------------------------------------------------------------------------------
 constexpr int GT_W = 32, GT_H = 8, G_MAXR = 6;
 
-__global__ __launch_bounds__(256) void k_gauss_rgba(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, int pitch,
+// blockIdx.z selects one of two independent images (the two frames of a pair share every launch)
+__global__ __launch_bounds__(256) void k_gauss_rgba(uint32_t* __restrict__ out0, const uint32_t* __restrict__ in0,
+                                                    uint32_t* __restrict__ out1, const uint32_t* __restrict__ in1, int pitch,
                                                     int h, int w, float sigma2, int radius)
 {
+    uint32_t* __restrict__ out = blockIdx.z ? out1 : out0;
+    const uint32_t* __restrict__ in = blockIdx.z ? in1 : in0;
     __shared__ uint32_t tile[(GT_H + 2 * G_MAXR) * (GT_W + 2 * G_MAXR)];
     __shared__ float wtab[(2 * G_MAXR + 1) * (2 * G_MAXR + 1)];
     const int tw = GT_W + 2 * radius, th = GT_H + 2 * radius;
@@ -55,7 +59,13 @@ __global__ __launch_bounds__(256) void k_gauss_rgba(uint32_t* __restrict__ out, 
 void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s)
 {
     dim3 grid((w + GT_W - 1) / GT_W, (h + GT_H - 1) / GT_H), block(GT_W, GT_H);
-    hipLaunchKernelGGL(k_gauss_rgba, grid, block, 0, s, out, in, pitch_px, h, w, sigma * sigma * 2, radius);
+    hipLaunchKernelGGL(k_gauss_rgba, grid, block, 0, s, out, in, out, in, pitch_px, h, w, sigma * sigma * 2, radius);
+}
+void launch_gauss_rgba2(uint32_t* out0, const uint32_t* in0, uint32_t* out1, const uint32_t* in1, int pitch_px, int h, int w, float sigma,
+                        int radius, hipStream_t s)
+{
+    dim3 grid((w + GT_W - 1) / GT_W, (h + GT_H - 1) / GT_H, 2), block(GT_W, GT_H);
+    hipLaunchKernelGGL(k_gauss_rgba, grid, block, 0, s, out0, in0, out1, in1, pitch_px, h, w, sigma * sigma * 2, radius);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -64,9 +74,12 @@ void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, i
 // every pixel of the finer level into a temp plane and keeps a quarter of them; here only the kept pixels are
 // blurred -- the same formula per pixel, so the same bytes.  32x8 outputs per block, source halo in LDS.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gauss_decimate2(uint32_t* __restrict__ out, int out_pitch, int outH, int outW,
-                                                         const uint32_t* __restrict__ in, int pitch, int h, int w, float sigma2, int radius)
+__global__ __launch_bounds__(256) void k_gauss_decimate2(uint32_t* __restrict__ out0, const uint32_t* __restrict__ in0,
+                                                         uint32_t* __restrict__ out1, const uint32_t* __restrict__ in1, int out_pitch,
+                                                         int outH, int outW, int pitch, int h, int w, float sigma2, int radius)
 {
+    uint32_t* __restrict__ out = blockIdx.z ? out1 : out0;
+    const uint32_t* __restrict__ in = blockIdx.z ? in1 : in0;
     __shared__ uint32_t tile[(2 * GT_H + 2 * G_MAXR) * (2 * GT_W + 2 * G_MAXR)];
     __shared__ float wtab[(2 * G_MAXR + 1) * (2 * G_MAXR + 1)];
     const int tw = 2 * GT_W + 2 * radius, th = 2 * GT_H + 2 * radius;
@@ -111,11 +124,13 @@ bool gauss_decimate2_ok(int outH, int outW, int h, int w, float ratio, int radiu
 {
     return ratio == 0.5f && radius <= G_MAXR && 2 * (outW - 1) + 1 <= w - 1 && 2 * (outH - 1) + 1 <= h - 1;
 }
-void launch_gauss_decimate2(uint32_t* out, int out_pitch_px, int outH, int outW, const uint32_t* in, int pitch_px, int h, int w,
-                            float sigma, int radius, hipStream_t s)
+// two images per launch (out1/in1 may repeat out0/in0 with nimg = 1)
+void launch_gauss_decimate2(uint32_t* out0, const uint32_t* in0, uint32_t* out1, const uint32_t* in1, int nimg, int out_pitch_px, int outH,
+                            int outW, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s)
 {
-    dim3 grid((outW + GT_W - 1) / GT_W, (outH + GT_H - 1) / GT_H), block(GT_W, GT_H);
-    hipLaunchKernelGGL(k_gauss_decimate2, grid, block, 0, s, out, out_pitch_px, outH, outW, in, pitch_px, h, w, sigma * sigma * 2, radius);
+    dim3 grid((outW + GT_W - 1) / GT_W, (outH + GT_H - 1) / GT_H, nimg), block(GT_W, GT_H);
+    hipLaunchKernelGGL(k_gauss_decimate2, grid, block, 0, s, out0, in0, out1, in1, out_pitch_px, outH, outW, pitch_px, h, w,
+                       sigma * sigma * 2, radius);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -193,6 +208,48 @@ __global__ __launch_bounds__(256) void k_census(uint8_t* __restrict__ census, in
     r += (lum[ly + 1][lx + 1] > c) ? 128u : 0u;
     census[y * cpitch + x] = (uint8_t)r;
     if (texels) texels[y * tpitch + x] = make_texel(img[y * ipitch + x], r);
+}
+
+// every level of both frames in ONE launch: a block finds its job by scanning the (at most 16) block offsets
+__global__ __launch_bounds__(256) void k_census_batch(CensusBatch B)
+{
+    int j = 0;
+    while (j + 1 < B.n && (int)blockIdx.x >= B.job[j + 1].first_block) j++;
+    const CensusJob& J = B.job[j];
+    const int b = blockIdx.x - J.first_block, bw = (J.w + 63) / 64;
+    __shared__ float lum[6][66];
+    const int x0 = (b % bw) * 64, y0 = (b / bw) * 4;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    for (int t = tid; t < 6 * 66; t += 256) {
+        const int ty = t / 66, tx = t % 66;
+        const int cy = iclamp(y0 + ty - 1, 0, J.h - 1), cx = iclamp(x0 + tx - 1, 0, J.w - 1);
+        lum[ty][tx] = lum_of(J.img[cy * J.ipitch + cx]);
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= J.w || y >= J.h) return;
+    const int lx = threadIdx.x + 1, ly = threadIdx.y + 1;
+    const float c = lum[ly][lx];
+    uint32_t r = 0;
+    r += (lum[ly - 1][lx - 1] > c) ? 1u : 0u;
+    r += (lum[ly - 1][lx] > c) ? 2u : 0u;
+    r += (lum[ly - 1][lx + 1] > c) ? 4u : 0u;
+    r += (lum[ly][lx - 1] > c) ? 8u : 0u;
+    r += (lum[ly][lx + 1] > c) ? 16u : 0u;
+    r += (lum[ly + 1][lx - 1] > c) ? 32u : 0u;
+    r += (lum[ly + 1][lx] > c) ? 64u : 0u;
+    r += (lum[ly + 1][lx + 1] > c) ? 128u : 0u;
+    J.census[y * J.cpitch + x] = (uint8_t)r;
+    if (J.texels) ((float4*)J.texels)[y * J.tpitch + x] = make_texel(J.img[y * J.ipitch + x], r);
+}
+void launch_census_batch(CensusBatch& B, hipStream_t s)
+{
+    int blocks = 0;
+    for (int j = 0; j < B.n; j++) {
+        B.job[j].first_block = blocks;
+        blocks += ((B.job[j].w + 63) / 64) * ((B.job[j].h + 3) / 4);
+    }
+    hipLaunchKernelGGL(k_census_batch, dim3(blocks), dim3(64, 4), 0, s, B);
 }
 
 void launch_census(uint8_t* census, int cpitch, void* texels, int tpitch, const uint32_t* img, int ipitch, int w, int h, hipStream_t s)

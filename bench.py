@@ -33,9 +33,9 @@ W, H = 1024, 436               # BASELINE.json configs[1]
 REFINE_BYTES_PER_PX = 26
 # HBM-side bytes per k_c2f_refine_tiled launch at 1024x436, mean of the level-1 and level-0 launches, from the PMC
 # passes committed under profiles/r01_g_pmc_{fetch,write}_size.csv: FETCH_SIZE 3621.8 / 11486.4 KB (x2: gfx950 tallies
-# the 128-B requests of 16-B-per-lane loads at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE 15721.3 / 3488.0 KB
+# the 128-B requests of 16-B-per-lane loads at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE 15710.4 / 3488.0 KB
 # (the level-1 launch is split by affine pass and writes 36 costs per pixel instead of the flow)
-TRAFFIC_BYTES_1024x436 = ((2 * 3621.8 + 15721.3) + (2 * 11486.4 + 3488.0)) / 2 * 1024
+TRAFFIC_BYTES_1024x436 = ((2 * 3621.8 + 15710.4) + (2 * 11486.4 + 3488.0)) / 2 * 1024
 # The kernel is bound by vector-ALU issue, not by HBM: SQ_INSTS_VALU per launch (wave64 instructions) from
 # profiles/r01_g_pmc_valu.csv, level-1 / level-0 launch; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 op
 VALU_INSTS_1024x436 = (3.1347e+08 + 1.2386e+09) / 2

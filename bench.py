@@ -4,24 +4,31 @@
 A step = one pass of the hot path (set_data's device part: prefilter + pyramid + census, then
 compute_flow: PatchMatch fwd/bwd at 1/4 res, L-R check, outlier removal, weighted median, hole fill,
 two coarse-to-fine levels, final smoothing) over ONE synthetic 1024x436 pair whose RGBA planes are
-already resident in HBM.  Steps are issued round robin over --inflight contexts (default 3), each on its own HIP stream, so the
-quarter-resolution stages of one pair (latency bound: too few pixels to fill 256 CUs) overlap the
-full-resolution stages of another; every step's work runs inside the timed region and the single-pair
-latency is reported next to the throughput.  N > 1: one process per GPU, each rank its own pairs
-(independent pairs, no data-path collective: SURVEY 8e); value = pairs of all ranks * W*H / max-over-ranks time.
+already resident in HBM.  Steps are issued round robin over --inflight contexts (default 3), each on its
+own HIP stream, so the quarter-resolution stages of one pair (latency bound: too few pixels to fill 256
+CUs) overlap the full-resolution stages of another; every step's work runs inside the timed region.
 
-Prints one JSON line (see the task contract) with `roofline` (dominant kernel: the level-0 plane-fit
-candidate refine, algorithmic HBM bytes / HIP-event duration) and `cpu_baseline` (the CPU oracle on a
-bounded sample, rank 0, N=1 only).
+N > 1 (`--gpus N`): one process per GPU, each rank its own pairs (independent pairs, no data-path
+collective: SURVEY 8e); value = pairs of all ranks * W*H / max-over-ranks time.  When RANK is not in the
+environment (plain `python bench.py --gpus N`) this process only spawns the N rank processes -- before
+importing torch or touching HIP -- relays rank 0's JSON line and exits non-zero if any rank failed; under
+`torch.distributed.run` (RANK set) it is a rank itself.
+
+Prints ONE JSON line: the contract fields, `roofline` (dominant kernel k_c2f_refine_tiled: algorithmic HBM
+bytes per launch / its mean HIP-event duration on the context's stream over the timed steps), and, on rank 0
+at N = 1: `valu_roofline` and `stage_ms` from a separate single-stream pass (no contention from other
+pairs), `latency_ms_per_pair`, `host_boundary` (PCIe-inclusive rates through eppm_set_images + eppm_compute),
+`cold_ms` (init + compute_flow, the window main.cpp:63-66 times), `config3` (8 distinct pairs per GPU:
+BASELINE.json configs[2]) and `cpu_baseline` (the CPU oracle on a bounded sample).
 """
 import argparse
-import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -31,18 +38,12 @@ W, H = 1024, 436               # BASELINE.json configs[1]
 # algorithmic HBM bytes per pixel of one k_c2f_refine launch (the dominant kernel; it runs once at level 1 and
 # once at level 0 per pair): reads flow 8 + img1 4 + img2 4 + census1 1 + census2 1, writes flow 8
 REFINE_BYTES_PER_PX = 26
-# HBM-side bytes per k_c2f_refine_tiled launch at 1024x436, mean of the level-1 and level-0 launches, from the PMC
-# passes committed under profiles/r01_g_pmc_{fetch,write}_size.csv: FETCH_SIZE 3621.8 / 11486.4 KB (x2: gfx950 tallies
-# the 128-B requests of 16-B-per-lane loads at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE 15710.4 / 3488.0 KB
-# (the level-1 launch is split by affine pass and writes 36 costs per pixel instead of the flow)
-TRAFFIC_BYTES_1024x436 = ((2 * 3621.8 + 15710.4) + (2 * 11486.4 + 3488.0)) / 2 * 1024
-# The kernel is bound by vector-ALU issue, not by HBM: SQ_INSTS_VALU per launch (wave64 instructions) from
-# profiles/r01_g_pmc_valu.csv, level-1 / level-0 launch; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 op
-VALU_INSTS_1024x436 = (3.1347e+08 + 1.2386e+09) / 2
-VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2      # 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
+KERNEL_SOURCES = ["eppm_amd/csrc/k_c2f.hip", "eppm_amd/csrc/eppm_device.cuh"]
 
 
-def main():
+def parse_args(known_only=False):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=120)
@@ -52,12 +53,59 @@ def main():
     ap.add_argument("--patch-r", type=int, default=9)
     ap.add_argument("--inflight", type=int, default=3,
                     help="pairs in flight per GPU: steps are issued round robin over this many contexts, each on its own HIP stream")
+    ap.add_argument("--pairs-per-gpu", type=int, default=8, help="size of the config-3 leg (distinct pairs per GPU)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per k_c2f_refine launch from a separate rocprofv3 --pmc pass (profiles/)")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip host_boundary / cold / config3 / single-stream legs (profiling runs)")
+    return ap.parse_known_args()[0] if known_only else ap.parse_args()
 
+
+def parse_args_known():
+    return parse_args(known_only=True)
+
+
+# ---------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: the parent spawns the ranks (it never imports torch nor touches the GPU)
+# ---------------------------------------------------------------------------------------------------
+def spawn_ranks(args, script=None):
+    """script: the rank program (default: this file); tests substitute a stub."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if line:
+        print(line[-1], flush=True)
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad or not line:
+        print(f"[bench] ranks failed: {bad}" if bad else "[bench] rank 0 printed no JSON line", file=sys.stderr)
+        sys.exit(1)
+
+
+def pmc_constants(w, h, patch_r):
+    """PMC-derived constants of the dominant kernel, valid only for the kernel sources they were measured on
+    (profiles/pmc_constants.json is keyed by the sha256 of those sources); None when nothing matches."""
+    try:
+        hsh = hashlib.sha256(b"".join(open(os.path.join(ROOT, f), "rb").read() for f in KERNEL_SOURCES)).hexdigest()
+        tab = json.load(open(PMC_FILE))
+        e = tab.get(hsh)
+        if e and (e["width"], e["height"], e["patch_r"]) == (w, h, patch_r):
+            return e
+    except Exception:
+        pass
+    return None
+
+
+def worker(args):
+    import numpy as np
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,16 +142,18 @@ def main():
         engs.append(e)
     eng = engs[0]
 
-    # synthetic pairs of this rank (one per context), as RGBA planes resident in HBM before the timed region
+    # synthetic pairs of this rank, as RGBA planes resident in HBM before any timed region
     def to_dev(img):
         rgba = np.zeros((h, w, 4), np.uint8)
         rgba[..., :3] = img
         return torch.from_numpy(rgba).to(dev)
-    inputs = []
-    for j in range(S):
-        img1, img2, gu_j, gv_j = synth.make_pair(h, w, seed=1234 + rank * S + j)
+    NP = max(S, 0 if args.no_extras else args.pairs_per_gpu)
+    host_pairs, inputs = [], []
+    for j in range(NP):
+        img1, img2, gu_j, gv_j = synth.make_pair(h, w, seed=1234 + rank * NP + j)
         if j == 0:
             gu, gv = gu_j, gv_j
+        host_pairs.append((img1, img2))
         inputs.append((to_dev(img1), to_dev(img2), torch.empty((h, w, 2), dtype=torch.float32, device=dev)))
     d_flow = inputs[0][2]
     pitch = w * 4
@@ -114,9 +164,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(i):
+    def all_max(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    def step(i, npairs=S):
         e = engs[i % S]
-        a, b, f = inputs[i % S]
+        a, b, f = inputs[i % npairs]
         e.set_data_device(a.data_ptr(), b.data_ptr(), pitch)
         e.compute_flow_device(f.data_ptr())
 
@@ -127,16 +184,9 @@ def main():
     for i in range(max(args.warmup, S)):
         step(i)
     sync_all()
-    # single-pair latency (one context, one stream, nothing else in flight): reported beside the throughput
-    lat = []
-    for _ in range(5):
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        step(0)
-        engs[0].synchronize()
-        lat.append((time.perf_counter() - t1) * 1e3)
-    latency_ms = float(np.median(lat))
-    eng.enable_stage_timing(True)
+
+    # ---- the timed region: exactly --steps steps; events only around the dominant kernel, from a pool ----
+    eng.enable_stage_timing(2)
     eng.stage_times(clear=True)
     barrier()
     t0 = time.perf_counter()
@@ -144,29 +194,41 @@ def main():
         step(i)
     sync_all()
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    stages = eng.stage_times(clear=True)
-    eng.enable_stage_timing(False)
+    dt = all_max(time.perf_counter() - t0)
+    dom = eng.stage_times(clear=True)
+    eng.enable_stage_timing(0)
 
     # sanity: the flow is finite and close to the synthetic ground truth (not a parity check)
     flow = d_flow.cpu().numpy()
     epe_gt = float(np.sqrt((flow[..., 0] - gu) ** 2 + (flow[..., 1] - gv) ** 2).mean())
 
+    extras = {}
+    if not args.no_extras:
+        # ---- config 3 (BASELINE.json configs[2]): --pairs-per-gpu DISTINCT pairs per GPU, same issue scheme ----
+        for i in range(NP):
+            step(i, NP)
+        sync_all()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(NP):
+            step(i, NP)
+        sync_all()
+        barrier()
+        dt3 = all_max(time.perf_counter() - t0)
+        extras["config3"] = {"workload": f"{NP} distinct {w}x{h} pairs per GPU x {world} GPU(s), one pass, {S} contexts in flight per GPU",
+                             "pairs": NP * world, "value": world * NP * w * h / dt3 / 1e6, "unit": "Mflow-vectors/s", "ms_per_pair": dt3 / NP * 1e3}
+
     if rank == 0:
         agg = {}
-        for name, ms in stages:
+        for name, ms in dom:
             agg.setdefault(name, []).append(ms)
-        stage_ms = {k: float(np.mean(v)) for k, v in agg.items()}
-        # dominant kernel = k_c2f_refine_tiled; per launch = mean over its two launches per pair (levels 1 and 0),
-        # which is what rocprofv3 --stats averages for that kernel name
         lv = eng.level_dims()
-        dom_ms = (stage_ms.get("c2f_refine_L0", float("nan")) + stage_ms.get("c2f_refine_L1", float("nan"))) / 2
+        # dominant kernel = k_c2f_refine_tiled; per launch = mean over its two launches per pair (levels 1 and 0),
+        # which is what rocprofv3 --stats averages for that kernel name family
+        dom_ms = (float(np.mean(agg["c2f_refine_L0"])) + float(np.mean(agg["c2f_refine_L1"]))) / 2
         alg_bytes = REFINE_BYTES_PER_PX * (lv[0][0] * lv[0][1] + lv[1][0] * lv[1][1]) / 2
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        pmc = pmc_constants(w, h, args.patch_r)
         out = {
             "metric": "Mflow-vectors/sec", "value": world * args.steps * w * h / dt / 1e6, "unit": "Mflow-vectors/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -174,18 +236,18 @@ def main():
             "config": {"workload": f"single {w}x{h} Sintel-shape synthetic pair per step, full 3-level pyramid, patch_r={args.patch_r}, "
                                    f"default defs.h parameters; {world} rank(s), independent pairs",
                        "pairs_per_step_per_gpu": 1, "pairs_in_flight_per_gpu": S, "width": w, "height": h},
-            "roofline": {"bound": "hbm", "kernel": "k_c2f_refine_tiled (mean of its level-1 and level-0 launches)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": args.traffic_bytes if args.traffic_bytes is not None else (TRAFFIC_BYTES_1024x436 if (w, h, args.patch_r) == (W, H, 9) else None),
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms},
-            "valu_roofline": ({"kernel": "k_c2f_refine_tiled", "wave64_valu_insts_per_launch": VALU_INSTS_1024x436,
-                               "achieved_insts_per_s": VALU_INSTS_1024x436 / (dom_ms * 1e-3), "peak_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
-                               "frac": VALU_INSTS_1024x436 / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S}
-                              if (w, h, args.patch_r) == (W, H, 9) else None),
-            "latency_ms_per_pair": latency_ms,
-            "stage_ms": stage_ms,
+            "roofline": {"bound": "hbm", "kernel": "k_c2f_refine_tiled (mean of its level-1 and level-0 launches, timed region, all streams busy)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                         "note": "the kernel is VALU-issue bound (3 600 patch samples x ~49 instructions per pixel against 26 bytes): see valu_roofline"},
             "epe_vs_synthetic_gt": epe_gt,
         }
+        out.update(extras)
+        if world == 1 and not args.no_extras:
+            out.update(single_stream_legs(args, eng, inputs, pitch, pmc, alg_bytes))
+            out["host_boundary"] = host_boundary(args, engs, host_pairs)
+            out["cold_ms"] = cold_window(args, local_rank, params, host_pairs[0])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h)
         print(json.dumps(out), flush=True)
@@ -193,19 +255,117 @@ def main():
         dist.destroy_process_group()
 
 
+def single_stream_legs(args, eng, inputs, pitch, pmc, alg_bytes):
+    """One context, one stream, nothing else in flight: per-pair latency, per-stage device times and the dominant
+    kernel against the bound that limits it (vector-ALU issue), free of the contention of the throughput window."""
+    import numpy as np
+    a, b, f = inputs[0]
+    lat = []
+    for _ in range(7):
+        eng.synchronize()
+        t1 = time.perf_counter()
+        eng.set_data_device(a.data_ptr(), b.data_ptr(), pitch)
+        eng.compute_flow_device(f.data_ptr())
+        eng.synchronize()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    eng.enable_stage_timing(1)
+    eng.stage_times(clear=True)
+    for _ in range(10):
+        eng.set_data_device(a.data_ptr(), b.data_ptr(), pitch)
+        eng.compute_flow_device(f.data_ptr())
+        eng.synchronize()
+    st = eng.stage_times(clear=True)
+    eng.enable_stage_timing(0)
+    agg = {}
+    for name, ms in st:
+        agg.setdefault(name, []).append(ms)
+    stage_ms = {k: float(np.mean(v)) for k, v in agg.items()}
+    out = {"latency_ms_per_pair": float(np.median(lat)), "stage_ms": stage_ms}
+    dom1 = (stage_ms["c2f_refine_L0"] + stage_ms["c2f_refine_L1"]) / 2
+    out["roofline_single_stream"] = {"achieved": alg_bytes / (dom1 * 1e-3) / 1e9, "unit": "GB/s", "avg_launch_ms": dom1}
+    if pmc:
+        v = pmc["valu_insts_per_launch"]
+        out["valu_roofline"] = {"bound": "valu", "kernel": "k_c2f_refine_tiled, single stream", "wave64_valu_insts_per_launch": v,
+                                "achieved_insts_per_s": v / (dom1 * 1e-3), "peak_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
+                                "frac": v / (dom1 * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S, "avg_launch_ms": dom1, "source": pmc.get("source")}
+    else:
+        out["valu_roofline"] = None
+    return out
+
+
+def host_boundary(args, engs, host_pairs):
+    """Through the host-pointer boundary (eppm_set_images + eppm_compute: RGB->RGBA, H2D, path, D2H, de-interleave):
+    synchronous on one context, and pipelined over the contexts in flight by one host thread.  PCIe-inclusive: never `value`."""
+    from eppm_amd import shard
+    w, h = args.width, args.height
+    a, b = host_pairs[0]
+    e = engs[0]
+    for _ in range(2):
+        e.set_data(a, b)
+        e.compute_flow()
+    n = 16
+    t = time.perf_counter()
+    for _ in range(n):
+        e.set_data(a, b)
+        e.compute_flow()
+    dt_sync = (time.perf_counter() - t) / n
+    pairs = [host_pairs[i % len(host_pairs)] for i in range(24)]
+    shard.run_pairs_pipelined(engs, pairs, range(len(engs) * 2))
+    t = time.perf_counter()
+    shard.run_pairs_pipelined(engs, pairs, range(len(pairs)))
+    dt_pipe = (time.perf_counter() - t) / len(pairs)
+    return {"unit": "Mflow-vectors/s", "sync": w * h / dt_sync / 1e6, "sync_ms_per_pair": dt_sync * 1e3,
+            "pipelined": w * h / dt_pipe / 1e6, "pipelined_ms_per_pair": dt_pipe * 1e3, "contexts_in_flight": len(engs),
+            "note": "host RGB in, host u/v out; includes RGB->RGBA, H2D 2x3wh B, D2H 8wh B and the de-interleave"}
+
+
+def cold_window(args, device, params, pair):
+    """init + compute_flow on a fresh object, the window main.cpp:63-66 times (allocation included); median of 3."""
+    import numpy as np
+    import eppm_amd
+    w, h = args.width, args.height
+    ts = []
+    for _ in range(3):
+        t = time.perf_counter()
+        e = eppm_amd.EPPM(device=device, params=params)
+        e.init(pair[0], pair[1], h, w)
+        e.compute_flow()
+        ts.append((time.perf_counter() - t) * 1e3)
+        e.close()
+    return float(np.median(ts))
+
+
 def cpu_baseline(w, h):
     """The CPU oracle (oracle/, a port of the reference's kernel semantics: the reference has no CPU path)
-    timed on this host on a bounded sample: the workload's pair once (about 25 s on 8 cores, 6 s on 128)."""
+    timed on this host on bounded samples: all cores on the workload's own pair once (about 25 s on 8 cores, 5 s on
+    128), and ONE thread on the pair's centre quarter (w/2 x h/2: a quarter of the vectors, about 12 s)."""
     from oracle import oracle as O
     from eppm_amd import synth
-    sw, sh = w, h
-    a, b, _, _ = synth.make_pair(sh, sw, seed=1234)
+    a, b, _, _ = synth.make_pair(h, w, seed=1234)
     O.compute_flow(a[:32, :32].copy(), b[:32, :32].copy())      # build + warm
     t0 = time.perf_counter()
     O.compute_flow(a, b)
     dt = time.perf_counter() - t0
-    return {"value": sw * sh / dt / 1e6, "unit": "Mflow-vectors/s", "cores": O.num_threads(), "kind": "port",
-            "sample": f"1 pair {sw}x{sh} (the workload's own pair, seed 1234), whole path once, {dt:.1f} s, OpenMP oracle"}
+    n_all = O.num_threads()
+    qh, qw = h // 2, w // 2
+    qa, qb = a[h // 4:h // 4 + qh, w // 4:w // 4 + qw].copy(), b[h // 4:h // 4 + qh, w // 4:w // 4 + qw].copy()
+    O.set_num_threads(1)
+    t0 = time.perf_counter()
+    O.compute_flow(qa, qb)
+    dt1 = time.perf_counter() - t0
+    O.set_num_threads(n_all)
+    return {"value": w * h / dt / 1e6, "unit": "Mflow-vectors/s", "cores": n_all, "kind": "port",
+            "sample": f"1 pair {w}x{h} (the workload's own pair, seed 1234), whole path once, {dt:.1f} s, OpenMP oracle",
+            "single_thread": {"value": qw * qh / dt1 / 1e6, "unit": "Mflow-vectors/s", "cores": 1,
+                              "sample": f"centre {qw}x{qh} crop of the same pair, whole path once, {dt1:.1f} s, one thread"}}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args)
+        return
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@ SYMBOLS = [
     "eppm_device_synchronize", "eppm_device_mem_info", "eppm_set_launcher_stream", "eppm_set_launcher_params", "eppm_launcher_status",
     "baoCudaPatchMatchMultiscalePrepare", "baoCudaCensusTransform", "baoCudaPatchMatch", "baoCudaLeftRightCheck",
     "baoCudaOutlierRemoval", "baoCudaWeightedMedianFilter", "baoCudaFillHole", "baoCudaNNF2Flow", "baoCudaBLF_C2F",
-    "baoCudaBLFCostFilterRefine", "baoCudaFlowSmoothing",
+    "baoCudaBLFCostFilterRefine", "baoCudaFlowSmoothing", "eppm_flow_to_color", "eppm_compute_color",
     "eppm_pm_rng_create", "eppm_pm_rng_reset", "eppm_pm_rng_destroy", "eppm_pm_rng_block_states", "eppm_pm_gen_rand_field",
     "eppm_pm_cost_field", "eppm_pm_seg_propagate", "eppm_pm_jump_propagate", "eppm_pm_parallel_propagate", "eppm_pm_random_search", "eppm_gauss_filter_rgba", "eppm_resize_rgba",
     "eppm_resize_flow", "eppm_probe_fast_exp", "eppm_probe_div_const",

@@ -71,6 +71,14 @@ class EPPM:
         check(lib().eppm_compute(self._ctx, u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "eppm_compute")
         return u, v
 
+    def compute_flow_color(self, max_disp=(20.0, 20.0)):
+        """The optional color_flow output of compute_flow (driver .cpp:308-314): (h, w, 3) uint8 R,G,B of the last flow."""
+        self._need()
+        rgb = np.empty((self.h, self.w, 3), np.uint8)
+        check(lib().eppm_compute_color(self._ctx, rgb.ctypes.data_as(C.c_void_p), C.c_size_t(self.w * 3),
+                                       C.c_float(max_disp[0]), C.c_float(max_disp[1])), "eppm_compute_color")
+        return rgb
+
     def compute_flow_begin(self):
         """Enqueue compute_flow and its device-to-host copy, return at once (eppm_compute_begin)."""
         self._need()

@@ -88,44 +88,6 @@ bool bao_flow_patchmatch_multiscale_cuda::set_data(unsigned char*** img1, unsign
     return true;
 }
 
-// Middlebury colour wheel (3rdparty/middlebury/colorcode.cpp:30-78, also basic/bao_basic_cuda.cuh:751-829)
-struct Wheel {
-    int ncols;
-    int c[60][3];
-    Wheel();
-    void setcols(int r, int g, int b, int k) { c[k][0] = r; c[k][1] = g; c[k][2] = b; }
-};
-Wheel::Wheel()
-{
-    const int RY = 15, YG = 6, GC = 4, CB = 11, BM = 13, MR = 6;
-    int k = 0;
-    for (int i = 0; i < RY; i++) setcols(255, 255 * i / RY, 0, k++);
-    for (int i = 0; i < YG; i++) setcols(255 - 255 * i / YG, 255, 0, k++);
-    for (int i = 0; i < GC; i++) setcols(0, 255, 255 * i / GC, k++);
-    for (int i = 0; i < CB; i++) setcols(0, 255 - 255 * i / CB, 255, k++);
-    for (int i = 0; i < BM; i++) setcols(255 * i / BM, 0, 255, k++);
-    for (int i = 0; i < MR; i++) setcols(255, 0, 255 - 255 * i / MR, k++);
-    ncols = k;
-}
-static void flow_color(float fx, float fy, unsigned char* pix)
-{
-    static const Wheel wheel;          // built once, thread-safe (contexts may run on several host threads)
-    const int g_ncols = wheel.ncols;
-    const int (*g_wheel)[3] = wheel.c;
-    const float rad = sqrtf(fx * fx + fy * fy);
-    const float a = atan2f(-fy, -fx) / (float)M_PI;
-    const float fk = (a + 1.0f) / 2.0f * (g_ncols - 1);
-    const int k0 = (int)fk, k1 = (k0 + 1) % g_ncols;
-    const float f = fk - k0;
-    for (int b = 0; b < 3; b++) {
-        const float col0 = g_wheel[k0][b] / 255.0f, col1 = g_wheel[k1][b] / 255.0f;
-        float col = (1 - f) * col0 + f * col1;
-        if (rad <= 1) col = 1 - rad * (1 - col);
-        else col *= .75f;
-        pix[b] = (unsigned char)(255.0f * col);
-    }
-}
-
 // driver .cpp:217-315
 void bao_flow_patchmatch_multiscale_cuda::compute_flow(float** disp1_x, float** disp1_y, unsigned char*** color_flow)
 {
@@ -140,12 +102,14 @@ void bao_flow_patchmatch_multiscale_cuda::compute_flow(float** disp1_x, float** 
             disp1_y[i][j] = m_v[(size_t)i * m_w + j];
         }
     if (color_flow != NULL) {
-        // bao_cuda_convert_flow_to_colorshow(d_colorflow, flow, h, w, 20, 20), driver .cpp:311: flow normalised by (20,20)
+        // bao_cuda_convert_flow_to_colorshow(d_colorflow, flow, h, w, 20, 20) on the device flow, D2H, bao_rgba2rgb: driver .cpp:308-314
+        unsigned char* rgb = m_stage;          // h*w*3 of the RGB staging buffer
+        if (eppm_compute_color(m_ctx, rgb, (size_t)m_w * 3, 20, 20) != EPPM_OK) {
+            fprintf(stderr, "bao_flow_patchmatch_multiscale_cuda::compute_flow (color): %s\n", eppm_last_error());
+            return;
+        }
         for (int i = 0; i < m_h; i++)
-            for (int j = 0; j < m_w; j++) {
-                float fx = m_u[(size_t)i * m_w + j], fy = m_v[(size_t)i * m_w + j];
-                if (fabsf(fx) > 1e9f || fabsf(fy) > 1e9f) { color_flow[i][j][0] = color_flow[i][j][1] = color_flow[i][j][2] = 0; continue; }
-                flow_color(fx / 20.0f, fy / 20.0f, color_flow[i][j]);
-            }
+            for (int j = 0; j < m_w; j++)
+                for (int c = 0; c < 3; c++) color_flow[i][j][c] = rgb[((size_t)i * m_w + j) * 3 + c];
     }
 }

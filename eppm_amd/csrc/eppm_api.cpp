@@ -203,13 +203,16 @@ struct eppm_ctx {
     float* c2f_cost9[kMaxLevels] = {};  // 9 candidates x 4 passes costs per pixel, only for levels whose refine launch is split
     float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
     eppm_pm_rng* rng = nullptr;
+    uint32_t* d_color = nullptr;        // colour-coded flow (optional output), allocated on first use
+    uint32_t* h_color = nullptr;        // pinned
     uint8_t* d_rgb = nullptr;           // staging for host RGB input
     uint8_t* h_rgb = nullptr;           // pinned
     float* h_flow = nullptr;            // pinned
     bool have_images = false, have_flow = false;
-    bool timing = false;
+    int timing = 0;                     // 0 off, 1 every stage, 2 only the dominant kernel (the candidate refine)
     std::vector<StageEv> ev;
     std::vector<StageEv> ev_prep;
+    std::vector<hipEvent_t> ev_pool;    // events are created once and reused: no hipEventCreate in a steady-state step
 };
 
 static PlanesH planes(const eppm_ctx* c, int l, bool swap)
@@ -222,24 +225,32 @@ static PlanesH planes(const eppm_ctx* c, int l, bool swap)
     return p;
 }
 
-static void stage_begin(eppm_ctx* c, std::vector<StageEv>& v, const char* name)
+static hipEvent_t pool_event(eppm_ctx* c)
 {
-    if (!c->timing) return;
+    hipEvent_t e = nullptr;
+    if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+    else (void)hipEventCreate(&e);
+    return e;
+}
+static bool stage_on(const eppm_ctx* c, bool dominant) { return c->timing == 1 || (c->timing == 2 && dominant); }
+static void stage_begin(eppm_ctx* c, std::vector<StageEv>& v, const char* name, bool dominant = false)
+{
+    if (!stage_on(c, dominant)) return;
     StageEv e;
     e.name = name;
-    (void)hipEventCreate(&e.a);
-    (void)hipEventCreate(&e.b);
+    e.a = pool_event(c);
+    e.b = pool_event(c);
     (void)hipEventRecord(e.a, c->stream);
     v.push_back(e);
 }
-static void stage_end(eppm_ctx* c, std::vector<StageEv>& v)
+static void stage_end(eppm_ctx* c, std::vector<StageEv>& v, bool dominant = false)
 {
-    if (!c->timing) return;
+    if (!stage_on(c, dominant)) return;
     (void)hipEventRecord(v.back().b, c->stream);
 }
-static void clear_events(std::vector<StageEv>& v)
+static void clear_events(eppm_ctx* c, std::vector<StageEv>& v)
 {
-    for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : v) { c->ev_pool.push_back(e.a); c->ev_pool.push_back(e.b); }
     v.clear();
 }
 
@@ -248,8 +259,9 @@ extern "C" int eppm_destroy(eppm_ctx* c)
     if (!c) return EPPM_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    clear_events(c->ev);
-    clear_events(c->ev_prep);
+    clear_events(c, c->ev);
+    clear_events(c, c->ev_prep);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipFree(c->raw1); (void)hipFree(c->raw2);
     for (int i = 0; i < kMaxLevels; i++) {
         (void)hipFree(c->img1[i]); (void)hipFree(c->img2[i]); (void)hipFree(c->tmpu[i]);
@@ -259,7 +271,8 @@ extern "C" int eppm_destroy(eppm_ctx* c)
     (void)hipFree(c->nnf1); (void)hipFree(c->nnf2); (void)hipFree(c->nnf_tmp); (void)hipFree(c->nnf_tmp2);
     (void)hipFree(c->cost1); (void)hipFree(c->cost2); (void)hipFree(c->wmf_ws);
     (void)hipFree(c->lut_pm); (void)hipFree(c->lut_wmf); (void)hipFree(c->lut_blf);
-    (void)hipFree(c->d_rgb);
+    (void)hipFree(c->d_rgb); (void)hipFree(c->d_color);
+    if (c->h_color) (void)hipHostFree(c->h_color);
     if (c->h_rgb) (void)hipHostFree(c->h_rgb);
     if (c->h_flow) (void)hipHostFree(c->h_flow);
     rng_free(c->rng);
@@ -363,7 +376,7 @@ extern "C" int eppm_level_dims(const eppm_ctx* c, int level, int* h, int* w)
 extern "C" int eppm_enable_stage_timing(eppm_ctx* c, int on)
 {
     if (!c) return set_err(EPPM_ERR_ARG, "NULL ctx");
-    c->timing = on != 0;
+    c->timing = (on == 2) ? 2 : (on != 0);
     return EPPM_OK;
 }
 
@@ -538,9 +551,9 @@ extern "C" int eppm_compute_device(eppm_ctx* c, void* d_flow)
         stage_begin(c, c->ev, up_names[l]);
         launch_resize_flow(c->flow[l], c->H[l], c->W[l], c->flow[l + 1], c->H[l + 1], c->W[l + 1], 2.0f, 2.0f, s);   // refine :1082-1083
         stage_end(c, c->ev);
-        stage_begin(c, c->ev, rf_names[l]);
+        stage_begin(c, c->ev, rf_names[l], true);
         launch_c2f_refine(planes(c, l, false), c->flow[l], c->lut_pm, c->prm.patch_r, c->c2f_cost9[l], s);   // refine :1086
-        stage_end(c, c->ev);
+        stage_end(c, c->ev, true);
         stage_begin(c, c->ev, bl_names[l]);
         launch_flow_blf(c->flow_tmp[l], c->flow[l], c->img1[l], (int)(c->ipitch[l] / 4), c->W[l], c->H[l], c->W[l], c->lut_blf, s);  // driver :280
         std::swap(c->flow[l], c->flow_tmp[l]);
@@ -613,8 +626,8 @@ extern "C" int eppm_clear_stage_times(eppm_ctx* c)
 {
     if (!c) return set_err(EPPM_ERR_ARG, "NULL ctx");
     (void)hipStreamSynchronize(c->stream);
-    clear_events(c->ev);
-    clear_events(c->ev_prep);
+    clear_events(c, c->ev);
+    clear_events(c, c->ev_prep);
     return EPPM_OK;
 }
 
@@ -677,7 +690,7 @@ struct DevState {
 std::mutex g_mu;
 std::map<int, DevState> g_dev;
 hipStream_t g_stream = nullptr;
-eppm_params g_prm = {9, 10, 30, 6, 10, 20, 1234ULL, 0};
+eppm_params g_prm = {9, 10, 30, 6, 10, 20, 1234ULL, 0, kNumLevels};
 int g_launch_status = EPPM_OK;
 
 int dev_state(DevState** out)
@@ -734,6 +747,12 @@ int mk_planes(DevState* ds, PlanesH* out, const void* i1, const void* i2, const 
     return EPPM_OK;
 }
 int finish() { HIPCHK(hipGetLastError()); return EPPM_OK; }
+// device-to-device copy on the launcher stream whose failure reaches eppm_launcher_status()
+int copy_d2d(void* dst, const void* src, size_t bytes)
+{
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
+    return EPPM_OK;
+}
 }  // namespace
 
 #define LAUNCHER_BEGIN std::lock_guard<std::mutex> lk_(g_mu); DevState* ds = nullptr; g_launch_status = dev_state(&ds); if (g_launch_status != EPPM_OK) return
@@ -967,7 +986,7 @@ extern "C" void baoCudaPatchMatch(eppm_short2* d_disp_vec, float* d_cost, eppm_u
     if (g_launch_status != EPPM_OK) return;
     b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0);
     run_patchmatch(b, r, ds->lut_pm, g_prm, g_stream);
-    if (b.p[0].nnf != (int16_t*)d_disp_vec) (void)hipMemcpyAsync(d_disp_vec, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream);
+    if (b.p[0].nnf != (int16_t*)d_disp_vec && (g_launch_status = copy_d2d(d_disp_vec, b.p[0].nnf, disp_pitch * h)) != EPPM_OK) return;
     g_launch_status = finish();
 }
 
@@ -986,7 +1005,7 @@ extern "C" void baoCudaOutlierRemoval(eppm_short2* d_disp_vec, float* d_cost, in
     void* tmp = nullptr;
     g_launch_status = get_scratch(ds, disp_pitch * h, &tmp);
     if (g_launch_status != EPPM_OK) return;
-    (void)hipMemcpyAsync(tmp, d_disp_vec, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream);
+    if ((g_launch_status = copy_d2d(tmp, d_disp_vec, disp_pitch * h)) != EPPM_OK) return;
     launch_outlier((int16_t*)d_disp_vec, d_cost, (const int16_t*)tmp, w, h, (int)(cost_pitch / 4), (int)(disp_pitch / 4), g_stream);
     g_launch_status = finish();
 }
@@ -1004,7 +1023,7 @@ extern "C" void baoCudaWeightedMedianFilter(eppm_short2* d_disp_vec, float* d_co
     if (g_launch_status != EPPM_OK) return;
     int16_t* res = launch_wmf((int16_t*)d_disp_vec, (int16_t*)tmp, (const uint32_t*)d_img, (int)(img_pitch / 4), w, h, (int)(disp_pitch / 4),
                               ds->lut_wmf, num_iter, is_only_occlusion ? 1 : 0, (uint32_t*)ws, g_stream);
-    if (res != (int16_t*)d_disp_vec) (void)hipMemcpyAsync(d_disp_vec, res, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream);
+    if (res != (int16_t*)d_disp_vec && (g_launch_status = copy_d2d(d_disp_vec, res, disp_pitch * h)) != EPPM_OK) return;
     g_launch_status = finish();
 }
 
@@ -1016,7 +1035,7 @@ extern "C" void baoCudaFillHole(eppm_short2* d_disp_vec, float* d_cost, eppm_uch
     void* tmp = nullptr;
     g_launch_status = get_scratch(ds, disp_pitch * h, &tmp);
     if (g_launch_status != EPPM_OK) return;
-    (void)hipMemcpyAsync(tmp, d_disp_vec, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream);
+    if ((g_launch_status = copy_d2d(tmp, d_disp_vec, disp_pitch * h)) != EPPM_OK) return;
     launch_fill_holes((int16_t*)d_disp_vec, (const int16_t*)tmp, (const uint32_t*)d_img, (int)(img_pitch / 4), w, h, (int)(disp_pitch / 4), g_stream);
     g_launch_status = finish();
 }
@@ -1061,9 +1080,44 @@ extern "C" void baoCudaFlowSmoothing(eppm_float2* d_flow, eppm_uchar4* d_img, in
     void* tmp = nullptr;
     g_launch_status = get_scratch(ds, flow_pitch * h, &tmp);
     if (g_launch_status != EPPM_OK) return;
-    (void)hipMemcpyAsync(tmp, d_flow, flow_pitch * h, hipMemcpyDeviceToDevice, g_stream);
+    if ((g_launch_status = copy_d2d(tmp, d_flow, flow_pitch * h)) != EPPM_OK) return;
     launch_flow_blf((float*)d_flow, (const float*)tmp, (const uint32_t*)d_img, (int)(img_pitch / 4), w, h, (int)(flow_pitch / 8), ds->lut_blf, g_stream);
     g_launch_status = finish();
+}
+
+// ---- flow colour coding (basic/bao_basic_cuda.cuh:776-845; driver :308-314) ----
+extern "C" int eppm_flow_to_color(eppm_uchar4* d_rgba, const eppm_float2* d_flow, int h, int w, float max_disp_x, float max_disp_y)
+{
+    if (!d_rgba || !d_flow || h < 1 || w < 1) return set_err(EPPM_ERR_ARG, "eppm_flow_to_color: bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_flow_to_color((uint32_t*)d_rgba, (const float*)d_flow, h, w, max_disp_x, max_disp_y, g_stream);
+    return finish();
+}
+// the C++-linkage symbol the reference's driver declares at :64 (defaults 100,100 there; the live call passes 20,20)
+void bao_cuda_convert_flow_to_colorshow(uchar4* rgbflow, float2* flow_vec, int h, int w, float max_disp_x, float max_disp_y)
+{
+    g_launch_status = eppm_flow_to_color((eppm_uchar4*)rgbflow, (const eppm_float2*)flow_vec, h, w, max_disp_x, max_disp_y);
+}
+
+extern "C" int eppm_compute_color(eppm_ctx* c, uint8_t* rgb, size_t row_stride, float max_disp_x, float max_disp_y)
+{
+    if (!c || !rgb) return set_err(EPPM_ERR_ARG, "eppm_compute_color: NULL argument");
+    if (!c->have_flow) return set_err(EPPM_ERR_STATE, "eppm_compute_color: no flow computed yet");
+    if (row_stride < (size_t)c->w * 3) return set_err(EPPM_ERR_ARG, "eppm_compute_color: row_stride %zu < 3*w", row_stride);
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n = (size_t)c->h * c->w;
+    if (!c->d_color) HIPCHK(hipMalloc((void**)&c->d_color, n * 4));
+    if (!c->h_color) HIPCHK(hipHostMalloc((void**)&c->h_color, n * 4, hipHostMallocDefault));
+    launch_flow_to_color(c->d_color, c->flow[0], c->h, c->w, max_disp_x, max_disp_y, c->stream);       // driver :311
+    HIPCHK(hipMemcpyAsync(c->h_color, c->d_color, n * 4, hipMemcpyDeviceToHost, c->stream));           // driver :312
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int y = 0; y < c->h; y++)                                                                         // bao_rgba2rgb, driver :313
+        for (int x = 0; x < c->w; x++) {
+            const uint32_t p = c->h_color[(size_t)y * c->w + x];
+            uint8_t* o = rgb + (size_t)y * row_stride + (size_t)x * 3;
+            o[0] = (uint8_t)(p & 0xff); o[1] = (uint8_t)((p >> 8) & 0xff); o[2] = (uint8_t)((p >> 16) & 0xff);
+        }
+    return EPPM_OK;
 }
 
 extern "C" int eppm_launcher_status(void) { return g_launch_status; }

@@ -101,6 +101,10 @@ void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, f
 void launch_flow_blf(float* out, const float* in, const uint32_t* img, int ipitch, int w, int h, int flow_pitch,
                      const float* blf_lut, hipStream_t s);
 
+// ---- flow colour coding (k_color.hip) ----
+// rgba: h*w packed R | G<<8 | B<<16 (alpha 0); flow: h*w float2
+void launch_flow_to_color(uint32_t* rgba, const float* flow, int h, int w, float max_disp_x, float max_disp_y, hipStream_t s);
+
 // ---- probes (k_prepare.hip) ----
 void launch_probe(const float* x, float* y, int n, int which, hipStream_t s);
 

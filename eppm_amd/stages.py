@@ -289,3 +289,11 @@ def flow_smoothing(flow, img):
     lib().baoCudaFlowSmoothing(f.ptr, i.ptr, w, h, _sz(i.pitch), _sz(f.pitch))
     check_launcher("baoCudaFlowSmoothing")
     return f.get()
+
+
+def flow_to_color(flow, max_disp_x=20.0, max_disp_y=20.0):
+    """bao_cuda_convert_flow_to_colorshow (float2 form, basic/bao_basic_cuda.cuh:839-845): (h,w) float2 -> (h,w) uchar4 {R,G,B,0}."""
+    h, w = flow.shape
+    f, c = Dev(flow), Dev(shape=(h, w), dtype=uchar4)
+    check(lib().eppm_flow_to_color(c.ptr, f.ptr, h, w, C.c_float(max_disp_x), C.c_float(max_disp_y)), "eppm_flow_to_color")
+    return c.get()

@@ -15,6 +15,7 @@
 #define _BAO_FLOW_PATCHMATCH_MULTISCALE_CUDA_H_
 
 #include <stddef.h>
+#include "bao_basic_cuda.h"   /* as the reference's header does (:31): callers get bao_timer_gpu / bao_timer_gpu_cpu through it */
 
 struct eppm_ctx;
 

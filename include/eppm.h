@@ -76,7 +76,9 @@ int  eppm_set_stream(eppm_ctx* ctx, void* hip_stream);
 /* Host images: h rows of w RGB triplets, row_stride bytes apart (>= 3*w).  RGB->RGBA, H2D,
  * prefilter, pyramid, census (set_data + _prepare_data, driver .cpp:159-168,212-215). */
 int  eppm_set_images(eppm_ctx* ctx, const uint8_t* rgb1, const uint8_t* rgb2, size_t row_stride);
-/* Device-resident RGBA (uchar4, alpha ignored/0) images, pitch in bytes: runs prepare only. */
+/* Device-resident RGBA (uchar4, alpha ignored/0) images, pitch in bytes: runs prepare only.  Asynchronous on the context's
+ * stream: the planes must be complete before the call (or produced on that stream) and must stay valid and unmodified
+ * until eppm_synchronize() or a later synchronous call on this context returns -- the prefilter may read them in place. */
 int  eppm_set_images_device(eppm_ctx* ctx, const void* d_rgba1, const void* d_rgba2, size_t pitch);
 
 /* compute_flow (driver .cpp:217-306).  u, v: h*w floats each (host). Synchronous. */
@@ -86,6 +88,10 @@ int  eppm_compute(eppm_ctx* ctx, float* u, float* v);
  * this context's stream and writes u, v.  eppm_set_images on a context waits for that context's previous work. */
 int  eppm_compute_begin(eppm_ctx* ctx);
 int  eppm_compute_end(eppm_ctx* ctx, float* u, float* v);
+/* Optional colour-coded flow of the last eppm_compute* (compute_flow's color_flow argument, driver .cpp:308-314):
+ * Middlebury colour wheel on the device flow (basic/bao_basic_cuda.cuh:776-845), h rows of w R,G,B triplets,
+ * row_stride bytes apart.  The reference calls it with max_disp (20,20). */
+int  eppm_compute_color(eppm_ctx* ctx, uint8_t* rgb, size_t row_stride, float max_disp_x, float max_disp_y);
 /* Same, asynchronous on the context's stream; the interleaved float2 flow stays in HBM.
  * d_flow may be NULL (result kept in the context; fetch with eppm_get_plane("flow",0)). */
 int  eppm_compute_device(eppm_ctx* ctx, void* d_flow);
@@ -105,7 +111,8 @@ int  eppm_get_plane(eppm_ctx* ctx, const char* name, int level, void* dst, size_
  * names[i] points to static strings.  Returns the number of entries written (<= max). */
 int  eppm_stage_times(eppm_ctx* ctx, const char** names, float* ms, int max);
 int  eppm_clear_stage_times(eppm_ctx* ctx);
-/* Enable/disable the per-stage events (off by default: they serialise nothing but cost a few us). */
+/* 0: no events (default); 1: an event pair around every stage; 2: only around the dominant kernel (the candidate
+ * refine, entries "c2f_refine_L<l>").  Events come from a per-context pool: none is created in a steady-state step. */
 int  eppm_enable_stage_timing(eppm_ctx* ctx, int on);
 
 const char* eppm_last_error(void);
@@ -173,6 +180,11 @@ void baoCudaBLFCostFilterRefine(eppm_float2* d_flow_vec, eppm_uchar4* d_img1, ep
         unsigned char* d_census2, int w, int h, size_t img_pitch, size_t census_pitch);
 /* bao_pmflow_refine_kernel.cu:801-826 */
 void baoCudaFlowSmoothing(eppm_float2* d_flow, eppm_uchar4* d_img, int w, int h, size_t img_pitch, size_t flow_pitch);
+/* basic/bao_basic_cuda.cuh:839-845 (float2 form): d_rgba h*w uchar4 {R,G,B,0}, d_flow h*w float2, both unpitched.
+ * The library also exports the C++-linkage symbol the reference's driver declares at :64,
+ *   void bao_cuda_convert_flow_to_colorshow(uchar4*, float2*, int h, int w, float max_disp_x, float max_disp_y)
+ * (HIP vector types; a C header cannot declare it). */
+int  eppm_flow_to_color(eppm_uchar4* d_rgba, const eppm_float2* d_flow, int h, int w, float max_disp_x, float max_disp_y);
 
 /* ----------------------------------------------------------------------------------------
  * sub-stage entry points of PatchMatch (for parity tests at kernel granularity).  They mirror
@@ -180,6 +192,10 @@ void baoCudaFlowSmoothing(eppm_float2* d_flow, eppm_uchar4* d_img, int w, int h,
  * baoRandomSearch (bao_pmflow_kernel.cu:153-165, 689-696, 1167-1181, 1588-1594), with the
  * texture bindings and the global RNG state made explicit arguments.
  * rng: opaque device buffer from eppm_pm_rng_create (one XORWOW stream per 16x16 block).
+ * PRECONDITION of the three propagate entry points: d_cost[p] is the patch cost of d_nnf[p] (as eppm_pm_cost_field,
+ * a propagate or a search leaves it).  A candidate equal to the pixel's stored match is rejected without being
+ * evaluated -- it would reproduce the stored cost bit for bit, and the reference's strict `<` rejects it too; with a
+ * cost plane that is NOT consistent with the NNF the reference would re-evaluate and could lower the cost, these would not.
  * -------------------------------------------------------------------------------------- */
 typedef struct eppm_pm_rng eppm_pm_rng;
 int  eppm_pm_rng_create(eppm_pm_rng** out, int w, int h, const eppm_params* p);

@@ -69,6 +69,15 @@ int orc_num_threads(void)
 #endif
 }
 
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n < 1 ? 1 : n);
+#else
+    (void)n;
+#endif
+}
+
 /* ------------------------------------------------------------------------------------------
  * __expf restated.  CUDA's __expf(x) is ex2.approx(x * log2(e)) (libdevice __nv_fast_expf; the
  * reference is built without -use_fast_math / -ftz, CMakeLists.txt:12-27, so subnormal results
@@ -1075,4 +1084,80 @@ int orc_compute_flow(const uint8_t* rgb1, const uint8_t* rgb2, int h, int w, con
     free(nnf1); free(nnf2); free(cost1); free(cost2);
     for (int i = 0; i < NL; i++) { free(img1[i]); free(img2[i]); free(cen1[i]); free(cen2[i]); free(flow[i]); }
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Flow colour coding (next: n4).  basic/bao_basic_cuda.cuh:743-845: colour wheel :751-775 (the table of
+ * 3rdparty/middlebury/colorcode.cpp:30-59), _d_bao_compute_flow_color :776-807, the float2 kernel :816-829,
+ * launcher :839-845 (max_rad = sqrt(mx*mx + my*my), the float overload); called by the driver at :311 with (20,20).
+ * CUDA's atan2f is a third-party routine that is not specified bit for bit: orc_color_atan2 is the restatement the
+ * HIP kernel shares (Cephes-style reduction to [0, tan(pi/8)], degree-4 polynomial in t^2, IEEE operations in this
+ * order, no contraction).  Against a CUDA build an 8-bit channel may differ by one level where atan2f rounds differently.
+ * ---------------------------------------------------------------------------------------- */
+static float orc_color_atan2(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    float t = (mx == 0.0f) ? 0.0f : mn / mx;
+    float base = 0.0f;
+    if (t > 0.4142135679721832275390625f) {
+        base = 0.785398185253143310546875f;
+        t = (t - 1.0f) / (t + 1.0f);
+    }
+    const float z = t * t;
+    float p = 8.05374449538e-2f * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    float r = base + (p * z * t + t);
+    if (ay > ax) r = 1.57079637050628662109375f - r;
+    if (signbit(x)) r = 3.1415927410125732421875f - r;
+    return copysignf(r, y);
+}
+
+static void orc_color_wheel(int wheel[60][3], int* ncols)
+{
+    const int RY = 15, YG = 6, GC = 4, CB = 11, BM = 13, MR = 6;
+    int k = 0, i;
+#define SETCOLS(r, g, b) do { wheel[k][0] = (r); wheel[k][1] = (g); wheel[k][2] = (b); k++; } while (0)
+    for (i = 0; i < RY; i++) SETCOLS(255, 255 * i / RY, 0);
+    for (i = 0; i < YG; i++) SETCOLS(255 - 255 * i / YG, 255, 0);
+    for (i = 0; i < GC; i++) SETCOLS(0, 255, 255 * i / GC);
+    for (i = 0; i < CB; i++) SETCOLS(0, 255 - 255 * i / CB, 255);
+    for (i = 0; i < BM; i++) SETCOLS(255 * i / BM, 0, 255);
+    for (i = 0; i < MR; i++) SETCOLS(255, 0, 255 - 255 * i / MR);
+#undef SETCOLS
+    *ncols = k;
+}
+
+/* rgba: h*w {R,G,B,0}; flow: h*w float2 */
+void orc_flow_to_color(orc_uchar4* rgba, const orc_float2* flow, int h, int w, float max_disp_x, float max_disp_y)
+{
+    int wheel[60][3], ncols;
+    orc_color_wheel(wheel, &ncols);
+    const float max_rad = sqrtf(max_disp_x * max_disp_x + max_disp_y * max_disp_y);         /* .cuh:844 */
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const float vx = flow[y * w + x].x, vy = flow[y * w + x].y;
+            orc_uchar4 out = {0, 0, 0, 0};
+            if (fabsf(vx) < 999999 && fabsf(vy) < 999999) {                                 /* .cuh:825 */
+                const float fx = vx / max_rad, fy = vy / max_rad;
+                const float rad = sqrtf(fx * fx + fy * fy);                                  /* __fsqrt_rn, :778 */
+                const float a = orc_color_atan2(-fy, -fx) / 3.14159f;
+                const float fk = (a + 1.0f) / 2.0f * (float)(ncols - 1);
+                const int k0 = (int)fk;
+                const int k1 = (k0 + 1) % ncols;
+                const float f = fk - (float)k0;
+                unsigned char pix[3];
+                for (int b = 0; b < 3; b++) {
+                    const float col0 = (float)wheel[k0][b] / 255.0f;
+                    const float col1 = (float)wheel[k1][b] / 255.0f;
+                    float col = (1 - f) * col0 + f * col1;
+                    if (rad <= 1) col = 1 - rad * (1 - col);
+                    else col = (float)((double)col * .75);                                   /* col *= .75 in double, :795 */
+                    pix[b] = (unsigned char)(int)(255.0 * (double)col);                      /* :797 */
+                }
+                out.x = pix[0]; out.y = pix[1]; out.z = pix[2];                              /* pix.x = pixval[2] = wheel channel 0 (R), :799-803 */
+            }
+            rgba[y * w + x] = out;
+        }
 }

@@ -131,7 +131,10 @@ void  orc_free_dump(orc_dump* d);
 int   orc_compute_flow(const uint8_t* rgb1, const uint8_t* rgb2, int h, int w, const orc_params* p,
                        float* u, float* v, orc_dump* dump /* may be NULL */);
 
+/* colour coding of a flow field (basic/bao_basic_cuda.cuh:776-845; driver :311 passes 20,20) */
+void  orc_flow_to_color(orc_uchar4* rgba, const orc_float2* flow, int h, int w, float max_disp_x, float max_disp_y);
 int   orc_num_threads(void);
+void  orc_set_num_threads(int n);    /* OpenMP threads of the following calls (bench.py's single-thread CPU baseline) */
 
 #ifdef __cplusplus
 }

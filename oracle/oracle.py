@@ -13,6 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libeppm_oracle.so")
 _REFIO_PATH = os.path.join(_HERE, "_ref", "libeppm_refio.so")
+_RUNREF_PATH = os.path.join(_HERE, "_ref", "runeppm_ref")
 
 uchar4 = np.dtype([("x", "u1"), ("y", "u1"), ("z", "u1"), ("w", "u1")])
 short2 = np.dtype([("x", "i2"), ("y", "i2")])
@@ -44,6 +45,11 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "_build/libeppm_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference") and (force or not os.path.exists(_REFIO_PATH)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    # the reference's main.cpp, unmodified, on the drop-in headers + libeppm_hip.so (needs the HIP library built first)
+    hip_lib = os.path.join(_HERE, "..", "eppm_amd", "lib", "libeppm_hip.so")
+    if os.path.isdir("/root/reference") and os.path.exists(hip_lib) and \
+            (force or not os.path.exists(_RUNREF_PATH) or os.path.getmtime(_RUNREF_PATH) < os.path.getmtime(hip_lib)):
+        subprocess.check_call(["make", "-C", _HERE, "runeppm_ref"], stdout=subprocess.DEVNULL)
 
 
 _lib = None
@@ -68,6 +74,11 @@ def refio():
     if not os.path.exists(_REFIO_PATH):
         return None
     return C.CDLL(_REFIO_PATH)
+
+
+def runeppm_ref():
+    """Path of the reference's own main.cpp built unmodified on the drop-in boundary (oracle/_ref), or None."""
+    return _RUNREF_PATH if os.path.exists(_RUNREF_PATH) else None
 
 
 def _p(a):
@@ -348,3 +359,15 @@ def compute_flow(rgb1, rgb2, params=None, dump=False):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
+def flow_to_color(flow, max_disp_x=20.0, max_disp_y=20.0):
+    """flow: (h,w) float2 -> (h,w) uchar4 {R,G,B,0} (basic/bao_basic_cuda.cuh:776-845)."""
+    h, w = flow.shape
+    out = np.zeros((h, w), uchar4)
+    lib().orc_flow_to_color(_p(out), _p(np.ascontiguousarray(flow)), h, w, C.c_float(max_disp_x), C.c_float(max_disp_y))
+    return out

@@ -4,6 +4,8 @@
 // against the reference implementation itself (kind "reference", not a restatement).
 #include "bao_basic.h"
 #include "bao_flow_tools.h"
+typedef unsigned char uchar;                       // imageLib/Image.h:… defines it for colorcode.h; only the prototype is needed here
+#include "../3rdparty/middlebury/colorcode.h"
 
 extern "C" {
 
@@ -55,6 +57,10 @@ void refio_flow_error(const float* u, const float* v, const float* gu, const flo
     *epe = e; *aae = g;
     bao_free(a); bao_free(b); bao_free(c); bao_free(d);
 }
+
+// 3rdparty/middlebury/colorcode.cpp:61-85 -- the CPU routine the reference's device colour coding (basic/bao_basic_cuda.cuh:776-807)
+// is a port of; pix is B,G,R.  fx, fy already divided by the maximum radius.
+void refio_compute_color(float fx, float fy, unsigned char* pix) { computeColor(fx, fy, pix); }
 
 // bao_basic.h:196-211
 int refio_pyr_init_dim(int* arrH, int* arrW, int h, int w, int maxDepth, float ratio)

@@ -109,3 +109,28 @@ def test_epe_aae_equal_reference():
     R.refio_flow_error(*[a.ctypes.data_as(C.c_void_p) for a in (u, v, gu, gv)], 24, 40, C.byref(epe), C.byref(aae))
     e2, a2 = eppm_amd.io.flow_error(u, v, gu, gv)
     assert e2 == epe.value and a2 == aae.value
+
+
+def test_reference_main_cpp_builds_unmodified_on_the_drop_in():
+    """oracle/_ref/runeppm_ref = the reference's own main.cpp (+ its host-only I/O sources), compiled unmodified against
+    include/ and linked with libeppm_hip.so (oracle/Makefile, target runeppm_ref).  Here: it was built and it resolves the
+    library; the GPU suite runs it and compares its flow.flo with runeppm's."""
+    if not os.path.isdir("/root/reference") and O.runeppm_ref() is None:
+        pytest.skip("reference sources absent and no prebuilt oracle/_ref/runeppm_ref")
+    O.build()
+    exe = O.runeppm_ref()
+    assert exe is not None
+    out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libeppm_hip.so" in out and "not found" not in out.split("libeppm_hip.so")[1].splitlines()[0], out
+    syms = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
+    for s in ("bao_flow_patchmatch_multiscale_cuda", "bao_timer_gpu_cpu"):
+        assert s in syms, s                            # the class and the timer come from the drop-in library
+
+
+def test_timers_header_is_plain_cxx(tmp_path):
+    """include/bao_basic_cuda.h needs no GPU runtime header (the reference's pulls in cuda_runtime.h)."""
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "bao_basic_cuda.h"\nint main(){ if (0) { bao_timer_gpu_cpu t; t.start(); t.time_display("x"); bao_timer_gpu g; g.start(); g.stop(); } return 0; }\n')
+    libdir = os.path.dirname(eppm_amd.lib_path())
+    subprocess.check_call(["g++", "-std=c++11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "t"),
+                           "-L", libdir, "-leppm_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])

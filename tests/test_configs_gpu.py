@@ -1,0 +1,211 @@
+"""GPU parity at the sizes of BASELINE.json's configurations, without running the oracle on the GPU box: the oracle's flows
+were computed once in the build container (tests/golden/make_golden_large.py) and MANIFEST_large.json keeps their sha256,
+per-band hashes, means and a 64x64 crop.  Plus: a fixed-seed fuzz sweep against the live oracle (small sizes), the flow
+colour coding, the reference's own main.cpp on the drop-in boundary, and bench.py's self-spawned ranks."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _manifest():
+    return json.load(open(os.path.join(GOLDEN, "MANIFEST_large.json")))
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _check_flow(name, u, v, rec, crops):
+    """HIP flow against the committed oracle record: crop first (readable failure), then band hashes, then the full hash."""
+    cy, cx = rec["crop_origin_yx"]
+    cu, cv = crops[name + "_u"], crops[name + "_v"]
+    du = np.abs(u[cy:cy + 64, cx:cx + 64] - cu).max()
+    dv = np.abs(v[cy:cy + 64, cx:cx + 64] - cv).max()
+    assert du == 0 and dv == 0, f"{name}: centre crop differs from the oracle's (max |du| {du}, |dv| {dv})"
+    bands = [hashlib.sha256(u[y:y + 16].tobytes() + v[y:y + 16].tobytes()).hexdigest()[:16] for y in range(0, u.shape[0], 16)]
+    badb = [i for i, (a, b) in enumerate(zip(bands, rec["band_sha256"])) if a != b]
+    assert not badb, f"{name}: {len(badb)} of {len(bands)} 16-row bands differ from the oracle's, first at rows {badb[0] * 16}.."
+    assert hashlib.sha256(u.tobytes() + v.tobytes()).hexdigest() == rec["flow_sha256"], name
+
+
+def _pair(rec):
+    from eppm_amd import synth
+    a, b, _, _ = synth.make_pair(rec["h"], rec["w"], seed=rec["seed"], max_flow=rec["max_flow"])
+    assert _sha(a) == rec["img1_sha256"] and _sha(b) == rec["img2_sha256"], \
+        "the synthetic pair generated on this host differs from the one the golden flow was computed on (numpy/libm difference)"
+    return a, b
+
+
+def _run_case(name):
+    import eppm_amd
+    rec = _manifest()[name]
+    crops = np.load(os.path.join(GOLDEN, "large_crops.npz"))
+    a, b = _pair(rec)
+    e = eppm_amd.EPPM(params=eppm_amd.Params(patch_r=rec["patch_r"]))
+    e.init(a, b, rec["h"], rec["w"])
+    u, v = e.compute_flow()
+    e.close()
+    _check_flow(name, u, v, rec, crops)
+
+
+def test_config2_sintel_shape_pair_bit_exact():
+    """BASELINE configs[1]: one 1024x436 pair (seed 1234), full pyramid: HIP flow == oracle flow, bit for bit."""
+    _run_case("sintel_1234")
+
+
+def test_config3_eight_pairs_per_gpu_pipelined():
+    """BASELINE configs[2]: the 8 pairs one GPU of the 64-pair / 8-GPU batch processes (seeds 1234..1241), through three
+    contexts kept in flight (eppm_amd.shard.run_pairs_pipelined, the sharded runner's per-GPU loop): every flow == oracle's."""
+    import eppm_amd
+    from eppm_amd import shard
+    man = _manifest()
+    crops = np.load(os.path.join(GOLDEN, "large_crops.npz"))
+    names = [f"sintel_{s}" for s in range(1234, 1242)]
+    pairs = [_pair(man[n]) for n in names]
+    engs = []
+    for _ in range(3):
+        e = eppm_amd.EPPM()
+        e.init(436, 1024)
+        engs.append(e)
+    mine = shard.pairs_for_rank(8, 0, 1)
+    out = shard.run_pairs_pipelined(engs, pairs, mine)
+    assert sorted(out) == list(range(8))
+    for i, n in enumerate(names):
+        _check_flow(n, out[i][0], out[i][1], man[n], crops)
+
+
+def test_config4_hd_pair_bit_exact():
+    """BASELINE configs[3]: 1920x1080, full pyramid + bilateral refine (the non-split tiled refine with many tiles, XCD tile
+    order, two-pixel-per-lane smoothing)."""
+    _run_case("hd_1234")
+
+
+def test_config5_uhd_patch_radius_17_bit_exact():
+    """BASELINE configs[4]: 3840x2160, PATCH_R 17, 10 PatchMatch iterations (64-lane sweeps, R=17 search and refine, 32-bit texel offsets)."""
+    _run_case("uhd_r17_1234")
+
+
+# ---------------------------------------------------------------------------------------------------
+# fixed-seed fuzz sweep: random sizes, parameters and image statistics; HIP == live oracle (small sizes: seconds)
+# ---------------------------------------------------------------------------------------------------
+def _fuzz_case(seed, t):
+    from eppm_amd import synth
+    rng = np.random.default_rng([seed, t])
+    h, w = int(rng.integers(16, 200)), int(rng.integers(16, 260))
+    kind = t % 4
+    if kind == 0:
+        a, b, _, _ = synth.make_pair(h, w, seed=int(rng.integers(1 << 30)), max_flow=float(rng.uniform(1, 30)))
+    elif kind == 1:   # pure noise, unrelated images
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        b = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    elif kind == 2:   # flat regions + saturated blocks
+        a = np.zeros((h, w, 3), np.uint8)
+        a[h // 3:, w // 4:] = 255
+        a[: h // 2, : w // 2, 1] = 128
+        b = np.roll(a, (int(rng.integers(-9, 9)), int(rng.integers(-9, 9))), axis=(0, 1))
+    else:             # low contrast
+        base = rng.integers(100, 110, (h, w, 3)).astype(np.uint8)
+        a, b = base, np.roll(base, 3, axis=1)
+    params = dict(patch_r=int(rng.choice([9, 9, 9, 17, 5, 4])), num_iter=int(rng.integers(1, 5)), num_guess=int(rng.integers(1, 9)),
+                  seg_len=int(rng.integers(2, 14)), wmf_iters=int(rng.integers(0, 6)), search_range=int(rng.integers(1, 40)),
+                  seed=int(rng.integers(1, 1 << 40)), propagation=int(rng.integers(0, 3)), levels=int(rng.integers(1, 5)))
+    return a, b, params
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_fuzz_parity_fixed_seeds(seed):
+    import eppm_amd
+    from oracle import oracle as O
+    for t in range(8):
+        a, b, params = _fuzz_case(seed, t)
+        h, w, _ = a.shape
+        e = eppm_amd.EPPM(params=eppm_amd.Params(**params))
+        e.init(a, b, h, w)
+        u, v = e.compute_flow()
+        e.close()
+        ou, ov = O.compute_flow(a, b, O.default_params(**params))
+        same = np.array_equal(u.view(np.uint32), ou.view(np.uint32)) and np.array_equal(v.view(np.uint32), ov.view(np.uint32))
+        assert same, f"fuzz seed {seed} case {t}: {w}x{h} {params}"
+
+
+# ---------------------------------------------------------------------------------------------------
+# n4: flow colour coding on the device
+# ---------------------------------------------------------------------------------------------------
+def test_flow_color_kernel_bytes(crop, crop_stages):
+    """k_flow_to_color == orc_flow_to_color byte for byte: random vectors (inside and beyond the radius), the validity
+    threshold, signed zeros and axis-aligned vectors (the atan2 quadrant edges), and the flow of the bundled crop."""
+    from eppm_amd import stages as S
+    from oracle import oracle as O
+    rng = np.random.default_rng(9)
+    h, w = 96, 160
+    f = np.zeros((h, w), O.float2)
+    f["x"] = (rng.standard_normal((h, w)) * 25).astype(np.float32)
+    f["y"] = (rng.standard_normal((h, w)) * 25).astype(np.float32)
+    edge = np.array([0.0, -0.0, 1e10, -1e10, 999999.0, -999999.0, 999998.94, 28.284271, -28.284271, 20.0, -20.0, 1e-30, -1e-30, 5.0], np.float32)
+    k = 0
+    for ex in edge:
+        for ey in edge:
+            f["x"].flat[k], f["y"].flat[k] = ex, ey
+            k += 1
+    for md in ((20.0, 20.0), (100.0, 100.0), (3.0, 50.0)):
+        got, want = S.flow_to_color(f, *md), O.flow_to_color(f, *md)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), int((got.view(np.uint32) != want.view(np.uint32)).sum())
+    # the class path: eppm_compute_color on the context's own flow (driver .cpp:308-314)
+    import eppm_amd
+    e = eppm_amd.EPPM()
+    e.init(crop[0], crop[1], 120, 160)
+    u, v = e.compute_flow()
+    rgb = e.compute_flow_color()
+    ff = np.zeros((120, 160), O.float2)
+    ff["x"], ff["y"] = u, v
+    want = O.flow_to_color(ff, 20, 20)
+    assert np.array_equal(rgb, np.stack([want["x"], want["y"], want["z"]], -1))
+    assert len(np.unique(rgb.reshape(-1, 3), axis=0)) > 8          # a real colour image, not a constant
+
+
+# ---------------------------------------------------------------------------------------------------
+# boundary: the reference's own main.cpp, unmodified, on include/ + libeppm_hip.so
+# ---------------------------------------------------------------------------------------------------
+def test_reference_main_cpp_unmodified_writes_the_same_flo(tmp_path):
+    """oracle/_ref/runeppm_ref (reference main.cpp compiled unmodified, oracle/Makefile) run where frame10/11.ppm lie:
+    its flow.flo equals, byte for byte, the one tools/runeppm writes through the same drop-in class."""
+    import shutil
+    import eppm_amd
+    from oracle import oracle as O
+    exe = O.runeppm_ref()
+    assert exe is not None, "oracle/_ref/runeppm_ref was not built (it travels with the snapshot; build() makes it when /root/reference is present)"
+    for n in ("frame10.ppm", "frame11.ppm"):
+        shutil.copy(os.path.join(GOLDEN, n), tmp_path / n)
+    txt = subprocess.check_output([exe], cwd=tmp_path, text=True, timeout=300)
+    assert "Running time (GPU)" in txt and "Saving flo file" in txt, txt          # bao_timer_gpu_cpu::time_display, main.cpp:66-68
+    ours = os.path.join(os.path.dirname(eppm_amd.lib_path()), "runeppm")
+    subprocess.check_call([ours, os.path.join(GOLDEN, "frame10.ppm"), os.path.join(GOLDEN, "frame11.ppm"), str(tmp_path / "ours.flo")])
+    assert open(tmp_path / "flow.flo", "rb").read() == open(tmp_path / "ours.flo", "rb").read()
+    man = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+    fu, fv = eppm_amd.io.load_flo(str(tmp_path / "flow.flo"))
+    assert hashlib.sha256(fu.tobytes() + fv.tobytes()).hexdigest() == man["oracle_flow_640x480_sha256"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench.py --gpus N without a launcher (two ranks share the one GPU of the test box; gloo for the barrier)
+# ---------------------------------------------------------------------------------------------------
+def test_bench_two_ranks_share_one_gpu():
+    env = dict(os.environ, EPPM_BENCH_SHARE_GPU="1")
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--dist-backend", "gloo",
+                          "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, out.stdout
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["avg_launch_ms"] > 0

@@ -80,3 +80,43 @@ def test_two_gloo_ranks_shard_pairs(tmp_path):
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e
     assert any(line.startswith("OK") for line in outs[0][0].splitlines())
+
+
+STUB = textwrap.dedent("""
+    import json, os, sys
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    dist.destroy_process_group()
+    if "--fail-rank" in sys.argv and rank == int(sys.argv[sys.argv.index("--fail-rank") + 1]):
+        sys.exit(3)
+    if rank == 0:
+        print("noise before the line")
+        print(json.dumps({"n_gpus": world, "argv": sys.argv[1:]}))
+""")
+
+
+def test_bench_gpus_n_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher: the parent spawns N rank processes with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, relays rank 0's JSON line, fails when a rank fails, and never imports torch itself
+    (it must not touch the GPU: ADVICE r1).  The rank program is replaced by a stub (no GPU here); the real ranks run
+    in the GPU suite (test_bench_two_ranks_share_one_gpu)."""
+    stub = tmp_path / "stub.py"
+    stub.write_text(STUB)
+    drv = textwrap.dedent(f"""
+        import json, sys
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        sys.argv = ["bench.py", "--gpus", "2", "--steps", "3"] + sys.argv[1:]
+        args = bench.parse_args_known()
+        bench.spawn_ranks(args, script={str(stub)!r})
+        assert "torch" not in sys.modules, "the spawning parent imported torch"
+    """)
+    ok = subprocess.run([sys.executable, "-c", drv], capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr
+    line = [ln for ln in ok.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1 and '"n_gpus": 2' in line[0] and "--steps" in line[0], ok.stdout
+    bad = subprocess.run([sys.executable, "-c", drv, "--fail-rank", "1"], capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 1 and "ranks failed" in bad.stderr, (bad.returncode, bad.stderr)

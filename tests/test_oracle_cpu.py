@@ -285,3 +285,80 @@ def test_planefit_offsets():
                         row.append(off)
                     if (a, b) == (C, D):
                         assert max(row) - min(row) <= 1, (R, i, row)
+
+
+# ---------------------------------------------------------------- XORWOW pins
+def test_xorwow_transition_and_2pow67_jump_equal_rocrand_matrices(tmp_path):
+    """The oracle's GF(2) transition and subsequence jump against an independent implementation shipped in the ROCm image."""
+    hdr = "/opt/rocm/include/rocrand/rocrand_xorwow_precomputed.h"
+    if not os.path.exists(hdr):
+        pytest.skip("rocRAND headers not installed")
+    O.lib()
+    so = os.path.join(ROOT, "oracle", "_build", "libeppm_oracle.so")
+    exe = str(tmp_path / "xpin")
+    subprocess.check_call(["g++", "-O2", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "csrc", "xorwow_rocrand_pin.cpp"), so,
+                           f"-Wl,-rpath,{os.path.dirname(so)}", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout
+
+
+def test_xorwow_curand_seeding_kat():
+    """curand_init's seed scrambling, from the constants file (restated from curand_kernel.h; see its _about)."""
+    import json
+    k = json.load(open(os.path.join(GOLDEN, "xorwow_curand_kat.json")))
+    M = 0xFFFFFFFF
+    for seed in (1234, 0, 0x0123456789abcdef):
+        s0 = (seed & M) ^ int(k["seed_xor_lo"], 16)
+        s1 = (seed >> 32) ^ int(k["seed_xor_hi"], 16)
+        t0, t1 = (k["mul_lo"] * s0) & M, (k["mul_hi"] * s1) & M
+        v = k["v_init"]
+        want = [(v[0] + t0) & M, v[1] ^ t0, (v[2] + t1) & M, v[3] ^ t1, (v[4] + t0) & M, (k["d_init"] + t1 + t0) & M]
+        assert [int(x) for x in O.xorwow_state(seed, 0)] == want
+
+
+# ---------------------------------------------------------------- flow colour coding (next: n4)
+def _flow2(u, v):
+    f = np.zeros(np.shape(u), O.float2)
+    f["x"], f["y"] = u, v
+    return f
+
+
+def test_flow_color_kats():
+    """basic/bao_basic_cuda.cuh:776-845: zero flow is white, an unknown / huge vector is black, a vector of the maximum
+    radius pointing right is the first wheel colour (pure red), beyond the radius colours are darkened by .75."""
+    mr = np.sqrt(np.float32(800.0))                    # sqrt(20^2 + 20^2), the driver's call (:311)
+    u = np.array([[0, 1e10, 999999, -999999, mr, 2 * mr, 999998.0]], np.float32)
+    v = np.zeros_like(u)
+    c = O.flow_to_color(_flow2(u, v), 20, 20)
+    rgb = np.stack([c["x"], c["y"], c["z"]], -1)[0]
+    assert (rgb[0] == 255).all()                       # rad 0: col = 1 - 0*(1-col) = 1
+    assert (rgb[1] == 0).all() and (rgb[2] == 0).all() and (rgb[3] == 0).all()     # |f| >= 999999 is not drawn (:825)
+    assert tuple(rgb[4]) == (255, 0, 0)                # rad 1, angle -pi: wheel[0] = (255,0,0)
+    assert tuple(rgb[5]) == (191, 0, 0)                # rad 2 > 1: (int)(255.0 * (1 * .75)) = 191
+    assert rgb[6][0] == 191                            # 999998 < 999999 is drawn
+    assert (c["w"] == 0).all()
+
+
+@needs_ref
+def test_flow_color_close_to_middlebury_cpu_routine():
+    """The device routine is a port of Middlebury's computeColor (colorcode.cpp:61-85), differing in pi (3.14159f vs M_PI):
+    on random vectors the oracle's restatement equals it except for rare one-level differences."""
+    R = O.refio()
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    n = 20000
+    fx = (rng.standard_normal(n) * 0.7).astype(np.float32)
+    fy = (rng.standard_normal(n) * 0.7).astype(np.float32)
+    mr = float(np.sqrt(np.float32(800.0)))
+    c = O.flow_to_color(_flow2((fx * np.float32(mr)).reshape(1, n), (fy * np.float32(mr)).reshape(1, n)), 20, 20)
+    ours = np.stack([c["x"], c["y"], c["z"]], -1)[0].astype(int)
+    ref = np.zeros((n, 3), int)
+    pix = (C.c_ubyte * 3)()
+    nx = ((fx * np.float32(mr)) / np.float32(mr)).astype(np.float32)      # what the kernel divides back to
+    ny = ((fy * np.float32(mr)) / np.float32(mr)).astype(np.float32)
+    for i in range(n):
+        R.refio_compute_color(C.c_float(float(nx[i])), C.c_float(float(ny[i])), pix)
+        ref[i] = (pix[2], pix[1], pix[0])              # Middlebury writes B,G,R
+    d = np.abs(ours - ref)
+    assert d.max() <= 1, d.max()
+    assert (d.max(axis=1) == 0).mean() > 0.995

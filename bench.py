@@ -53,6 +53,9 @@ def parse_args(known_only=False):
     ap.add_argument("--patch-r", type=int, default=9)
     ap.add_argument("--inflight", type=int, default=3,
                     help="pairs in flight per GPU: steps are issued round robin over this many contexts, each on its own HIP stream")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="pairs per launch sequence: > 1 groups consecutive steps into batch contexts (eppm_create_batch) whose every kernel launch "
+                         "covers the whole group; --inflight such contexts are kept in flight")
     ap.add_argument("--pairs-per-gpu", type=int, default=8, help="size of the config-3 leg (distinct pairs per GPU)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,12 +138,14 @@ def worker(args):
     w, h = args.width, args.height
     params = eppm_amd.Params(patch_r=args.patch_r)
     S = max(1, args.inflight)
+    NB = max(1, args.batch)
     engs = []
     for _ in range(S):
         e = eppm_amd.EPPM(device=local_rank, params=params)
         e.init(h, w)
         engs.append(e)
     eng = engs[0]
+    bengs = [eppm_amd.EPPMBatch(h, w, NB, device=local_rank, params=params) for _ in range(S)] if NB > 1 else []
 
     # synthetic pairs of this rank, as RGBA planes resident in HBM before any timed region
     def to_dev(img):
@@ -177,26 +182,40 @@ def worker(args):
         e.set_data_device(a.data_ptr(), b.data_ptr(), pitch)
         e.compute_flow_device(f.data_ptr())
 
+    def run_steps(first, count, npairs):
+        """Issue steps first .. first+count-1 (step i works on input pair i % npairs): one context per step, or -- with
+        --batch B -- groups of B consecutive steps per batch context (the last group may be partial)."""
+        if NB == 1:
+            for i in range(first, first + count):
+                step(i, npairs)
+            return
+        g = 0
+        for i0 in range(first, first + count, NB):
+            idx = [i % npairs for i in range(i0, min(i0 + NB, first + count))]
+            e = bengs[g % S]
+            g += 1
+            e.set_data_device([inputs[j][0].data_ptr() for j in idx], [inputs[j][1].data_ptr() for j in idx], pitch)
+            e.compute_flow_device([inputs[j][2].data_ptr() for j in idx])
+
     def sync_all():
-        for e in engs:
+        for e in engs + bengs:
             e.synchronize()
 
-    for i in range(max(args.warmup, S)):
-        step(i)
+    run_steps(0, max(args.warmup, S * NB), NP)
     sync_all()
 
     # ---- the timed region: exactly --steps steps; events only around the dominant kernel, from a pool ----
-    eng.enable_stage_timing(2)
-    eng.stage_times(clear=True)
+    teng = bengs[0] if NB > 1 else eng
+    teng.enable_stage_timing(2)
+    teng.stage_times(clear=True)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run_steps(0, args.steps, S * NB if NB > 1 else S)
     sync_all()
     barrier()
     dt = all_max(time.perf_counter() - t0)
-    dom = eng.stage_times(clear=True)
-    eng.enable_stage_timing(0)
+    dom = teng.stage_times(clear=True)
+    teng.enable_stage_timing(0)
 
     # sanity: the flow is finite and close to the synthetic ground truth (not a parity check)
     flow = d_flow.cpu().numpy()
@@ -205,18 +224,39 @@ def worker(args):
     extras = {}
     if not args.no_extras:
         # ---- config 3 (BASELINE.json configs[2]): --pairs-per-gpu DISTINCT pairs per GPU, same issue scheme ----
-        for i in range(NP):
-            step(i, NP)
-        sync_all()
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(NP):
-            step(i, NP)
-        sync_all()
-        barrier()
-        dt3 = all_max(time.perf_counter() - t0)
-        extras["config3"] = {"workload": f"{NP} distinct {w}x{h} pairs per GPU x {world} GPU(s), one pass, {S} contexts in flight per GPU",
-                             "pairs": NP * world, "value": world * NP * w * h / dt3 / 1e6, "unit": "Mflow-vectors/s", "ms_per_pair": dt3 / NP * 1e3}
+        # (a) one context per pair, S contexts in flight on S streams; (b) ONE batch context: every launch covers the NP pairs
+        def timed(fn, reps=3):
+            fn()
+            sync_all()
+            ts = []
+            for _ in range(reps):
+                barrier()
+                t0 = time.perf_counter()
+                fn()
+                sync_all()
+                barrier()
+                ts.append(all_max(time.perf_counter() - t0))
+            return float(np.median(ts))
+        dt3 = timed(lambda: [step(i, NP) for i in range(NP)])
+        cb = eppm_amd.EPPMBatch(h, w, NP, device=local_rank, params=params)
+
+        def batch_pass():
+            cb.set_data_device([x[0].data_ptr() for x in inputs[:NP]], [x[1].data_ptr() for x in inputs[:NP]], pitch)
+            cb.compute_flow_device([x[2].data_ptr() for x in inputs[:NP]])
+            cb.synchronize()
+        dt3b = timed(batch_pass)
+        cb.enable_stage_timing(1)
+        cb.stage_times(clear=True)
+        batch_pass()
+        bst = {}
+        for name, ms in cb.stage_times(clear=True):
+            bst[name] = bst.get(name, 0.0) + ms / NP
+        cb.close()
+        extras["config3"] = {"workload": f"{NP} distinct {w}x{h} pairs per GPU x {world} GPU(s), one pass (median of 3)",
+                             "pairs": NP * world, "unit": "Mflow-vectors/s",
+                             "streams": {"value": world * NP * w * h / dt3 / 1e6, "ms_per_pair": dt3 / NP * 1e3, "contexts_in_flight": S},
+                             "batch": {"value": world * NP * w * h / dt3b / 1e6, "ms_per_pair": dt3b / NP * 1e3, "pairs_per_launch": NP,
+                                       "stage_ms_per_pair": bst}}
 
     if rank == 0:
         agg = {}
@@ -226,7 +266,10 @@ def worker(args):
         # dominant kernel = k_c2f_refine_tiled; per launch = mean over its two launches per pair (levels 1 and 0),
         # which is what rocprofv3 --stats averages for that kernel name family
         dom_ms = (float(np.mean(agg["c2f_refine_L0"])) + float(np.mean(agg["c2f_refine_L1"]))) / 2
-        alg_bytes = REFINE_BYTES_PER_PX * (lv[0][0] * lv[0][1] + lv[1][0] * lv[1][1]) / 2
+        alg_bytes1 = REFINE_BYTES_PER_PX * (lv[0][0] * lv[0][1] + lv[1][0] * lv[1][1]) / 2      # one pair
+        # pairs per timed launch: NB, except in a last partial group
+        groups = [min(NB, args.steps - i0) for i0 in range(0, args.steps, NB)][0::S] if NB > 1 else [1]
+        alg_bytes = alg_bytes1 * float(np.mean(groups))
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         pmc = pmc_constants(w, h, args.patch_r)
         out = {
@@ -235,17 +278,18 @@ def worker(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"single {w}x{h} Sintel-shape synthetic pair per step, full 3-level pyramid, patch_r={args.patch_r}, "
                                    f"default defs.h parameters; {world} rank(s), independent pairs",
-                       "pairs_per_step_per_gpu": 1, "pairs_in_flight_per_gpu": S, "width": w, "height": h},
+                       "pairs_per_step_per_gpu": 1, "pairs_in_flight_per_gpu": S * NB, "pairs_per_launch": NB, "contexts_in_flight": S,
+                       "width": w, "height": h},
             "roofline": {"bound": "hbm", "kernel": "k_c2f_refine_tiled (mean of its level-1 and level-0 launches, timed region, all streams busy)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                         "traffic": pmc["traffic_bytes_per_launch"] if (pmc and NB == 1) else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                          "note": "the kernel is VALU-issue bound (3 600 patch samples x ~49 instructions per pixel against 26 bytes): see valu_roofline"},
             "epe_vs_synthetic_gt": epe_gt,
         }
         out.update(extras)
         if world == 1 and not args.no_extras:
-            out.update(single_stream_legs(args, eng, inputs, pitch, pmc, alg_bytes))
+            out.update(single_stream_legs(args, eng, inputs, pitch, pmc, alg_bytes1))
             out["host_boundary"] = host_boundary(args, engs, host_pairs)
             out["cold_ms"] = cold_window(args, local_rank, params, host_pairs[0])
         if world == 1 and not args.no_cpu_baseline:

@@ -19,7 +19,8 @@ _lib = None
 
 # every symbol include/eppm.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "eppm_default_params", "eppm_create", "eppm_destroy", "eppm_set_stream", "eppm_set_images", "eppm_set_images_device",
+    "eppm_default_params", "eppm_create", "eppm_create_batch", "eppm_batch_size", "eppm_batch_set_images", "eppm_batch_set_images_device",
+    "eppm_batch_compute", "eppm_batch_compute_device", "eppm_batch_compute_end", "eppm_batch_get_plane", "eppm_destroy", "eppm_set_stream", "eppm_set_images", "eppm_set_images_device",
     "eppm_compute", "eppm_compute_begin", "eppm_compute_end", "eppm_compute_device", "eppm_synchronize", "eppm_num_levels", "eppm_level_dims", "eppm_get_plane",
     "eppm_stage_times", "eppm_clear_stage_times", "eppm_enable_stage_timing", "eppm_last_error", "eppm_version",
     "eppm_device_count", "eppm_set_device", "eppm_malloc_device", "eppm_malloc_pitched", "eppm_free_device",

@@ -161,3 +161,96 @@ class EPPM:
             self.close()
         except Exception:
             pass
+
+
+class EPPMBatch:
+    """A batch of independent pairs of one size on one GPU (eppm_create_batch): every kernel launch of the path covers all
+    active pairs.  ``set_data(pairs)`` / ``compute_flow()`` mirror the single-pair class; each pair's flow is bit-identical
+    to the single-pair result."""
+
+    def __init__(self, h, w, npairs, device=0, params=None):
+        self._ctx = C.c_void_p()
+        check(lib().eppm_create_batch(C.byref(self._ctx), int(h), int(w), int(device),
+                                      C.byref(params) if params is not None else None, int(npairs)), "eppm_create_batch")
+        self.h, self.w, self.npairs, self.n = int(h), int(w), int(npairs), 0
+
+    @staticmethod
+    def _ptrs(arrs):
+        return (C.c_void_p * len(arrs))(*[a.ctypes.data if hasattr(a, "ctypes") else a for a in arrs])
+
+    def set_data(self, pairs):
+        """pairs: up to npairs (img1, img2) tuples of (h, w, 3) uint8 arrays."""
+        a = [np.ascontiguousarray(p[0], np.uint8) for p in pairs]
+        b = [np.ascontiguousarray(p[1], np.uint8) for p in pairs]
+        for x in a + b:
+            if x.shape != (self.h, self.w, 3):
+                raise EppmError(f"set_data: images must be ({self.h},{self.w},3) uint8")
+        check(lib().eppm_batch_set_images(self._ctx, len(pairs), self._ptrs(a), self._ptrs(b), C.c_size_t(self.w * 3)), "eppm_batch_set_images")
+        self.n = len(pairs)
+
+    def set_data_device(self, d1, d2, pitch):
+        """d1, d2: lists of device addresses of RGBA planes."""
+        check(lib().eppm_batch_set_images_device(self._ctx, len(d1), self._ptrs(list(d1)), self._ptrs(list(d2)), C.c_size_t(pitch)),
+              "eppm_batch_set_images_device")
+        self.n = len(d1)
+
+    def _outs(self):
+        u = [np.empty((self.h, self.w), np.float32) for _ in range(self.n)]
+        v = [np.empty((self.h, self.w), np.float32) for _ in range(self.n)]
+        return u, v
+
+    def compute_flow(self):
+        """[(u, v)] for the active pairs."""
+        u, v = self._outs()
+        check(lib().eppm_batch_compute(self._ctx, self._ptrs(u), self._ptrs(v)), "eppm_batch_compute")
+        return list(zip(u, v))
+
+    def compute_flow_device(self, d_flows=None):
+        check(lib().eppm_batch_compute_device(self._ctx, self._ptrs(list(d_flows)) if d_flows is not None else None), "eppm_batch_compute_device")
+
+    def compute_flow_begin(self):
+        check(lib().eppm_compute_begin(self._ctx), "eppm_compute_begin")
+
+    def compute_flow_end(self):
+        u, v = self._outs()
+        check(lib().eppm_batch_compute_end(self._ctx, self._ptrs(u), self._ptrs(v)), "eppm_batch_compute_end")
+        return list(zip(u, v))
+
+    def synchronize(self):
+        check(lib().eppm_synchronize(self._ctx), "eppm_synchronize")
+
+    def plane(self, pair, name, level):
+        dims = []
+        for l in range(lib().eppm_num_levels(self._ctx)):
+            hh, ww = C.c_int(), C.c_int()
+            check(lib().eppm_level_dims(self._ctx, l, C.byref(hh), C.byref(ww)), "eppm_level_dims")
+            dims.append((hh.value, ww.value))
+        hh, ww = dims[level]
+        a = np.empty((hh, ww), _PLANE_DTYPES[name])
+        check(lib().eppm_batch_get_plane(self._ctx, int(pair), name.encode(), level, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes)),
+              "eppm_batch_get_plane")
+        return a
+
+    def enable_stage_timing(self, on=True):
+        check(lib().eppm_enable_stage_timing(self._ctx, int(on)), "eppm_enable_stage_timing")
+
+    def stage_times(self, clear=True):
+        cap = 1 << 16
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        n = lib().eppm_stage_times(self._ctx, names, ms, cap)
+        out = [(names[i].decode(), float(ms[i])) for i in range(n)]
+        if clear:
+            check(lib().eppm_clear_stage_times(self._ctx), "eppm_clear_stage_times")
+        return out
+
+    def close(self):
+        if self._ctx:
+            lib().eppm_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

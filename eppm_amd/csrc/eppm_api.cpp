@@ -112,6 +112,7 @@ struct eppm_pm_rng {
     uint32_t* init_tab = nullptr;
     uint32_t* iter_tab = nullptr;
     uint32_t* work[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [problem][ping-pong]
+    bool own_work = true;              // false: the states live in a context's slab (one set per pair of the batch)
     int cur[2] = {0, 0};
     uint32_t* skip_mat = nullptr;
     uint32_t skip_weyl = 0;
@@ -124,7 +125,7 @@ struct eppm_pm_rng {
     }
 };
 
-static int rng_create(eppm_pm_rng** out, int w, int h, const eppm_params& p)
+static int rng_create(eppm_pm_rng** out, int w, int h, const eppm_params& p, bool alloc_work = true)
 {
     eppm_pm_rng* r = new eppm_pm_rng();
     HIPCHK(hipGetDevice(&r->device));
@@ -154,13 +155,17 @@ static int rng_create(eppm_pm_rng** out, int w, int h, const eppm_params& p)
     r->skip_weyl = 362437u * (uint32_t)skip;
     HIPCHK(hipMalloc(&r->init_tab, words * 4));
     HIPCHK(hipMalloc(&r->iter_tab, words * 4));
-    for (int k = 0; k < 2; k++)
-        for (int q = 0; q < 2; q++) HIPCHK(hipMalloc(&r->work[k][q], words * 4));
+    r->own_work = alloc_work;
+    if (alloc_work)
+        for (int k = 0; k < 2; k++)
+            for (int q = 0; q < 2; q++) HIPCHK(hipMalloc(&r->work[k][q], words * 4));
     HIPCHK(hipMalloc(&r->skip_mat, mat.size() * 4));
     HIPCHK(hipMemcpy(r->init_tab, it.data(), words * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(r->iter_tab, st.data(), words * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(r->work[0][0], st.data(), words * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(r->work[1][0], st.data(), words * 4, hipMemcpyHostToDevice));
+    if (alloc_work) {       // (a context's states are set by k_pm_init_field at the start of every PatchMatch run)
+        HIPCHK(hipMemcpy(r->work[0][0], st.data(), words * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(r->work[1][0], st.data(), words * 4, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemcpy(r->skip_mat, mat.data(), mat.size() * 4, hipMemcpyHostToDevice));
     *out = r;
     return EPPM_OK;
@@ -170,8 +175,9 @@ static void rng_free(eppm_pm_rng* r)
 {
     if (!r) return;
     (void)hipFree(r->init_tab); (void)hipFree(r->iter_tab);
-    for (int k = 0; k < 2; k++)
-        for (int q = 0; q < 2; q++) (void)hipFree(r->work[k][q]);
+    if (r->own_work)
+        for (int k = 0; k < 2; k++)
+            for (int q = 0; q < 2; q++) (void)hipFree(r->work[k][q]);
     (void)hipFree(r->skip_mat);
     delete r;
 }
@@ -182,12 +188,19 @@ static void rng_free(eppm_pm_rng* r)
 
 struct StageEv { const char* name; hipEvent_t a, b; };
 
+// One context = a batch of `npairs` independent pairs of one size (1 for the plain eppm_create).  Every device plane of
+// pair k lives at the same offset inside pair k's SLAB and the slabs are `stride` bytes apart in one allocation, so every
+// launch covers all active pairs: it gets pair 0's pointers and {n_active, stride} (eppm_internal.h: Batch), and
+// blockIdx.z / .y selects the pair.  The pointer members below are pair 0's; ping-pong swaps apply to every pair alike.
 struct eppm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     eppm_params prm;
     int h = 0, w = 0, nl = 0;
+    int npairs = 1, n_active = 1;
+    char* slab = nullptr;
+    size_t stride = 0;
     int H[kMaxLevels], W[kMaxLevels];
     size_t ipitch[kMaxLevels], cpitch[kMaxLevels];   // bytes
     uint32_t *raw1 = nullptr, *raw2 = nullptr;
@@ -203,16 +216,18 @@ struct eppm_ctx {
     float* c2f_cost9[kMaxLevels] = {};  // 9 candidates x 4 passes costs per pixel, only for levels whose refine launch is split
     float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
     eppm_pm_rng* rng = nullptr;
-    uint32_t* d_color = nullptr;        // colour-coded flow (optional output), allocated on first use
-    uint32_t* h_color = nullptr;        // pinned
-    uint8_t* d_rgb = nullptr;           // staging for host RGB input
-    uint8_t* h_rgb = nullptr;           // pinned
-    float* h_flow = nullptr;            // pinned
+    uint32_t* d_color = nullptr;        // colour-coded flow (optional output), in the slab
+    uint32_t* h_color = nullptr;        // pinned, allocated on first use
+    uint8_t* d_rgb = nullptr;           // staging for host RGB input (both frames), in the slab
+    uint8_t* h_rgb = nullptr;           // pinned, npairs x both frames
+    float* h_flow = nullptr;            // pinned, npairs x h*w float2
     bool have_images = false, have_flow = false;
     int timing = 0;                     // 0 off, 1 every stage, 2 only the dominant kernel (the candidate refine)
     std::vector<StageEv> ev;
     std::vector<StageEv> ev_prep;
     std::vector<hipEvent_t> ev_pool;    // events are created once and reused: no hipEventCreate in a steady-state step
+    Batch bt() const { return Batch{n_active, stride}; }
+    template <class T> T* of_pair(T* p, int k) const { return (T*)((char*)p + (size_t)k * stride); }
 };
 
 static PlanesH planes(const eppm_ctx* c, int l, bool swap)
@@ -262,16 +277,8 @@ extern "C" int eppm_destroy(eppm_ctx* c)
     clear_events(c, c->ev);
     clear_events(c, c->ev_prep);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-    (void)hipFree(c->raw1); (void)hipFree(c->raw2);
-    for (int i = 0; i < kMaxLevels; i++) {
-        (void)hipFree(c->img1[i]); (void)hipFree(c->img2[i]); (void)hipFree(c->tmpu[i]);
-        (void)hipFree(c->cen1[i]); (void)hipFree(c->cen2[i]); (void)hipFree(c->pk1[i]); (void)hipFree(c->pk2[i]);
-        (void)hipFree(c->flow[i]); (void)hipFree(c->flow_tmp[i]); (void)hipFree(c->c2f_cost9[i]);
-    }
-    (void)hipFree(c->nnf1); (void)hipFree(c->nnf2); (void)hipFree(c->nnf_tmp); (void)hipFree(c->nnf_tmp2);
-    (void)hipFree(c->cost1); (void)hipFree(c->cost2); (void)hipFree(c->wmf_ws);
+    (void)hipFree(c->slab);
     (void)hipFree(c->lut_pm); (void)hipFree(c->lut_wmf); (void)hipFree(c->lut_blf);
-    (void)hipFree(c->d_rgb); (void)hipFree(c->d_color);
     if (c->h_color) (void)hipHostFree(c->h_color);
     if (c->h_rgb) (void)hipHostFree(c->h_rgb);
     if (c->h_flow) (void)hipHostFree(c->h_flow);
@@ -288,49 +295,68 @@ static int upload_lut(float** dst, const std::vector<float>& v)
     return EPPM_OK;
 }
 
+// Lays the planes of ONE pair out in a slab (256-byte aligned offsets, pitched rows padded to 256 bytes), allocates
+// npairs slabs in one block and points the context's members at pair 0's planes.
 static int ctx_alloc(eppm_ctx* c)
 {
     const int h = c->h, w = c->w;
-    HIPCHK(hipMallocPitch((void**)&c->raw1, &c->raw_pitch, (size_t)w * 4, h));
-    HIPCHK(hipMallocPitch((void**)&c->raw2, &c->raw_pitch, (size_t)w * 4, h));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    auto pitch_of = [](size_t row_bytes) { return (row_bytes + 255) & ~(size_t)255; };
+    struct Fix { void** dst; size_t off; };
+    std::vector<Fix> fix;
+    auto plane = [&](void** dst, size_t bytes) { fix.push_back(Fix{dst, take(bytes)}); };
+    c->raw_pitch = pitch_of((size_t)w * 4);
+    plane((void**)&c->raw1, c->raw_pitch * h);
+    plane((void**)&c->raw2, c->raw_pitch * h);
     for (int i = 0; i < c->nl; i++) {
-        HIPCHK(hipMallocPitch((void**)&c->img1[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
-        HIPCHK(hipMallocPitch((void**)&c->img2[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
-        HIPCHK(hipMallocPitch((void**)&c->tmpu[i], &c->ipitch[i], (size_t)c->W[i] * 4, c->H[i]));
-        HIPCHK(hipMalloc(&c->pk1[i], (size_t)c->W[i] * c->H[i] * 16));
-        HIPCHK(hipMalloc(&c->pk2[i], (size_t)c->W[i] * c->H[i] * 16));
-        HIPCHK(hipMallocPitch((void**)&c->cen1[i], &c->cpitch[i], (size_t)c->W[i], c->H[i]));
-        HIPCHK(hipMallocPitch((void**)&c->cen2[i], &c->cpitch[i], (size_t)c->W[i], c->H[i]));
+        c->ipitch[i] = pitch_of((size_t)c->W[i] * 4);
+        c->cpitch[i] = pitch_of((size_t)c->W[i]);
         const size_t n = (size_t)c->W[i] * c->H[i];
-        HIPCHK(hipMalloc((void**)&c->flow[i], n * 8));
-        HIPCHK(hipMalloc((void**)&c->flow_tmp[i], n * 8));
-        if (i < c->nl - 1 && c2f_refine_wants_split(c->W[i], c->H[i], c->prm.patch_r)) HIPCHK(hipMalloc((void**)&c->c2f_cost9[i], n * 36 * 4));
+        plane((void**)&c->img1[i], c->ipitch[i] * c->H[i]);
+        plane((void**)&c->img2[i], c->ipitch[i] * c->H[i]);
+        plane((void**)&c->tmpu[i], c->ipitch[i] * c->H[i]);
+        plane(&c->pk1[i], n * 16);
+        plane(&c->pk2[i], n * 16);
+        plane((void**)&c->cen1[i], c->cpitch[i] * c->H[i]);
+        plane((void**)&c->cen2[i], c->cpitch[i] * c->H[i]);
+        plane((void**)&c->flow[i], n * 8);
+        plane((void**)&c->flow_tmp[i], n * 8);
+        if (i < c->nl - 1 && c2f_refine_wants_split(c->W[i], c->H[i], c->prm.patch_r, 1)) plane((void**)&c->c2f_cost9[i], n * 36 * 4);
     }
-    if (c->raw_pitch != c->ipitch[0]) return set_err(EPPM_ERR_HIP, "unexpected pitch mismatch");
     const int L = c->nl - 1;
-    const size_t n = (size_t)c->W[L] * c->H[L];
-    HIPCHK(hipMalloc((void**)&c->nnf1, n * 4));
-    HIPCHK(hipMalloc((void**)&c->nnf2, n * 4));
-    HIPCHK(hipMalloc((void**)&c->nnf_tmp, n * 4));
-    HIPCHK(hipMalloc((void**)&c->nnf_tmp2, n * 4));
-    HIPCHK(hipMalloc((void**)&c->cost1, n * 4));
-    HIPCHK(hipMalloc((void**)&c->cost2, n * 4));
-    HIPCHK(hipMalloc((void**)&c->wmf_ws, wmf_workspace_words(c->W[L], c->H[L], c->prm.wmf_iters) * 4));
+    const size_t n2 = (size_t)c->W[L] * c->H[L];
+    plane((void**)&c->nnf1, n2 * 4);
+    plane((void**)&c->nnf2, n2 * 4);
+    plane((void**)&c->nnf_tmp, n2 * 4);
+    plane((void**)&c->nnf_tmp2, n2 * 4);
+    plane((void**)&c->cost1, n2 * 4);
+    plane((void**)&c->cost2, n2 * 4);
+    plane((void**)&c->wmf_ws, wmf_workspace_words(c->W[L], c->H[L], c->prm.wmf_iters) * 4);
+    plane((void**)&c->d_rgb, (size_t)h * w * 3 * 2);
+    plane((void**)&c->d_color, (size_t)h * w * 4);
+    CHK(rng_create(&c->rng, c->W[L], c->H[L], c->prm, false));
+    const size_t rng_bytes = (size_t)c->rng->gx * c->rng->gy * 64 * 6 * 4;
+    for (int k = 0; k < 2; k++)
+        for (int q = 0; q < 2; q++) plane((void**)&c->rng->work[k][q], rng_bytes);
+    c->stride = (off + 4095) & ~(size_t)4095;
+    // every texel plane is addressed with 32-bit byte offsets from ITS OWN base; the slab stride itself is 64-bit
+    HIPCHK(hipMalloc((void**)&c->slab, c->stride * c->npairs));
+    for (const Fix& f : fix) *f.dst = c->slab + f.off;
     std::vector<float> v;
     host_pm_lut(c->prm.patch_r, v);  CHK(upload_lut(&c->lut_pm, v));
     host_wmf_lut(v);                 CHK(upload_lut(&c->lut_wmf, v));
     host_blf_lut(v);                 CHK(upload_lut(&c->lut_blf, v));
-    CHK(rng_create(&c->rng, c->W[L], c->H[L], c->prm));
-    HIPCHK(hipMalloc((void**)&c->d_rgb, (size_t)h * w * 3 * 2));
-    HIPCHK(hipHostMalloc((void**)&c->h_rgb, (size_t)h * w * 3 * 2, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&c->h_flow, (size_t)h * w * 8, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->h_rgb, (size_t)h * w * 3 * 2 * c->npairs, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->h_flow, (size_t)h * w * 8 * c->npairs, hipHostMallocDefault));
     return EPPM_OK;
 }
 
-extern "C" int eppm_create(eppm_ctx** out, int h, int w, int device, const eppm_params* params)
+extern "C" int eppm_create_batch(eppm_ctx** out, int h, int w, int device, const eppm_params* params, int npairs)
 {
     if (!out) return set_err(EPPM_ERR_ARG, "eppm_create: NULL out");
     *out = nullptr;
+    if (npairs < 1 || npairs > 4096) return set_err(EPPM_ERR_ARG, "eppm_create_batch: npairs %d out of range [1,4096]", npairs);
     if (h < 4 || w < 4 || h > 32767 || w > 32767) return set_err(EPPM_ERR_ARG, "eppm_create: size %dx%d out of range (NNF coordinates are int16)", w, h);
     if ((unsigned long long)h * (unsigned long long)w * 16ULL >= (1ULL << 32))
         return set_err(EPPM_ERR_ARG, "eppm_create: size %dx%d out of range (texel planes are addressed with 32-bit byte offsets)", w, h);
@@ -340,7 +366,7 @@ extern "C" int eppm_create(eppm_ctx** out, int h, int w, int device, const eppm_
     CHK(check_params(p));
     HIPCHK(hipSetDevice(device));
     eppm_ctx* c = new eppm_ctx();
-    c->device = device; c->prm = p; c->h = h; c->w = w;
+    c->device = device; c->prm = p; c->h = h; c->w = w; c->npairs = npairs; c->n_active = 1;
     c->nl = pyr_init_dim(c->H, c->W, h, w, p.levels, 0.5f);
     const int L = c->nl - 1;
     if (c->H[L] < 1 || c->W[L] < 1 || (c->W[L] + p.seg_len - 1) / p.seg_len > 1024 || (c->H[L] + p.seg_len - 1) / p.seg_len > 1024) {
@@ -355,6 +381,13 @@ extern "C" int eppm_create(eppm_ctx** out, int h, int w, int device, const eppm_
     *out = c;
     return EPPM_OK;
 }
+
+extern "C" int eppm_create(eppm_ctx** out, int h, int w, int device, const eppm_params* params)
+{
+    return eppm_create_batch(out, h, w, device, params, 1);
+}
+
+extern "C" int eppm_batch_size(const eppm_ctx* c) { return c ? c->npairs : 0; }
 
 extern "C" int eppm_set_stream(eppm_ctx* c, void* s)
 {
@@ -380,14 +413,16 @@ extern "C" int eppm_enable_stage_timing(eppm_ctx* c, int on)
     return EPPM_OK;
 }
 
-// ---- prepare: refine :1060-1071 + .cuh:642-664.  The two frames share every launch. ----
-static int prepare(eppm_ctx* c, const uint32_t* raw1, const uint32_t* raw2)
+// ---- prepare: refine :1060-1071 + .cuh:642-664.  The two frames of every active pair share every launch; the raw
+// RGBA planes of the active pairs are in the slabs already. ----
+static int prepare(eppm_ctx* c)
 {
     stage_begin(c, c->ev_prep, "prepare");
     hipStream_t s = c->stream;
+    const Batch bt = c->bt();
     uint32_t **p1 = c->img1, **p2 = c->img2, **tmp = c->tmpu;
     const int p0 = (int)(c->ipitch[0] / 4);
-    launch_gauss_rgba2(p1[0], raw1, p2[0], raw2, p0, c->H[0], c->W[0], .5f, 2, s);    // refine :1063-1064
+    launch_gauss_rgba2(p1[0], c->raw1, p2[0], c->raw2, p0, c->H[0], c->W[0], .5f, 2, s, bt);    // refine :1063-1064
     const float ratio = 0.5f;                                                             // PYR_RATIO
     const float baseSigma = (1 / ratio - 1);
     const int n = (int)(log(0.25) / (double)logf(ratio));   // C++ float overload in the reference: n = 1
@@ -401,12 +436,12 @@ static int prepare(eppm_ctx* c, const uint32_t* raw1, const uint32_t* raw2)
         const int pj = (int)(c->ipitch[j] / 4), pi = (int)(c->ipitch[i] / 4);
         if (gauss_decimate2_ok(c->H[i], c->W[i], c->H[j], c->W[j], r, radius)) {
             // exact 2:1 step: blur only the pixels the decimation keeps (a quarter of the level)
-            launch_gauss_decimate2(p1[i], p1[j], p2[i], p2[j], 2, pi, c->H[i], c->W[i], pj, c->H[j], c->W[j], sigma, radius, s);
+            launch_gauss_decimate2(p1[i], p1[j], p2[i], p2[j], 2, pi, c->H[i], c->W[i], pj, c->H[j], c->W[j], sigma, radius, s, bt);
         } else {
             for (int k = 0; k < 2; k++) {
                 uint32_t** pyr = k ? p2 : p1;
-                launch_gauss_rgba(tmp[j], pyr[j], pj, c->H[j], c->W[j], sigma, radius, s);
-                launch_resize_rgba(pyr[i], pi, c->H[i], c->W[i], tmp[j], pj, c->H[j], c->W[j], r, s);
+                launch_gauss_rgba(tmp[j], pyr[j], pj, c->H[j], c->W[j], sigma, radius, s, bt);
+                launch_resize_rgba(pyr[i], pi, c->H[i], c->W[i], tmp[j], pj, c->H[j], c->W[j], r, s, bt);
             }
         }
     }
@@ -420,7 +455,7 @@ static int prepare(eppm_ctx* c, const uint32_t* raw1, const uint32_t* raw2)
             J.img = k ? c->img2[i] : c->img1[i];    J.ipitch = (int)(c->ipitch[i] / 4);
             J.w = c->W[i]; J.h = c->H[i]; J.first_block = 0;
         }
-    launch_census_batch(cb, s);
+    launch_census_batch(cb, s, bt);
     stage_end(c, c->ev_prep);
     HIPCHK(hipGetLastError());
     c->have_images = true;
@@ -428,34 +463,69 @@ static int prepare(eppm_ctx* c, const uint32_t* raw1, const uint32_t* raw2)
     return EPPM_OK;
 }
 
-extern "C" int eppm_set_images(eppm_ctx* c, const uint8_t* rgb1, const uint8_t* rgb2, size_t row_stride)
+// host RGB of pairs 0..n-1 -> pinned staging -> ONE H2D -> RGBA planes (bao_rgb2rgba, alpha = 0) -> prepare
+static int set_images_host(eppm_ctx* c, int n, const uint8_t* const* rgb1, const uint8_t* const* rgb2, size_t row_stride)
 {
-    if (!c || !rgb1 || !rgb2) return set_err(EPPM_ERR_ARG, "eppm_set_images: NULL argument");
     if (row_stride < (size_t)c->w * 3) return set_err(EPPM_ERR_ARG, "eppm_set_images: row_stride %zu < 3*w", row_stride);
     HIPCHK(hipSetDevice(c->device));
     const size_t row = (size_t)c->w * 3, img = row * c->h;
     HIPCHK(hipStreamSynchronize(c->stream));       // the pinned staging buffer may still be in flight
-    for (int y = 0; y < c->h; y++) {
-        memcpy(c->h_rgb + (size_t)y * row, rgb1 + (size_t)y * row_stride, row);
-        memcpy(c->h_rgb + img + (size_t)y * row, rgb2 + (size_t)y * row_stride, row);
+    for (int k = 0; k < n; k++) {
+        if (!rgb1[k] || !rgb2[k]) return set_err(EPPM_ERR_ARG, "eppm_set_images: NULL image");
+        uint8_t* dst = c->h_rgb + (size_t)k * img * 2;
+        for (int y = 0; y < c->h; y++) {
+            memcpy(dst + (size_t)y * row, rgb1[k] + (size_t)y * row_stride, row);
+            memcpy(dst + img + (size_t)y * row, rgb2[k] + (size_t)y * row_stride, row);
+        }
     }
-    HIPCHK(hipMemcpyAsync(c->d_rgb, c->h_rgb, img * 2, hipMemcpyHostToDevice, c->stream));
+    c->n_active = n;
+    for (int k = 0; k < n; k++)       // one copy per pair (the slab stride may exceed what a 2-D copy accepts as a pitch)
+        HIPCHK(hipMemcpyAsync(c->of_pair(c->d_rgb, k), c->h_rgb + (size_t)k * img * 2, img * 2, hipMemcpyHostToDevice, c->stream));
     const int p0 = (int)(c->raw_pitch / 4);
-    launch_rgb_to_rgba(c->raw1, p0, c->d_rgb, c->h, c->w, c->stream);          // bao_rgb2rgba, alpha = 0
-    launch_rgb_to_rgba(c->raw2, p0, c->d_rgb + img, c->h, c->w, c->stream);
-    return prepare(c, c->raw1, c->raw2);
+    launch_rgb_to_rgba(c->raw1, p0, c->d_rgb, c->h, c->w, c->stream, c->bt());
+    launch_rgb_to_rgba(c->raw2, p0, c->d_rgb + img, c->h, c->w, c->stream, c->bt());
+    return prepare(c);
+}
+
+extern "C" int eppm_set_images(eppm_ctx* c, const uint8_t* rgb1, const uint8_t* rgb2, size_t row_stride)
+{
+    if (!c || !rgb1 || !rgb2) return set_err(EPPM_ERR_ARG, "eppm_set_images: NULL argument");
+    return set_images_host(c, 1, &rgb1, &rgb2, row_stride);
+}
+
+extern "C" int eppm_batch_set_images(eppm_ctx* c, int n, const uint8_t* const* rgb1, const uint8_t* const* rgb2, size_t row_stride)
+{
+    if (!c || !rgb1 || !rgb2) return set_err(EPPM_ERR_ARG, "eppm_batch_set_images: NULL argument");
+    if (n < 1 || n > c->npairs) return set_err(EPPM_ERR_ARG, "eppm_batch_set_images: %d pairs, context holds %d", n, c->npairs);
+    return set_images_host(c, n, rgb1, rgb2, row_stride);
+}
+
+// device-resident RGBA of pairs 0..n-1: copied into the slabs' raw planes in stream order (the caller's planes are not
+// read after the copies complete, and never in place), then prepare
+static int set_images_device(eppm_ctx* c, int n, const void* const* d1, const void* const* d2, size_t pitch)
+{
+    if (pitch < (size_t)c->w * 4 || (pitch & 3)) return set_err(EPPM_ERR_ARG, "eppm_set_images_device: bad pitch %zu", pitch);
+    HIPCHK(hipSetDevice(c->device));
+    for (int k = 0; k < n; k++) {
+        if (!d1[k] || !d2[k]) return set_err(EPPM_ERR_ARG, "eppm_set_images_device: NULL image");
+        HIPCHK(hipMemcpy2DAsync(c->of_pair(c->raw1, k), c->raw_pitch, d1[k], pitch, (size_t)c->w * 4, c->h, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpy2DAsync(c->of_pair(c->raw2, k), c->raw_pitch, d2[k], pitch, (size_t)c->w * 4, c->h, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->n_active = n;
+    return prepare(c);
 }
 
 extern "C" int eppm_set_images_device(eppm_ctx* c, const void* d1, const void* d2, size_t pitch)
 {
     if (!c || !d1 || !d2) return set_err(EPPM_ERR_ARG, "eppm_set_images_device: NULL argument");
-    if (pitch < (size_t)c->w * 4 || (pitch & 3)) return set_err(EPPM_ERR_ARG, "eppm_set_images_device: bad pitch %zu", pitch);
-    HIPCHK(hipSetDevice(c->device));
-    // the prefilter reads the caller's planes directly when the pitch matches, else through a 2-D copy
-    if (pitch == c->raw_pitch) return prepare(c, (const uint32_t*)d1, (const uint32_t*)d2);
-    HIPCHK(hipMemcpy2DAsync(c->raw1, c->raw_pitch, d1, pitch, (size_t)c->w * 4, c->h, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpy2DAsync(c->raw2, c->raw_pitch, d2, pitch, (size_t)c->w * 4, c->h, hipMemcpyDeviceToDevice, c->stream));
-    return prepare(c, c->raw1, c->raw2);
+    return set_images_device(c, 1, &d1, &d2, pitch);
+}
+
+extern "C" int eppm_batch_set_images_device(eppm_ctx* c, int n, const void* const* d_rgba1, const void* const* d_rgba2, size_t pitch)
+{
+    if (!c || !d_rgba1 || !d_rgba2) return set_err(EPPM_ERR_ARG, "eppm_batch_set_images_device: NULL argument");
+    if (n < 1 || n > c->npairs) return set_err(EPPM_ERR_ARG, "eppm_batch_set_images_device: %d pairs, context holds %d", n, c->npairs);
+    return set_images_device(c, n, d_rgba1, d_rgba2, pitch);
 }
 
 // ---- baoCudaPatchMatch (kernel.cu:1760-1826) for one problem or for the forward+backward pair at once ----
@@ -512,19 +582,20 @@ static void run_patchmatch(PmBatch& b, eppm_pm_rng* rng, const float* lut, const
     }
 }
 
-extern "C" int eppm_compute_device(eppm_ctx* c, void* d_flow)
+// compute_flow (driver :217-306) for every active pair; the flows stay in the slabs (flow[0])
+static int compute_all(eppm_ctx* c)
 {
-    if (!c) return set_err(EPPM_ERR_ARG, "NULL ctx");
     if (!c->have_images) return set_err(EPPM_ERR_STATE, "eppm_compute: no images set");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    const Batch bt = c->bt();
     const int L = c->nl - 1;                                            // pm_layer, driver :219
     const int lw = c->W[L], lh = c->H[L];
 
     stage_begin(c, c->ev, "patchmatch");
     {
         PmBatch b;
-        b.n = 2; b.cpitch = lw; b.npitch = lw;
+        b.n = 2; b.cpitch = lw; b.npitch = lw; b.npairs = bt.n; b.stride = bt.stride;
         b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0);     // driver :223
         b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1);     // driver :224
         run_patchmatch(b, c->rng, c->lut_pm, c->prm, s);
@@ -532,16 +603,16 @@ extern "C" int eppm_compute_device(eppm_ctx* c, void* d_flow)
     stage_end(c, c->ev);
 
     stage_begin(c, c->ev, "l2_post");
-    launch_lr_check(c->nnf1, c->cost1, c->nnf2, lw, lh, lw, lw, s);                                          // driver :233
-    launch_lr_check(c->nnf2, c->cost2, c->nnf1, lw, lh, lw, lw, s);
-    launch_outlier(c->nnf_tmp, c->cost1, c->nnf1, lw, lh, lw, lw, s);                                        // driver :237
+    launch_lr_check(c->nnf1, c->cost1, c->nnf2, lw, lh, lw, lw, s, bt);                                      // driver :233
+    launch_lr_check(c->nnf2, c->cost2, c->nnf1, lw, lh, lw, lw, s, bt);
+    launch_outlier(c->nnf_tmp, c->cost1, c->nnf1, lw, lh, lw, lw, s, bt);                                    // driver :237
     std::swap(c->nnf1, c->nnf_tmp);
     if (launch_wmf(c->nnf1, c->nnf_tmp, c->img1[L], (int)(c->ipitch[L] / 4), lw, lh, lw, c->lut_wmf, c->prm.wmf_iters, 1,      // driver :239
-                   c->wmf_ws, s) != c->nnf1)
+                   c->wmf_ws, s, bt) != c->nnf1)
         std::swap(c->nnf1, c->nnf_tmp);
-    launch_fill_holes(c->nnf_tmp, c->nnf1, c->img1[L], (int)(c->ipitch[L] / 4), lw, lh, lw, s);              // driver :240
+    launch_fill_holes(c->nnf_tmp, c->nnf1, c->img1[L], (int)(c->ipitch[L] / 4), lw, lh, lw, s, bt);          // driver :240
     std::swap(c->nnf1, c->nnf_tmp);
-    launch_nnf2flow(c->flow[L], lw, c->nnf1, lw, lw, lh, s);                                                 // driver :258
+    launch_nnf2flow(c->flow[L], lw, c->nnf1, lw, lw, lh, s, bt);                                             // driver :258
     stage_end(c, c->ev);
 
     static const char* up_names[] = {"upsample_L0", "upsample_L1", "upsample_L2", "upsample_L3", "upsample_L4", "upsample_L5", "upsample_L6"};
@@ -549,23 +620,40 @@ extern "C" int eppm_compute_device(eppm_ctx* c, void* d_flow)
     static const char* bl_names[] = {"flow_blf_L0", "flow_blf_L1", "flow_blf_L2", "flow_blf_L3", "flow_blf_L4", "flow_blf_L5", "flow_blf_L6"};
     for (int l = L - 1; l >= 0; l--) {                                                                       // driver :275-282
         stage_begin(c, c->ev, up_names[l]);
-        launch_resize_flow(c->flow[l], c->H[l], c->W[l], c->flow[l + 1], c->H[l + 1], c->W[l + 1], 2.0f, 2.0f, s);   // refine :1082-1083
+        launch_resize_flow(c->flow[l], c->H[l], c->W[l], c->flow[l + 1], c->H[l + 1], c->W[l + 1], 2.0f, 2.0f, s, bt);   // refine :1082-1083
         stage_end(c, c->ev);
         stage_begin(c, c->ev, rf_names[l], true);
-        launch_c2f_refine(planes(c, l, false), c->flow[l], c->lut_pm, c->prm.patch_r, c->c2f_cost9[l], s);   // refine :1086
+        launch_c2f_refine(planes(c, l, false), c->flow[l], c->lut_pm, c->prm.patch_r, c->c2f_cost9[l], s, bt);   // refine :1086
         stage_end(c, c->ev, true);
         stage_begin(c, c->ev, bl_names[l]);
-        launch_flow_blf(c->flow_tmp[l], c->flow[l], c->img1[l], (int)(c->ipitch[l] / 4), c->W[l], c->H[l], c->W[l], c->lut_blf, s);  // driver :280
+        launch_flow_blf(c->flow_tmp[l], c->flow[l], c->img1[l], (int)(c->ipitch[l] / 4), c->W[l], c->H[l], c->W[l], c->lut_blf, s, bt);  // driver :280
         std::swap(c->flow[l], c->flow_tmp[l]);
         stage_end(c, c->ev);
     }
     stage_begin(c, c->ev, "flow_blf_final");
-    launch_flow_blf(c->flow_tmp[0], c->flow[0], c->img1[0], (int)(c->ipitch[0] / 4), c->W[0], c->H[0], c->W[0], c->lut_blf, s);      // driver :289
+    launch_flow_blf(c->flow_tmp[0], c->flow[0], c->img1[0], (int)(c->ipitch[0] / 4), c->W[0], c->H[0], c->W[0], c->lut_blf, s, bt);      // driver :289
     std::swap(c->flow[0], c->flow_tmp[0]);
     stage_end(c, c->ev);
-    if (d_flow) HIPCHK(hipMemcpyAsync(d_flow, c->flow[0], (size_t)c->h * c->w * 8, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipGetLastError());
     c->have_flow = true;
+    return EPPM_OK;
+}
+
+extern "C" int eppm_compute_device(eppm_ctx* c, void* d_flow)
+{
+    if (!c) return set_err(EPPM_ERR_ARG, "NULL ctx");
+    CHK(compute_all(c));
+    if (d_flow) HIPCHK(hipMemcpyAsync(d_flow, c->flow[0], (size_t)c->h * c->w * 8, hipMemcpyDeviceToDevice, c->stream));
+    return EPPM_OK;
+}
+
+extern "C" int eppm_batch_compute_device(eppm_ctx* c, void* const* d_flows)
+{
+    if (!c) return set_err(EPPM_ERR_ARG, "NULL ctx");
+    CHK(compute_all(c));
+    if (d_flows)
+        for (int k = 0; k < c->n_active; k++)
+            if (d_flows[k]) HIPCHK(hipMemcpyAsync(d_flows[k], c->of_pair(c->flow[0], k), (size_t)c->h * c->w * 8, hipMemcpyDeviceToDevice, c->stream));
     return EPPM_OK;
 }
 
@@ -574,23 +662,39 @@ extern "C" int eppm_compute_device(eppm_ctx* c, void* d_flow)
 extern "C" int eppm_compute_begin(eppm_ctx* c)
 {
     if (!c) return set_err(EPPM_ERR_ARG, "eppm_compute_begin: NULL ctx");
-    CHK(eppm_compute_device(c, nullptr));
+    CHK(compute_all(c));
     const size_t n = (size_t)c->h * c->w;
-    HIPCHK(hipMemcpyAsync(c->h_flow, c->flow[0], n * 8, hipMemcpyDeviceToHost, c->stream));    // driver :299
+    for (int k = 0; k < c->n_active; k++)                                                                                         // driver :299
+        HIPCHK(hipMemcpyAsync(c->h_flow + (size_t)k * n * 2, c->of_pair(c->flow[0], k), n * 8, hipMemcpyDeviceToHost, c->stream));
     c->flow_pending = true;
+    return EPPM_OK;
+}
+
+static int compute_end(eppm_ctx* c, int n_out, float* const* u, float* const* v)
+{
+    if (!c->flow_pending) return set_err(EPPM_ERR_STATE, "eppm_compute_end without eppm_compute_begin");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->flow_pending = false;
+    const size_t n = (size_t)c->h * c->w;
+    for (int k = 0; k < n_out; k++) {
+        if (!u[k] || !v[k]) continue;
+        const float* f = c->h_flow + (size_t)k * n * 2;
+        for (size_t i = 0; i < n; i++) { u[k][i] = f[2 * i]; v[k][i] = f[2 * i + 1]; }    // driver :302-306
+    }
     return EPPM_OK;
 }
 
 extern "C" int eppm_compute_end(eppm_ctx* c, float* u, float* v)
 {
     if (!c || !u || !v) return set_err(EPPM_ERR_ARG, "eppm_compute_end: NULL argument");
-    if (!c->flow_pending) return set_err(EPPM_ERR_STATE, "eppm_compute_end without eppm_compute_begin");
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->flow_pending = false;
-    const size_t n = (size_t)c->h * c->w;
-    for (size_t i = 0; i < n; i++) { u[i] = c->h_flow[2 * i]; v[i] = c->h_flow[2 * i + 1]; }    // driver :302-306
-    return EPPM_OK;
+    return compute_end(c, 1, &u, &v);
+}
+
+extern "C" int eppm_batch_compute_end(eppm_ctx* c, float* const* u, float* const* v)
+{
+    if (!c || !u || !v) return set_err(EPPM_ERR_ARG, "eppm_batch_compute_end: NULL argument");
+    return compute_end(c, c->n_active, u, v);
 }
 
 extern "C" int eppm_compute(eppm_ctx* c, float* u, float* v)
@@ -598,6 +702,13 @@ extern "C" int eppm_compute(eppm_ctx* c, float* u, float* v)
     if (!c || !u || !v) return set_err(EPPM_ERR_ARG, "eppm_compute: NULL argument");
     CHK(eppm_compute_begin(c));
     return eppm_compute_end(c, u, v);
+}
+
+extern "C" int eppm_batch_compute(eppm_ctx* c, float* const* u, float* const* v)
+{
+    if (!c || !u || !v) return set_err(EPPM_ERR_ARG, "eppm_batch_compute: NULL argument");
+    CHK(eppm_compute_begin(c));
+    return eppm_batch_compute_end(c, u, v);
 }
 
 extern "C" int eppm_synchronize(eppm_ctx* c)
@@ -631,10 +742,11 @@ extern "C" int eppm_clear_stage_times(eppm_ctx* c)
     return EPPM_OK;
 }
 
-extern "C" int eppm_get_plane(eppm_ctx* c, const char* name, int level, void* dst, size_t dst_bytes)
+extern "C" int eppm_batch_get_plane(eppm_ctx* c, int pair, const char* name, int level, void* dst, size_t dst_bytes)
 {
     if (!c || !name || !dst) return set_err(EPPM_ERR_ARG, "eppm_get_plane: NULL argument");
     if (level < 0 || level >= c->nl) return set_err(EPPM_ERR_ARG, "eppm_get_plane: bad level %d", level);
+    if (pair < 0 || pair >= c->npairs) return set_err(EPPM_ERR_ARG, "eppm_get_plane: bad pair %d", pair);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     const int w = c->W[level], h = c->H[level], L = c->nl - 1;
@@ -648,8 +760,13 @@ extern "C" int eppm_get_plane(eppm_ctx* c, const char* name, int level, void* ds
     else if (level == L && (n == "cost1" || n == "cost2")) { src = (n == "cost1") ? c->cost1 : c->cost2; esz = 4; pitch = (size_t)w * 4; }
     else return set_err(EPPM_ERR_ARG, "eppm_get_plane: unknown plane '%s' at level %d", name, level);
     if (dst_bytes < (size_t)w * h * esz) return set_err(EPPM_ERR_ARG, "eppm_get_plane: dst too small");
-    HIPCHK(hipMemcpy2D(dst, (size_t)w * esz, src, pitch, (size_t)w * esz, h, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(dst, (size_t)w * esz, c->of_pair((const char*)src, pair), pitch, (size_t)w * esz, h, hipMemcpyDeviceToHost));
     return EPPM_OK;
+}
+
+extern "C" int eppm_get_plane(eppm_ctx* c, const char* name, int level, void* dst, size_t dst_bytes)
+{
+    return eppm_batch_get_plane(c, 0, name, level, dst, dst_bytes);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1106,7 +1223,6 @@ extern "C" int eppm_compute_color(eppm_ctx* c, uint8_t* rgb, size_t row_stride, 
     if (row_stride < (size_t)c->w * 3) return set_err(EPPM_ERR_ARG, "eppm_compute_color: row_stride %zu < 3*w", row_stride);
     HIPCHK(hipSetDevice(c->device));
     const size_t n = (size_t)c->h * c->w;
-    if (!c->d_color) HIPCHK(hipMalloc((void**)&c->d_color, n * 4));
     if (!c->h_color) HIPCHK(hipHostMalloc((void**)&c->h_color, n * 4, hipHostMallocDefault));
     launch_flow_to_color(c->d_color, c->flow[0], c->h, c->w, max_disp_x, max_disp_y, c->stream);       // driver :311
     HIPCHK(hipMemcpyAsync(c->h_color, c->d_color, n * 4, hipMemcpyDeviceToHost, c->stream));           // driver :312

@@ -14,6 +14,18 @@
 
 namespace eppm {
 
+// ---- batches of pairs: pair k's plane = pair 0's pointer + k * stride bytes (eppm_internal.h: Batch) ----------
+template <class T>
+__device__ __forceinline__ T* pair_ptr(T* p, size_t stride, unsigned pair)
+{
+    return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + stride * pair);
+}
+template <class T>
+__device__ __forceinline__ T* pair_ptr_opt(T* p, size_t stride, unsigned pair)     // NULL stays NULL
+{
+    return p ? pair_ptr(p, stride, pair) : p;
+}
+
 // ---- constants (defs.h:31-76 and file-local #defines of the reference) -------------------------
 constexpr float kLambdaAd2 = 0.1f * 0.1f;          // LAMBDA_AD*LAMBDA_AD, defs.h:51
 constexpr float kPmSigR2 = 0.1f * 0.1f;            // PM_SIG_R*PM_SIG_R, defs.h:48

@@ -18,6 +18,15 @@ constexpr int kMaxS = 32;        // samples per patch row: patch_r + 1 <= 32
 constexpr int kWmfRadius = 4;    // defs.h:58
 constexpr int kBlfRadius = 10;   // 2*POSTPROC_BLF_SIG_S, refine :753
 
+// Batch of independent pairs processed by ONE launch: every device plane of pair k lives at the same offset inside
+// pair k's slab, and the slabs are `stride` bytes apart, so a kernel finds pair k's planes by adding k*stride to the
+// pointers it was given for pair 0 (blockIdx.z, or .y for 1-D grids, selects the pair).  {1, 0} = a single pair.
+struct Batch {
+    int n;
+    size_t stride;
+};
+constexpr Batch kOnePair = {1, 0};
+
 struct PlanesH {            // host-side mirror of eppm::Planes: float4 texel planes {r,g,b,census bits}, pitch in pixels
     const void* pk1;
     const void* pk2;
@@ -25,24 +34,24 @@ struct PlanesH {            // host-side mirror of eppm::Planes: float4 texel pl
 };
 
 // ---- prepare (k_prepare.hip) ----
-void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s);
+void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s, Batch bt = kOnePair);
 // blur + exact 2:1 decimation in one kernel (only the kept pixels are blurred); use when gauss_decimate2_ok()
 bool gauss_decimate2_ok(int outH, int outW, int h, int w, float ratio, int radius);
 void launch_gauss_decimate2(uint32_t* out0, const uint32_t* in0, uint32_t* out1, const uint32_t* in1, int nimg, int out_pitch_px, int outH,
-                            int outW, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s);
+                            int outW, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s, Batch bt = kOnePair);
 // the same blur on two images of equal geometry in one launch
 void launch_gauss_rgba2(uint32_t* out0, const uint32_t* in0, uint32_t* out1, const uint32_t* in1, int pitch_px, int h, int w, float sigma,
-                        int radius, hipStream_t s);
+                        int radius, hipStream_t s, Batch bt = kOnePair);
 // census (+ texel plane) of several planes in one launch
 struct CensusJob { uint8_t* census; int cpitch; void* texels; int tpitch; const uint32_t* img; int ipitch; int w, h; int first_block; };
 struct CensusBatch { int n; CensusJob job[2 * kMaxLevels]; };
-void launch_census_batch(CensusBatch& B, hipStream_t s);
+void launch_census_batch(CensusBatch& B, hipStream_t s, Batch bt = kOnePair);
 void launch_resize_rgba(uint32_t* out, int out_pitch_px, int outH, int outW, const uint32_t* in, int in_pitch_px, int h, int w,
-                        float ratio, hipStream_t s);
+                        float ratio, hipStream_t s, Batch bt = kOnePair);
 // census plane and (optionally, texels != NULL) the float4 texel plane the patch kernels read
 void launch_census(uint8_t* census, int cpitch, void* texels, int tpitch, const uint32_t* img, int ipitch, int w, int h, hipStream_t s);
 void launch_pack(void* texels, int tpitch, const uint32_t* img, int ipitch, const uint8_t* census, int cpitch, int w, int h, hipStream_t s);
-void launch_rgb_to_rgba(uint32_t* out, int pitch_px, const uint8_t* rgb, int h, int w, hipStream_t s);
+void launch_rgb_to_rgba(uint32_t* out, int pitch_px, const uint8_t* rgb, int h, int w, hipStream_t s, Batch bt = kOnePair);
 
 // ---- PatchMatch (k_patchmatch.hip) ----
 // One PatchMatch problem = (source planes, target planes, NNF, cost).  The forward (1->2) and backward (2->1)
@@ -56,9 +65,11 @@ struct PmProblem {
     uint32_t* rng_work_next;  // ... written by it (ping-pong: four workgroups read each block's state, one advances it)
 };
 struct PmBatch {
-    PmProblem p[2];
-    int n;               // 1 or 2
+    PmProblem p[2];      // the problems of pair 0; pair k's are `stride` bytes further (every pointer of PmProblem)
+    int n;               // problems per pair: 1 or 2
     int cpitch, npitch;  // elements
+    int npairs = 1;      // a launch covers n * npairs problems
+    size_t stride = 0;
 };
 // RNG tables shared by both problems (same seed, same block ids: the reference re-initialises the states on
 // every baoCudaPatchMatch call, kernel.cu:160); see xorwow_host.cpp
@@ -82,28 +93,28 @@ void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float*
                              hipStream_t s);
 
 // ---- level-2 post-processing (k_post.hip) ----
-void launch_lr_check(int16_t* nnf1, float* cost1, const int16_t* nnf2, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s);
-void launch_outlier(int16_t* nnf_out, float* cost, const int16_t* nnf_in, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s);
+void launch_lr_check(int16_t* nnf1, float* cost1, const int16_t* nnf2, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s, Batch bt = kOnePair);
+void launch_outlier(int16_t* nnf_out, float* cost, const int16_t* nnf_in, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s, Batch bt = kOnePair);
 // all num_iter Jacobi launches; ping-pongs buf_a (input) / buf_b, ws = 2*w*h + num_iter + 2 uint32 words; returns the result buffer
 size_t wmf_workspace_words(int w, int h, int num_iter);
 int16_t* launch_wmf(int16_t* buf_a, int16_t* buf_b, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
-                    const float* wmf_lut, int num_iter, int only_occlusion, uint32_t* ws, hipStream_t s);
+                    const float* wmf_lut, int num_iter, int only_occlusion, uint32_t* ws, hipStream_t s, Batch bt = kOnePair);
 void launch_fill_holes(int16_t* nnf_out, const int16_t* nnf_in, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
-                       hipStream_t s);
-void launch_nnf2flow(float* flow, int flow_pitch, const int16_t* nnf, int nnf_pitch, int w, int h, hipStream_t s);
+                       hipStream_t s, Batch bt = kOnePair);
+void launch_nnf2flow(float* flow, int flow_pitch, const int16_t* nnf, int nnf_pitch, int w, int h, hipStream_t s, Batch bt = kOnePair);
 
 // ---- coarse to fine (k_c2f.hip) ----
-void launch_resize_flow(float* out, int outH, int outW, const float* in, int h, int w, float ratio, float post_scale, hipStream_t s);
+void launch_resize_flow(float* out, int outH, int outW, const float* in, int h, int w, float ratio, float post_scale, hipStream_t s, Batch bt = kOnePair);
 void launch_mul_scalar(float* flow, float scale, int h, int w, hipStream_t s);
-bool c2f_refine_wants_split(int w, int h, int R);
+bool c2f_refine_wants_split(int w, int h, int R, int npairs = 1);
 // cost9: scratch of 36 floats per pixel for launches that c2f_refine_wants_split(), or NULL
-void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, float* cost9, hipStream_t s);
+void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, float* cost9, hipStream_t s, Batch bt = kOnePair);
 void launch_flow_blf(float* out, const float* in, const uint32_t* img, int ipitch, int w, int h, int flow_pitch,
-                     const float* blf_lut, hipStream_t s);
+                     const float* blf_lut, hipStream_t s, Batch bt = kOnePair);
 
 // ---- flow colour coding (k_color.hip) ----
 // rgba: h*w packed R | G<<8 | B<<16 (alpha 0); flow: h*w float2
-void launch_flow_to_color(uint32_t* rgba, const float* flow, int h, int w, float max_disp_x, float max_disp_y, hipStream_t s);
+void launch_flow_to_color(uint32_t* rgba, const float* flow, int h, int w, float max_disp_x, float max_disp_y, hipStream_t s, Batch bt = kOnePair);
 
 // ---- probes (k_prepare.hip) ----
 void launch_probe(const float* x, float* y, int n, int which, hipStream_t s);

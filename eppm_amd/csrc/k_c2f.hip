@@ -17,18 +17,20 @@ namespace eppm {
 #define EPPM_PRAGMA_(x) _Pragma(#x)
 #define EPPM_UNROLL(n) EPPM_PRAGMA_(unroll n)
 
-__device__ __forceinline__ Planes to_dev(const PlanesH& h)
+__device__ __forceinline__ Planes to_dev(const PlanesH& h, size_t pstride = 0, unsigned pair = 0)
 {
     Planes p;
-    p.pk1 = (const float4*)h.pk1; p.pk2 = (const float4*)h.pk2;
+    p.pk1 = pair_ptr((const float4*)h.pk1, pstride, pair); p.pk2 = pair_ptr((const float4*)h.pk2, pstride, pair);
     p.w = h.w; p.h = h.h; p.pitch = h.pitch;
     return p;
 }
 
 // .cuh:511-537 as written (m outer over x, n inner over y), then the x post_scale of .cuh:135-142
-__global__ __launch_bounds__(256) void k_resize_flow(float* __restrict__ out, int outH, int outW, const float* __restrict__ in,
-                                                     int h, int w, float ratio, float post_scale)
+__global__ __launch_bounds__(256) void k_resize_flow(float* __restrict__ out_, int outH, int outW, const float* __restrict__ in_,
+                                                     int h, int w, float ratio, float post_scale, size_t pstride)
 {
+    float* __restrict__ out = pair_ptr(out_, pstride, blockIdx.z);
+    const float* __restrict__ in = pair_ptr(in_, pstride, blockIdx.z);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= outW || y >= outH) return;
     const float div_scale = 1.f / ratio;
@@ -49,10 +51,10 @@ __global__ __launch_bounds__(256) void k_resize_flow(float* __restrict__ out, in
     out[(y * outW + x) * 2] = rx * post_scale;
     out[(y * outW + x) * 2 + 1] = ry * post_scale;
 }
-void launch_resize_flow(float* out, int outH, int outW, const float* in, int h, int w, float ratio, float post_scale, hipStream_t s)
+void launch_resize_flow(float* out, int outH, int outW, const float* in, int h, int w, float ratio, float post_scale, hipStream_t s, Batch bt)
 {
-    dim3 block(64, 4), grid((outW + 63) / 64, (outH + 3) / 4);
-    hipLaunchKernelGGL(k_resize_flow, grid, block, 0, s, out, outH, outW, in, h, w, ratio, post_scale);
+    dim3 block(64, 4), grid((outW + 63) / 64, (outH + 3) / 4, bt.n);
+    hipLaunchKernelGGL(k_resize_flow, grid, block, 0, s, out, outH, outW, in, h, w, ratio, post_scale, bt.stride);
 }
 
 __global__ __launch_bounds__(256) void k_mul_scalar(float* __restrict__ f, float scale, int n)
@@ -71,12 +73,13 @@ void launch_mul_scalar(float* flow, float scale, int h, int w, hipStream_t s)
 // up-sampled flow; cost = min of 4 affine passes; strict < keeps the first minimum; the centre candidate
 // is the initial best with cost 999999.  In place: a thread reads and writes only its own pixel.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_c2f_refine(PlanesH Ph, float* __restrict__ flow, const float* __restrict__ lut, int R)
+__global__ __launch_bounds__(256) void k_c2f_refine(PlanesH Ph, float* __restrict__ flow_, const float* __restrict__ lut, int R, size_t pstride)
 {
     __shared__ PatchLut L;
     load_patch_lut(L, lut, R, threadIdx.y * kBlock + threadIdx.x, 256);
     __syncthreads();
-    const Planes P = to_dev(Ph);
+    const Planes P = to_dev(Ph, pstride, blockIdx.z);
+    float* __restrict__ flow = pair_ptr(flow_, pstride, blockIdx.z);
     const int x = blockIdx.x * kBlock + threadIdx.x, y = blockIdx.y * kBlock + threadIdx.y;
     if (x >= P.w || y >= P.h) return;
     const float fvx = flow[(y * P.w + x) * 2], fvy = flow[(y * P.w + x) * 2 + 1];
@@ -243,9 +246,11 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
 // each), whichever divides more evenly over the 256 CUs; the costs of a pixel (9 x 4 passes) go to a scratch plane and
 // k_c2f_select replays the reference's nested minimum and candidate loop.  Same costs, same selection order.
 template <int R, int SPLIT>
-__global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH Ph, float* __restrict__ flow, const float* __restrict__ lut,
-                                                                       float* __restrict__ cost9)
+__global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH Ph, float* __restrict__ flow_, const float* __restrict__ lut,
+                                                                       float* __restrict__ cost9_, size_t pstride)
 {
+    float* __restrict__ flow = pair_ptr(flow_, pstride, blockIdx.y);             // blockIdx.y = pair of the batch
+    float* __restrict__ cost9 = pair_ptr_opt(cost9_, pstride, blockIdx.y);
     constexpr int TWU = kBlock + 2 * R;                 // used tile width
     // row stride padded to a multiple of 16 texels (256 B): a ds_read_b128 wave access is served in groups made
     // of 8 lanes of one tile row and 8 of the next (MI355X LDS lane groups); with the stride = 0 mod 256 B the two
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
     __shared__ float4 s_src[TWU * TW];
     const int tid = threadIdx.y * kBlock + threadIdx.x;
     load_patch_lut(L, lut, R, tid, 256);
-    const Planes P = to_dev(Ph);
+    const Planes P = to_dev(Ph, pstride, blockIdx.y);
     // XCD-aware tile order: workgroups are dealt round robin over the 8 XCDs (b % 8), each with its own L2.
     // Give XCD k the k-th contiguous eighth of the row-major tile list so that neighbouring tiles -- which
     // share their R-pixel halos and their target windows -- hit the same L2 (speed only, never correctness).
@@ -331,8 +336,10 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
 
 // the candidate loop of kernel.cu:2028-2040 over the 9 costs written by the split launch
 template <int SPLIT>
-__global__ __launch_bounds__(256) void k_c2f_select(float* __restrict__ flow, const float* __restrict__ cost9, int w, int h)
+__global__ __launch_bounds__(256) void k_c2f_select(float* __restrict__ flow_, const float* __restrict__ cost9_, int w, int h, size_t pstride)
 {
+    float* __restrict__ flow = pair_ptr(flow_, pstride, blockIdx.z);
+    const float* __restrict__ cost9 = pair_ptr(cost9_, pstride, blockIdx.z);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
     const float fvx = flow[(y * w + x) * 2], fvy = flow[(y * w + x) * 2 + 1];
@@ -366,9 +373,9 @@ __global__ __launch_bounds__(256) void k_c2f_select(float* __restrict__ flow, co
     flow[(y * w + x) * 2 + 1] = (float)(by - y);
 }
 
-bool c2f_refine_wants_split(int w, int h, int R)
+bool c2f_refine_wants_split(int w, int h, int R, int npairs)
 {
-    const int tiles = ((w + kBlock - 1) / kBlock) * ((h + kBlock - 1) / kBlock);
+    const int tiles = ((w + kBlock - 1) / kBlock) * ((h + kBlock - 1) / kBlock) * npairs;
 #ifndef EPPM_C2F_SPLIT_BELOW_WAVES
 #define EPPM_C2F_SPLIT_BELOW_WAVES (3 * 1024)        // fewer than 3 waves per SIMD on 256 CUs
 #endif
@@ -376,32 +383,32 @@ bool c2f_refine_wants_split(int w, int h, int R)
 }
 
 // cost9: scratch of 36 floats per pixel, or NULL (never split)
-void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, float* cost9, hipStream_t s)
+void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, float* cost9, hipStream_t s, Batch bt)
 {
-    dim3 grid((P.w + kBlock - 1) / kBlock, (P.h + kBlock - 1) / kBlock), block(kBlock, kBlock);
+    dim3 grid((P.w + kBlock - 1) / kBlock, (P.h + kBlock - 1) / kBlock, bt.n), block(kBlock, kBlock);
     const int tiles = grid.x * grid.y;
     const int per_xcd = (tiles + 7) / 8;
-    dim3 grid1(per_xcd * 8);                     // 1-D, padded so every XCD gets the same number of slots
+    dim3 grid1(per_xcd * 8, bt.n);               // x: padded so every XCD gets the same number of slots; y: pair
     const bool table_ok = (P.w + R < 32764) && (P.h + R < 32764);     // range of the offset-table identity (c2f_pass)
-    if (cost9 && table_ok && c2f_refine_wants_split(P.w, P.h, R)) {
+    if (cost9 && table_ok && c2f_refine_wants_split(P.w, P.h, R, bt.n)) {
         // 3 or 4 workgroups per tile: the factor whose workgroup count divides more evenly over the 256 CUs
-        auto imbalance = [&](int f) { const int wgs = tiles * f; return (float)((wgs + 255) / 256) * 256.0f / (float)wgs; };
+        auto imbalance = [&](int f) { const int wgs = tiles * f * bt.n; return (float)((wgs + 255) / 256) * 256.0f / (float)wgs; };
         const int f = (imbalance(4) < imbalance(3)) ? 4 : 3;
-        dim3 gridf(per_xcd * f * 8), gs((P.w + 63) / 64, (P.h + 3) / 4), bs(64, 4);
+        dim3 gridf(per_xcd * f * 8, bt.n), gs((P.w + 63) / 64, (P.h + 3) / 4, bt.n), bs(64, 4);
         if (f == 3) {
-            if (R == 9) hipLaunchKernelGGL((k_c2f_refine_tiled<9, 3>), gridf, block, 0, s, P, flow, lut, cost9);
-            else hipLaunchKernelGGL((k_c2f_refine_tiled<17, 3>), gridf, block, 0, s, P, flow, lut, cost9);
-            hipLaunchKernelGGL(k_c2f_select<3>, gs, bs, 0, s, flow, cost9, P.w, P.h);
+            if (R == 9) hipLaunchKernelGGL((k_c2f_refine_tiled<9, 3>), gridf, block, 0, s, P, flow, lut, cost9, bt.stride);
+            else hipLaunchKernelGGL((k_c2f_refine_tiled<17, 3>), gridf, block, 0, s, P, flow, lut, cost9, bt.stride);
+            hipLaunchKernelGGL(k_c2f_select<3>, gs, bs, 0, s, flow, cost9, P.w, P.h, bt.stride);
         } else {
-            if (R == 9) hipLaunchKernelGGL((k_c2f_refine_tiled<9, 4>), gridf, block, 0, s, P, flow, lut, cost9);
-            else hipLaunchKernelGGL((k_c2f_refine_tiled<17, 4>), gridf, block, 0, s, P, flow, lut, cost9);
-            hipLaunchKernelGGL(k_c2f_select<4>, gs, bs, 0, s, flow, cost9, P.w, P.h);
+            if (R == 9) hipLaunchKernelGGL((k_c2f_refine_tiled<9, 4>), gridf, block, 0, s, P, flow, lut, cost9, bt.stride);
+            else hipLaunchKernelGGL((k_c2f_refine_tiled<17, 4>), gridf, block, 0, s, P, flow, lut, cost9, bt.stride);
+            hipLaunchKernelGGL(k_c2f_select<4>, gs, bs, 0, s, flow, cost9, P.w, P.h, bt.stride);
         }
         return;
     }
-    if (R == 9 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<9, 0>), grid1, block, 0, s, P, flow, lut, (float*)nullptr);
-    else if (R == 17 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<17, 0>), grid1, block, 0, s, P, flow, lut, (float*)nullptr);
-    else hipLaunchKernelGGL(k_c2f_refine, grid, block, 0, s, P, flow, lut, R);
+    if (R == 9 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<9, 0>), grid1, block, 0, s, P, flow, lut, (float*)nullptr, bt.stride);
+    else if (R == 17 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<17, 0>), grid1, block, 0, s, P, flow, lut, (float*)nullptr, bt.stride);
+    else hipLaunchKernelGGL(k_c2f_refine, grid, block, 0, s, P, flow, lut, R, bt.stride);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -418,10 +425,13 @@ void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, f
 constexpr int BT_W = 32, BR = kBlfRadius, BTW = BT_W + 2 * BR;
 
 template <int PPL>
-__global__ __launch_bounds__(256) void k_flow_blf(float* __restrict__ out, const float* __restrict__ in,
-                                                  const uint32_t* __restrict__ img, int ipitch, int w, int h, int fpitch,
-                                                  const float* __restrict__ blf_lut)
+__global__ __launch_bounds__(256) void k_flow_blf(float* __restrict__ out_, const float* __restrict__ in_,
+                                                  const uint32_t* __restrict__ img_, int ipitch, int w, int h, int fpitch,
+                                                  const float* __restrict__ blf_lut, size_t pstride)
 {
+    float* __restrict__ out = pair_ptr(out_, pstride, blockIdx.z);
+    const float* __restrict__ in = pair_ptr(in_, pstride, blockIdx.z);
+    const uint32_t* __restrict__ img = pair_ptr(img_, pstride, blockIdx.z);
     constexpr int BT_H = 8 * PPL, BTH = BT_H + 2 * BR;
     __shared__ float4 s_t[BTH * BTW];          // r, g, b (unorm), flow x
     __shared__ float s_fy[BTH * BTW];
@@ -508,16 +518,16 @@ EPPM_UNROLL(EPPM_BLF_UNROLL)
     }
 }
 void launch_flow_blf(float* out, const float* in, const uint32_t* img, int ipitch, int w, int h, int flow_pitch,
-                     const float* blf_lut, hipStream_t s)
+                     const float* blf_lut, hipStream_t s, Batch bt)
 {
     dim3 block(BT_W, 8);
-    const int wgs2 = ((w + BT_W - 1) / BT_W) * ((h + 15) / 16);
+    const int wgs2 = ((w + BT_W - 1) / BT_W) * ((h + 15) / 16) * bt.n;
     // two pixels per lane halve the LDS traffic but double the work quantum: they pay from about 8 workgroups per CU
     // (1920x1080: 0.96 vs 1.03 ms); below that the finer quantum balances the 256 CUs better (1024x436: 0.25 vs 0.27 ms)
     if (wgs2 >= 8 * 256) {
-        hipLaunchKernelGGL(k_flow_blf<2>, dim3((w + BT_W - 1) / BT_W, (h + 15) / 16), block, 0, s, out, in, img, ipitch, w, h, flow_pitch, blf_lut);
+        hipLaunchKernelGGL(k_flow_blf<2>, dim3((w + BT_W - 1) / BT_W, (h + 15) / 16, bt.n), block, 0, s, out, in, img, ipitch, w, h, flow_pitch, blf_lut, bt.stride);
     } else {
-        hipLaunchKernelGGL(k_flow_blf<1>, dim3((w + BT_W - 1) / BT_W, (h + 7) / 8), block, 0, s, out, in, img, ipitch, w, h, flow_pitch, blf_lut);
+        hipLaunchKernelGGL(k_flow_blf<1>, dim3((w + BT_W - 1) / BT_W, (h + 7) / 8, bt.n), block, 0, s, out, in, img, ipitch, w, h, flow_pitch, blf_lut, bt.stride);
     }
 }
 

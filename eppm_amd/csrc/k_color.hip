@@ -75,8 +75,10 @@ __device__ __forceinline__ uint32_t flow_color(float fx, float fy)
 }
 
 // _d_bao_convert_flow_to_colorshow (float2 form), .cuh:816-829
-__global__ __launch_bounds__(256) void k_flow_to_color(uint32_t* __restrict__ rgba, const float2* __restrict__ flow, int h, int w, float max_rad)
+__global__ __launch_bounds__(256) void k_flow_to_color(uint32_t* __restrict__ rgba_, const float2* __restrict__ flow_, int h, int w, float max_rad, size_t pstride)
 {
+    uint32_t* __restrict__ rgba = pair_ptr(rgba_, pstride, blockIdx.z);
+    const float2* __restrict__ flow = pair_ptr(flow_, pstride, blockIdx.z);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
     const float2 v = flow[y * w + x];
@@ -85,11 +87,11 @@ __global__ __launch_bounds__(256) void k_flow_to_color(uint32_t* __restrict__ rg
     rgba[y * w + x] = c;
 }
 
-void launch_flow_to_color(uint32_t* rgba, const float* flow, int h, int w, float max_disp_x, float max_disp_y, hipStream_t s)
+void launch_flow_to_color(uint32_t* rgba, const float* flow, int h, int w, float max_disp_x, float max_disp_y, hipStream_t s, Batch bt)
 {
     const float max_rad = sqrtf(max_disp_x * max_disp_x + max_disp_y * max_disp_y);     // sqrt(float) overload, .cuh:835,844
-    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(k_flow_to_color, grid, block, 0, s, rgba, (const float2*)flow, h, w, max_rad);
+    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4, bt.n);
+    hipLaunchKernelGGL(k_flow_to_color, grid, block, 0, s, rgba, (const float2*)flow, h, w, max_rad, bt.stride);
 }
 
 }  // namespace eppm

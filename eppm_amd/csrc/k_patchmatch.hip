@@ -32,6 +32,21 @@ __device__ __forceinline__ Planes to_dev(const PlanesH& h)
     return p;
 }
 
+// problem q of a launch: direction q % n of pair q / n; pair k's planes lie k * stride bytes after pair 0's
+__device__ __forceinline__ PmProblem pm_problem(const PmBatch& B, unsigned q)
+{
+    PmProblem p = B.p[q % (unsigned)B.n];
+    const unsigned pair = q / (unsigned)B.n;
+    p.P.pk1 = pair_ptr_opt(p.P.pk1, B.stride, pair);
+    p.P.pk2 = pair_ptr_opt(p.P.pk2, B.stride, pair);
+    p.cost = pair_ptr_opt(p.cost, B.stride, pair);
+    p.nnf = pair_ptr_opt(p.nnf, B.stride, pair);
+    p.nnf_alt = pair_ptr_opt(p.nnf_alt, B.stride, pair);
+    p.rng_work = pair_ptr_opt(p.rng_work, B.stride, pair);
+    p.rng_work_next = pair_ptr_opt(p.rng_work_next, B.stride, pair);
+    return p;
+}
+
 __device__ __forceinline__ Xorwow load_state(const uint32_t* p)
 {
     Xorwow s;
@@ -52,7 +67,7 @@ __device__ __forceinline__ void store_state(uint32_t* p, const Xorwow& s)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_pm_init_field(PmBatch B, PmRngDev rng)
 {
-    const PmProblem& pr = B.p[blockIdx.z];
+    const PmProblem pr = pm_problem(B, blockIdx.z);
     const int bx = blockIdx.x, by = blockIdx.y, lane = threadIdx.x;
     const int w = pr.P.w, h = pr.P.h;
     const int block_id = by * rng.gx + bx;
@@ -76,7 +91,7 @@ __global__ __launch_bounds__(64) void k_pm_init_field(PmBatch B, PmRngDev rng)
 
 void launch_pm_init_field(const PmBatch& b, const PmRngDev& rng, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pm_init_field, dim3(rng.gx, rng.gy, b.n), dim3(64), 0, s, b, rng);
+    hipLaunchKernelGGL(k_pm_init_field, dim3(rng.gx, rng.gy, b.n * b.npairs), dim3(64), 0, s, b, rng);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -87,7 +102,7 @@ __global__ __launch_bounds__(256) void k_pm_cost_field(PmBatch B, const float* _
     __shared__ PatchLut L;
     load_patch_lut(L, lut, R, threadIdx.y * kBlock + threadIdx.x, 256);
     __syncthreads();
-    const PmProblem& pr = B.p[blockIdx.z];
+    const PmProblem pr = pm_problem(B, blockIdx.z);
     const Planes P = to_dev(pr.P);
     const int x = blockIdx.x * kBlock + threadIdx.x, y = blockIdx.y * kBlock + threadIdx.y;
     if (x >= P.w || y >= P.h) return;
@@ -98,7 +113,7 @@ __global__ __launch_bounds__(256) void k_pm_cost_field(PmBatch B, const float* _
 void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t s)
 {
     const int w = b.p[0].P.w, h = b.p[0].P.h;
-    dim3 grid((w + kBlock - 1) / kBlock, (h + kBlock - 1) / kBlock, b.n), block(kBlock, kBlock);
+    dim3 grid((w + kBlock - 1) / kBlock, (h + kBlock - 1) / kBlock, b.n * b.npairs), block(kBlock, kBlock);
     hipLaunchKernelGGL(k_pm_cost_field, grid, block, 0, s, b, lut, R);
 }
 
@@ -135,7 +150,7 @@ __global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __rest
     constexpr int S = R + 1, NS = S * S, CH = (NS + LPC - 1) / LPC, CPB = 256 / LPC;
     __shared__ PatchLut L;
     load_patch_lut(L, lut, R, threadIdx.x, 256);
-    const PmProblem& pr = B.p[blockIdx.y];
+    const PmProblem pr = pm_problem(B, blockIdx.y);
     const Planes P = to_dev(pr.P);
     const int16_t* __restrict__ nin = pr.nnf;
     int16_t* __restrict__ nout = pr.nnf_alt;
@@ -262,7 +277,7 @@ __global__ __launch_bounds__(1024) void k_pm_seg_propagate(PmBatch B, const floa
 {
     __shared__ PatchLut L;
     load_patch_lut(L, lut, R, threadIdx.x, blockDim.x);
-    const PmProblem& pr = B.p[blockIdx.y];
+    const PmProblem pr = pm_problem(B, blockIdx.y);
     const Planes P = to_dev(pr.P);
     int16_t* __restrict__ nnf = pr.nnf;
     float* __restrict__ cost = pr.cost;
@@ -320,7 +335,7 @@ static void launch_sweep_r(const PmBatch& b, const float* lut, int seg_len, int 
     const int nseg_pad = (nseg + 1) & ~1;
     const int chains = lines * nseg_pad;
     constexpr int CPB = 256 / LPC;
-    dim3 grid((chains + CPB - 1) / CPB, b.n), block(256);
+    dim3 grid((chains + CPB - 1) / CPB, b.n * b.npairs), block(256);
     switch (dir) {
         case 0: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, false>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
         case 1: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, false>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
@@ -339,7 +354,7 @@ bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int
         // 16 lanes per chain are the most instruction-efficient; when that leaves fewer than two waves per SIMD (the
         // quarter-resolution level of a 1024x436 pair: 1.4) the chip is latency bound and 32 lanes per chain shorten
         // the dependent step (PatchMatch 1.78 -> 1.61 ms, no change in throughput with pairs in flight)
-        const int chains = lines * ((nseg + 1) & ~1) * b.n;
+        const int chains = lines * ((nseg + 1) & ~1) * b.n * b.npairs;
         if (chains * EPPM_LPC9 / 64 < 2 * 1024) launch_sweep_r<9, 2 * EPPM_LPC9>(b, lut, seg_len, dir, nseg, lines, s);
         else launch_sweep_r<9, EPPM_LPC9>(b, lut, seg_len, dir, nseg, lines, s);
         return true;
@@ -349,7 +364,7 @@ bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int
     int lpb = 256 / nseg;
     if (lpb < 1) lpb = 1;
     const int threads = ((nseg * lpb + 63) / 64) * 64;
-    dim3 grid((lines + lpb - 1) / lpb, b.n), block(threads);
+    dim3 grid((lines + lpb - 1) / lpb, b.n * b.npairs), block(threads);
     switch (dir) {
         case 0: hipLaunchKernelGGL((k_pm_seg_propagate<true, false>), grid, block, 0, s, b, lut, R, seg_len, nseg, lpb); break;
         case 1: hipLaunchKernelGGL((k_pm_seg_propagate<false, false>), grid, block, 0, s, b, lut, R, seg_len, nseg, lpb); break;
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(256) void k_pm_jump(PmBatch B, const float* __restr
     __shared__ PatchLut L;
     __shared__ float s_cost[4][64];
     __shared__ int s_cand[4][64];
-    const PmProblem& pr = B.p[blockIdx.z];
+    const PmProblem pr = pm_problem(B, blockIdx.z);
     const int tid = threadIdx.x, lane = tid & 63, k = tid >> 6;
     load_patch_lut(L, lut, R, tid, 256);
     __syncthreads();
@@ -434,14 +449,14 @@ __global__ __launch_bounds__(256) void k_pm_jump(PmBatch B, const float* __restr
 void launch_pm_jump(const PmBatch& b, const float* lut, int R, int step, hipStream_t s)
 {
     const int w = b.p[0].P.w, h = b.p[0].P.h;
-    dim3 grid((w + kBlock - 1) / kBlock, (h + 3) / 4, b.n), block(256);
+    dim3 grid((w + kBlock - 1) / kBlock, (h + 3) / 4, b.n * b.npairs), block(256);
     hipLaunchKernelGGL(k_pm_jump<false>, grid, block, 0, s, b, lut, R, step);
 }
 
 void launch_pm_neighbor(const PmBatch& b, const float* lut, int R, hipStream_t s)
 {
     const int w = b.p[0].P.w, h = b.p[0].P.h;
-    dim3 grid((w + kBlock - 1) / kBlock, (h + 3) / 4, b.n), block(256);
+    dim3 grid((w + kBlock - 1) / kBlock, (h + 3) / 4, b.n * b.npairs), block(256);
     hipLaunchKernelGGL(k_pm_jump<true>, grid, block, 0, s, b, lut, R, 1);
 }
 
@@ -507,7 +522,7 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     __shared__ float s_cost[8][64];
     __shared__ int s_guess[8][64];
     __shared__ uint32_t s_state[64 * 6];
-    const PmProblem& pr = B.p[blockIdx.z];
+    const PmProblem pr = pm_problem(B, blockIdx.z);
     const int tid = threadIdx.x;
     const int tile_y = blockIdx.y >> 2, quarter = blockIdx.y & 3;
     const int block_id = tile_y * rng.gx + blockIdx.x;
@@ -590,7 +605,7 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
 void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float* lut, int R, int search_range, int num_guess,
                              hipStream_t s)
 {
-    dim3 grid(rng.gx, rng.gy * 4, b.n), block(64 * (num_guess + 1));      // + the wave that advances the RNG states
+    dim3 grid(rng.gx, rng.gy * 4, b.n * b.npairs), block(64 * (num_guess + 1));      // + the wave that advances the RNG states
     if (R == 9) hipLaunchKernelGGL(k_pm_random_search<9>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else if (R == 17) hipLaunchKernelGGL(k_pm_random_search<17>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else hipLaunchKernelGGL(k_pm_random_search<0>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);

@@ -9,9 +9,12 @@ namespace eppm {
 // ---------------------------------------------------------------------------------------------------
 // refine :53-76.  In place on (nnf1,cost1): a thread touches only its own pixel; nnf2 is read-only.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lr_check(int16_t* __restrict__ nnf1, float* __restrict__ cost1,
-                                                  const int16_t* __restrict__ nnf2, int w, int h, int cpitch, int npitch)
+__global__ __launch_bounds__(256) void k_lr_check(int16_t* __restrict__ nnf1_, float* __restrict__ cost1_,
+                                                  const int16_t* __restrict__ nnf2_, int w, int h, int cpitch, int npitch, size_t pstride)
 {
+    int16_t* __restrict__ nnf1 = pair_ptr(nnf1_, pstride, blockIdx.z);
+    float* __restrict__ cost1 = pair_ptr(cost1_, pstride, blockIdx.z);
+    const int16_t* __restrict__ nnf2 = pair_ptr(nnf2_, pstride, blockIdx.z);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
     const int dx = nnf1[(y * npitch + x) * 2], dy = nnf1[(y * npitch + x) * 2 + 1];
@@ -27,19 +30,22 @@ __global__ __launch_bounds__(256) void k_lr_check(int16_t* __restrict__ nnf1, fl
         cost1[y * cpitch + x] = FLT_MAX;
     }
 }
-void launch_lr_check(int16_t* nnf1, float* cost1, const int16_t* nnf2, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s)
+void launch_lr_check(int16_t* nnf1, float* cost1, const int16_t* nnf2, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s, Batch bt)
 {
-    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(k_lr_check, grid, block, 0, s, nnf1, cost1, nnf2, w, h, cost_pitch, nnf_pitch);
+    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4, bt.n);
+    hipLaunchKernelGGL(k_lr_check, grid, block, 0, s, nnf1, cost1, nnf2, w, h, cost_pitch, nnf_pitch, bt.stride);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // refine :149-182.  13x13 vote on flow similarity; 32x8 tile + 6-px halo of relative flows in LDS.
 // ---------------------------------------------------------------------------------------------------
 constexpr int OT_W = 32, OT_H = 8;
-__global__ __launch_bounds__(256) void k_outlier(int16_t* __restrict__ nnf_out, float* __restrict__ cost,
-                                                 const int16_t* __restrict__ nnf_in, int w, int h, int cpitch, int npitch)
+__global__ __launch_bounds__(256) void k_outlier(int16_t* __restrict__ nnf_out_, float* __restrict__ cost_,
+                                                 const int16_t* __restrict__ nnf_in_, int w, int h, int cpitch, int npitch, size_t pstride)
 {
+    int16_t* __restrict__ nnf_out = pair_ptr(nnf_out_, pstride, blockIdx.z);
+    float* __restrict__ cost = pair_ptr(cost_, pstride, blockIdx.z);
+    const int16_t* __restrict__ nnf_in = pair_ptr(nnf_in_, pstride, blockIdx.z);
     constexpr int TW = OT_W + 2 * kStatRadius, TH = OT_H + 2 * kStatRadius;
     __shared__ int s_fx[TH * TW];
     __shared__ int s_fy[TH * TW];
@@ -77,10 +83,10 @@ __global__ __launch_bounds__(256) void k_outlier(int16_t* __restrict__ nnf_out, 
     nnf_out[(y * npitch + x) * 2] = (int16_t)rx;
     nnf_out[(y * npitch + x) * 2 + 1] = (int16_t)ry;
 }
-void launch_outlier(int16_t* nnf_out, float* cost, const int16_t* nnf_in, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s)
+void launch_outlier(int16_t* nnf_out, float* cost, const int16_t* nnf_in, int w, int h, int cost_pitch, int nnf_pitch, hipStream_t s, Batch bt)
 {
-    dim3 block(OT_W, OT_H), grid((w + OT_W - 1) / OT_W, (h + OT_H - 1) / OT_H);
-    hipLaunchKernelGGL(k_outlier, grid, block, 0, s, nnf_out, cost, nnf_in, w, h, cost_pitch, nnf_pitch);
+    dim3 block(OT_W, OT_H), grid((w + OT_W - 1) / OT_W, (h + OT_H - 1) / OT_H, bt.n);
+    hipLaunchKernelGGL(k_outlier, grid, block, 0, s, nnf_out, cost, nnf_in, w, h, cost_pitch, nnf_pitch, bt.stride);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -105,9 +111,12 @@ constexpr uint32_t kCopyOnly = 0x80000000u;
 #endif
 constexpr uint32_t kWmfBatch = 256;      // list entries a workgroup processes between two appends
 
-__global__ __launch_bounds__(256) void k_wmf_build_list(const int16_t* __restrict__ nnf, int npitch, int w, int h, int only_occ,
-                                                        uint32_t* __restrict__ list, uint32_t* __restrict__ count)
+__global__ __launch_bounds__(256) void k_wmf_build_list(const int16_t* __restrict__ nnf_, int npitch, int w, int h, int only_occ,
+                                                        uint32_t* __restrict__ list_, uint32_t* __restrict__ count_, size_t pstride)
 {
+    const int16_t* __restrict__ nnf = pair_ptr(nnf_, pstride, blockIdx.z);
+    uint32_t* __restrict__ list = pair_ptr(list_, pstride, blockIdx.z);
+    uint32_t* __restrict__ count = pair_ptr(count_, pstride, blockIdx.z);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
     const int ox = nnf[(y * npitch + x) * 2], oy = nnf[(y * npitch + x) * 2 + 1];
@@ -115,13 +124,23 @@ __global__ __launch_bounds__(256) void k_wmf_build_list(const int16_t* __restric
     list[atomicAdd(count, 1u)] = ((uint32_t)y << 16) | (uint32_t)x;
 }
 
-__global__ __launch_bounds__(256) void k_wmf_iter(int16_t* __restrict__ nnf_out, const int16_t* __restrict__ nnf_in,
-                                                  const uint32_t* __restrict__ img, int ipitch, int w, int h, int npitch,
+// blockIdx.y = pair of the batch (work lists, counters and flags are per pair)
+__global__ __launch_bounds__(256) void k_wmf_iter(int16_t* __restrict__ nnf_out_, const int16_t* __restrict__ nnf_in_,
+                                                  const uint32_t* __restrict__ img_, int ipitch, int w, int h, int npitch,
                                                   const float* __restrict__ wmf_lut, int only_occ,
-                                                  const uint32_t* __restrict__ list_in, const uint32_t* __restrict__ count_in,
-                                                  uint32_t* __restrict__ list_out, uint32_t* __restrict__ count_out,
-                                                  const uint32_t* __restrict__ changed_prev, uint32_t* __restrict__ changed_cur)
+                                                  const uint32_t* __restrict__ list_in_, const uint32_t* __restrict__ count_in_,
+                                                  uint32_t* __restrict__ list_out_, uint32_t* __restrict__ count_out_,
+                                                  const uint32_t* __restrict__ changed_prev_, uint32_t* __restrict__ changed_cur_, size_t pstride)
 {
+    int16_t* __restrict__ nnf_out = pair_ptr(nnf_out_, pstride, blockIdx.y);
+    const int16_t* __restrict__ nnf_in = pair_ptr(nnf_in_, pstride, blockIdx.y);
+    const uint32_t* __restrict__ img = pair_ptr(img_, pstride, blockIdx.y);
+    const uint32_t* __restrict__ list_in = pair_ptr(list_in_, pstride, blockIdx.y);
+    const uint32_t* __restrict__ count_in = pair_ptr(count_in_, pstride, blockIdx.y);
+    uint32_t* __restrict__ list_out = pair_ptr(list_out_, pstride, blockIdx.y);
+    uint32_t* __restrict__ count_out = pair_ptr(count_out_, pstride, blockIdx.y);
+    const uint32_t* __restrict__ changed_prev = pair_ptr_opt(changed_prev_, pstride, blockIdx.y);
+    uint32_t* __restrict__ changed_cur = pair_ptr(changed_cur_, pstride, blockIdx.y);
     // Occlusion-only mode: if the previous launch filled no pixel, the field is at a fixed point -- the listed pixels
     // would be recomputed from unchanged neighbourhoods and stay invalid, and both ping-pong buffers already agree.
     // The remaining launches do nothing (their output count stays 0).
@@ -234,6 +253,18 @@ __global__ __launch_bounds__(256) void k_wmf_iter(int16_t* __restrict__ nnf_out,
     }
 }
 
+// start of a weighted-median run for every pair of the batch: counters and flags zeroed, buf_b = buf_a
+__global__ __launch_bounds__(256) void k_wmf_begin(uint32_t* __restrict__ dst_, const uint32_t* __restrict__ src_, int n_words,
+                                                   uint32_t* __restrict__ counts_, int n_counts, size_t pstride)
+{
+    uint32_t* __restrict__ dst = pair_ptr(dst_, pstride, blockIdx.z);
+    const uint32_t* __restrict__ src = pair_ptr(src_, pstride, blockIdx.z);
+    uint32_t* __restrict__ counts = pair_ptr(counts_, pstride, blockIdx.z);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) dst[i] = src[i];
+    if (i < n_counts) counts[i] = 0u;
+}
+
 size_t wmf_workspace_words(int w, int h, int num_iter)
 {
     return 2 * (size_t)w * h + 2 * (size_t)((num_iter > 0 ? num_iter : 0) + 2);
@@ -243,17 +274,21 @@ size_t wmf_workspace_words(int w, int h, int num_iter)
 // wmf_workspace_words() words (two lists, per-launch counters and "filled a pixel" flags).  Returns the buffer that
 // holds the result.
 int16_t* launch_wmf(int16_t* buf_a, int16_t* buf_b, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
-                    const float* wmf_lut, int num_iter, int only_occlusion, uint32_t* ws, hipStream_t s)
+                    const float* wmf_lut, int num_iter, int only_occlusion, uint32_t* ws, hipStream_t s, Batch bt)
 {
     if (num_iter <= 0) return buf_a;
     uint32_t* list0 = ws;
     uint32_t* list1 = ws + (size_t)w * h;
     uint32_t* counts = ws + 2 * (size_t)w * h;
     uint32_t* changed = counts + num_iter + 2;
-    (void)hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2 * (num_iter + 2), s);
-    (void)hipMemcpyAsync(buf_b, buf_a, (size_t)nnf_pitch * h * 4, hipMemcpyDeviceToDevice, s);
-    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(k_wmf_build_list, grid, block, 0, s, buf_a, nnf_pitch, w, h, only_occlusion, list0, counts);
+    {
+        const int n_words = nnf_pitch * h, n_counts = 2 * (num_iter + 2);
+        const int n = n_words > n_counts ? n_words : n_counts;
+        hipLaunchKernelGGL(k_wmf_begin, dim3((n + 255) / 256, 1, bt.n), dim3(256), 0, s, (uint32_t*)buf_b, (const uint32_t*)buf_a, n_words, counts,
+                           n_counts, bt.stride);
+    }
+    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4, bt.n);
+    hipLaunchKernelGGL(k_wmf_build_list, grid, block, 0, s, buf_a, nnf_pitch, w, h, only_occlusion, list0, counts, bt.stride);
     const int pixels = w * h;
     int nblocks0 = (pixels + 3) / 4;
     if (nblocks0 > EPPM_WMF_MAX_BLOCKS) nblocks0 = EPPM_WMF_MAX_BLOCKS;
@@ -263,9 +298,9 @@ int16_t* launch_wmf(int16_t* buf_a, int16_t* buf_b, const uint32_t* img, int ipi
         // smaller grid so that a (nearly) empty launch costs a launch, not 1024 workgroups reading the counter
         int nblocks = nblocks0;
         if (only_occlusion) nblocks = (nblocks0 >> i) > 64 ? (nblocks0 >> i) : (nblocks0 < 64 ? nblocks0 : 64);
-        hipLaunchKernelGGL(k_wmf_iter, dim3(nblocks), dim3(256), 0, s, out, in, img, ipitch, w, h, nnf_pitch, wmf_lut, only_occlusion,
+        hipLaunchKernelGGL(k_wmf_iter, dim3(nblocks, bt.n), dim3(256), 0, s, out, in, img, ipitch, w, h, nnf_pitch, wmf_lut, only_occlusion,
                            (i & 1) ? list1 : list0, counts + i, (i & 1) ? list0 : list1, counts + i + 1,
-                           i > 0 ? changed + i - 1 : nullptr, changed + i);
+                           i > 0 ? changed + i - 1 : nullptr, changed + i, bt.stride);
         int16_t* t = in; in = out; out = t;
     }
     return in;
@@ -274,9 +309,12 @@ int16_t* launch_wmf(int16_t* buf_a, int16_t* buf_b, const uint32_t* img, int ipi
 // ---------------------------------------------------------------------------------------------------
 // refine :297-371: nearest valid pixel in the four directions (left, right, up, down), closest colour.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fill_holes(int16_t* __restrict__ nnf_out, const int16_t* __restrict__ nnf_in,
-                                                    const uint32_t* __restrict__ img, int ipitch, int w, int h, int npitch)
+__global__ __launch_bounds__(256) void k_fill_holes(int16_t* __restrict__ nnf_out_, const int16_t* __restrict__ nnf_in_,
+                                                    const uint32_t* __restrict__ img_, int ipitch, int w, int h, int npitch, size_t pstride)
 {
+    int16_t* __restrict__ nnf_out = pair_ptr(nnf_out_, pstride, blockIdx.z);
+    const int16_t* __restrict__ nnf_in = pair_ptr(nnf_in_, pstride, blockIdx.z);
+    const uint32_t* __restrict__ img = pair_ptr(img_, pstride, blockIdx.z);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
     int cx_ = nnf_in[(y * npitch + x) * 2], cy_ = nnf_in[(y * npitch + x) * 2 + 1];
@@ -307,15 +345,17 @@ __global__ __launch_bounds__(256) void k_fill_holes(int16_t* __restrict__ nnf_ou
     nnf_out[(y * npitch + x) * 2 + 1] = (int16_t)cy_;
 }
 void launch_fill_holes(int16_t* nnf_out, const int16_t* nnf_in, const uint32_t* img, int ipitch, int w, int h, int nnf_pitch,
-                       hipStream_t s)
+                       hipStream_t s, Batch bt)
 {
-    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(k_fill_holes, grid, block, 0, s, nnf_out, nnf_in, img, ipitch, w, h, nnf_pitch);
+    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4, bt.n);
+    hipLaunchKernelGGL(k_fill_holes, grid, block, 0, s, nnf_out, nnf_in, img, ipitch, w, h, nnf_pitch, bt.stride);
 }
 
 // refine :636-655
-__global__ __launch_bounds__(256) void k_nnf2flow(float* __restrict__ flow, int fpitch, const int16_t* __restrict__ nnf, int npitch, int w, int h)
+__global__ __launch_bounds__(256) void k_nnf2flow(float* __restrict__ flow_, int fpitch, const int16_t* __restrict__ nnf_, int npitch, int w, int h, size_t pstride)
 {
+    float* __restrict__ flow = pair_ptr(flow_, pstride, blockIdx.z);
+    const int16_t* __restrict__ nnf = pair_ptr(nnf_, pstride, blockIdx.z);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
     const int dx = nnf[(y * npitch + x) * 2], dy = nnf[(y * npitch + x) * 2 + 1];
@@ -325,10 +365,10 @@ __global__ __launch_bounds__(256) void k_nnf2flow(float* __restrict__ flow, int 
     flow[(y * fpitch + x) * 2] = fx;
     flow[(y * fpitch + x) * 2 + 1] = fy;
 }
-void launch_nnf2flow(float* flow, int flow_pitch, const int16_t* nnf, int nnf_pitch, int w, int h, hipStream_t s)
+void launch_nnf2flow(float* flow, int flow_pitch, const int16_t* nnf, int nnf_pitch, int w, int h, hipStream_t s, Batch bt)
 {
-    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(k_nnf2flow, grid, block, 0, s, flow, flow_pitch, nnf, nnf_pitch, w, h);
+    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4, bt.n);
+    hipLaunchKernelGGL(k_nnf2flow, grid, block, 0, s, flow, flow_pitch, nnf, nnf_pitch, w, h, bt.stride);
 }
 
 }  // namespace eppm

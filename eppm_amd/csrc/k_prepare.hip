@@ -14,13 +14,14 @@ namespace eppm {
 // ---------------------------------------------------------------------------------------------------
 constexpr int GT_W = 32, GT_H = 8, G_MAXR = 6;
 
-// blockIdx.z selects one of two independent images (the two frames of a pair share every launch)
+// blockIdx.z = pair * nimg + image: the (one or two) frames of a pair and all pairs of a batch share every launch
 __global__ __launch_bounds__(256) void k_gauss_rgba(uint32_t* __restrict__ out0, const uint32_t* __restrict__ in0,
                                                     uint32_t* __restrict__ out1, const uint32_t* __restrict__ in1, int pitch,
-                                                    int h, int w, float sigma2, int radius)
+                                                    int h, int w, float sigma2, int radius, int nimg, size_t pstride)
 {
-    uint32_t* __restrict__ out = blockIdx.z ? out1 : out0;
-    const uint32_t* __restrict__ in = blockIdx.z ? in1 : in0;
+    const unsigned pair = blockIdx.z / nimg, im = blockIdx.z % nimg;
+    uint32_t* __restrict__ out = pair_ptr(im ? out1 : out0, pstride, pair);
+    const uint32_t* __restrict__ in = pair_ptr(im ? in1 : in0, pstride, pair);
     __shared__ uint32_t tile[(GT_H + 2 * G_MAXR) * (GT_W + 2 * G_MAXR)];
     __shared__ float wtab[(2 * G_MAXR + 1) * (2 * G_MAXR + 1)];
     const int tw = GT_W + 2 * radius, th = GT_H + 2 * radius;
@@ -56,16 +57,16 @@ __global__ __launch_bounds__(256) void k_gauss_rgba(uint32_t* __restrict__ out0,
     out[y * pitch + x] = r;
 }
 
-void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s)
+void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s, Batch bt)
 {
-    dim3 grid((w + GT_W - 1) / GT_W, (h + GT_H - 1) / GT_H), block(GT_W, GT_H);
-    hipLaunchKernelGGL(k_gauss_rgba, grid, block, 0, s, out, in, out, in, pitch_px, h, w, sigma * sigma * 2, radius);
+    dim3 grid((w + GT_W - 1) / GT_W, (h + GT_H - 1) / GT_H, bt.n), block(GT_W, GT_H);
+    hipLaunchKernelGGL(k_gauss_rgba, grid, block, 0, s, out, in, out, in, pitch_px, h, w, sigma * sigma * 2, radius, 1, bt.stride);
 }
 void launch_gauss_rgba2(uint32_t* out0, const uint32_t* in0, uint32_t* out1, const uint32_t* in1, int pitch_px, int h, int w, float sigma,
-                        int radius, hipStream_t s)
+                        int radius, hipStream_t s, Batch bt)
 {
-    dim3 grid((w + GT_W - 1) / GT_W, (h + GT_H - 1) / GT_H, 2), block(GT_W, GT_H);
-    hipLaunchKernelGGL(k_gauss_rgba, grid, block, 0, s, out0, in0, out1, in1, pitch_px, h, w, sigma * sigma * 2, radius);
+    dim3 grid((w + GT_W - 1) / GT_W, (h + GT_H - 1) / GT_H, 2 * bt.n), block(GT_W, GT_H);
+    hipLaunchKernelGGL(k_gauss_rgba, grid, block, 0, s, out0, in0, out1, in1, pitch_px, h, w, sigma * sigma * 2, radius, 2, bt.stride);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -76,10 +77,12 @@ void launch_gauss_rgba2(uint32_t* out0, const uint32_t* in0, uint32_t* out1, con
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gauss_decimate2(uint32_t* __restrict__ out0, const uint32_t* __restrict__ in0,
                                                          uint32_t* __restrict__ out1, const uint32_t* __restrict__ in1, int out_pitch,
-                                                         int outH, int outW, int pitch, int h, int w, float sigma2, int radius)
+                                                         int outH, int outW, int pitch, int h, int w, float sigma2, int radius, int nimg,
+                                                         size_t pstride)
 {
-    uint32_t* __restrict__ out = blockIdx.z ? out1 : out0;
-    const uint32_t* __restrict__ in = blockIdx.z ? in1 : in0;
+    const unsigned pair = blockIdx.z / nimg, im = blockIdx.z % nimg;
+    uint32_t* __restrict__ out = pair_ptr(im ? out1 : out0, pstride, pair);
+    const uint32_t* __restrict__ in = pair_ptr(im ? in1 : in0, pstride, pair);
     __shared__ uint32_t tile[(2 * GT_H + 2 * G_MAXR) * (2 * GT_W + 2 * G_MAXR)];
     __shared__ float wtab[(2 * G_MAXR + 1) * (2 * G_MAXR + 1)];
     const int tw = 2 * GT_W + 2 * radius, th = 2 * GT_H + 2 * radius;
@@ -126,20 +129,22 @@ bool gauss_decimate2_ok(int outH, int outW, int h, int w, float ratio, int radiu
 }
 // two images per launch (out1/in1 may repeat out0/in0 with nimg = 1)
 void launch_gauss_decimate2(uint32_t* out0, const uint32_t* in0, uint32_t* out1, const uint32_t* in1, int nimg, int out_pitch_px, int outH,
-                            int outW, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s)
+                            int outW, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s, Batch bt)
 {
-    dim3 grid((outW + GT_W - 1) / GT_W, (outH + GT_H - 1) / GT_H, nimg), block(GT_W, GT_H);
+    dim3 grid((outW + GT_W - 1) / GT_W, (outH + GT_H - 1) / GT_H, nimg * bt.n), block(GT_W, GT_H);
     hipLaunchKernelGGL(k_gauss_decimate2, grid, block, 0, s, out0, in0, out1, in1, out_pitch_px, outH, outW, pitch_px, h, w,
-                       sigma * sigma * 2, radius);
+                       sigma * sigma * 2, radius, nimg, bt.stride);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Bilinear resize, uchar4 (.cuh:565-601), as written: fx=(x+1)/ratio-1, trunc, 4 taps, trunc to u8.
 // For ratio 1/2 and 1/4 the weights are exactly 1,0,0,0 (pixel (2x+1,2y+1) / (4x+3,4y+3)).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_resize_rgba(uint32_t* __restrict__ out, int out_pitch, int outH, int outW,
-                                                     const uint32_t* __restrict__ in, int in_pitch, int h, int w, float ratio)
+__global__ __launch_bounds__(256) void k_resize_rgba(uint32_t* __restrict__ out_, int out_pitch, int outH, int outW,
+                                                     const uint32_t* __restrict__ in_, int in_pitch, int h, int w, float ratio, size_t pstride)
 {
+    uint32_t* __restrict__ out = pair_ptr(out_, pstride, blockIdx.z);
+    const uint32_t* __restrict__ in = pair_ptr(in_, pstride, blockIdx.z);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= outW || y >= outH) return;
     const float div_scale = 1.f / ratio;
@@ -164,10 +169,10 @@ __global__ __launch_bounds__(256) void k_resize_rgba(uint32_t* __restrict__ out,
 }
 
 void launch_resize_rgba(uint32_t* out, int out_pitch_px, int outH, int outW, const uint32_t* in, int in_pitch_px, int h, int w,
-                        float ratio, hipStream_t s)
+                        float ratio, hipStream_t s, Batch bt)
 {
-    dim3 block(64, 4), grid((outW + 63) / 64, (outH + 3) / 4);
-    hipLaunchKernelGGL(k_resize_rgba, grid, block, 0, s, out, out_pitch_px, outH, outW, in, in_pitch_px, h, w, ratio);
+    dim3 block(64, 4), grid((outW + 63) / 64, (outH + 3) / 4, bt.n);
+    hipLaunchKernelGGL(k_resize_rgba, grid, block, 0, s, out, out_pitch_px, outH, outW, in, in_pitch_px, h, w, ratio, bt.stride);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -211,11 +216,15 @@ __global__ __launch_bounds__(256) void k_census(uint8_t* __restrict__ census, in
 }
 
 // every level of both frames in ONE launch: a block finds its job by scanning the (at most 16) block offsets
-__global__ __launch_bounds__(256) void k_census_batch(CensusBatch B)
+// blockIdx.y = pair of the batch
+__global__ __launch_bounds__(256) void k_census_batch(CensusBatch B, size_t pstride)
 {
     int j = 0;
     while (j + 1 < B.n && (int)blockIdx.x >= B.job[j + 1].first_block) j++;
-    const CensusJob& J = B.job[j];
+    CensusJob J = B.job[j];
+    J.census = pair_ptr(J.census, pstride, blockIdx.y);
+    J.texels = pair_ptr_opt(J.texels, pstride, blockIdx.y);
+    J.img = pair_ptr(J.img, pstride, blockIdx.y);
     const int b = blockIdx.x - J.first_block, bw = (J.w + 63) / 64;
     __shared__ float lum[6][66];
     const int x0 = (b % bw) * 64, y0 = (b / bw) * 4;
@@ -242,14 +251,14 @@ __global__ __launch_bounds__(256) void k_census_batch(CensusBatch B)
     J.census[y * J.cpitch + x] = (uint8_t)r;
     if (J.texels) ((float4*)J.texels)[y * J.tpitch + x] = make_texel(J.img[y * J.ipitch + x], r);
 }
-void launch_census_batch(CensusBatch& B, hipStream_t s)
+void launch_census_batch(CensusBatch& B, hipStream_t s, Batch bt)
 {
     int blocks = 0;
     for (int j = 0; j < B.n; j++) {
         B.job[j].first_block = blocks;
         blocks += ((B.job[j].w + 63) / 64) * ((B.job[j].h + 3) / 4);
     }
-    hipLaunchKernelGGL(k_census_batch, dim3(blocks), dim3(64, 4), 0, s, B);
+    hipLaunchKernelGGL(k_census_batch, dim3(blocks, bt.n), dim3(64, 4), 0, s, B, bt.stride);
 }
 
 void launch_census(uint8_t* census, int cpitch, void* texels, int tpitch, const uint32_t* img, int ipitch, int w, int h, hipStream_t s)
@@ -273,17 +282,19 @@ void launch_pack(void* texels, int tpitch, const uint32_t* img, int ipitch, cons
 }
 
 // RGB (3 B/px, tightly packed rows) -> RGBA with alpha 0 (bao_rgb2rgba, basic/bao_basic_cuda.h:258-267)
-__global__ __launch_bounds__(256) void k_rgb_to_rgba(uint32_t* __restrict__ out, int pitch, const uint8_t* __restrict__ rgb, int h, int w)
+__global__ __launch_bounds__(256) void k_rgb_to_rgba(uint32_t* __restrict__ out_, int pitch, const uint8_t* __restrict__ rgb_, int h, int w, size_t pstride)
 {
+    uint32_t* __restrict__ out = pair_ptr(out_, pstride, blockIdx.z);
+    const uint8_t* __restrict__ rgb = pair_ptr(rgb_, pstride, blockIdx.z);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const uint8_t* p = rgb + ((size_t)y * w + x) * 3;
     out[y * pitch + x] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
 }
-void launch_rgb_to_rgba(uint32_t* out, int pitch_px, const uint8_t* rgb, int h, int w, hipStream_t s)
+void launch_rgb_to_rgba(uint32_t* out, int pitch_px, const uint8_t* rgb, int h, int w, hipStream_t s, Batch bt)
 {
-    dim3 block(256), grid((w + 255) / 256, h);
-    hipLaunchKernelGGL(k_rgb_to_rgba, grid, block, 0, s, out, pitch_px, rgb, h, w);
+    dim3 block(256), grid((w + 255) / 256, h, bt.n);
+    hipLaunchKernelGGL(k_rgb_to_rgba, grid, block, 0, s, out, pitch_px, rgb, h, w, bt.stride);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -76,10 +76,33 @@ int  eppm_set_stream(eppm_ctx* ctx, void* hip_stream);
 /* Host images: h rows of w RGB triplets, row_stride bytes apart (>= 3*w).  RGB->RGBA, H2D,
  * prefilter, pyramid, census (set_data + _prepare_data, driver .cpp:159-168,212-215). */
 int  eppm_set_images(eppm_ctx* ctx, const uint8_t* rgb1, const uint8_t* rgb2, size_t row_stride);
-/* Device-resident RGBA (uchar4, alpha ignored/0) images, pitch in bytes: runs prepare only.  Asynchronous on the context's
- * stream: the planes must be complete before the call (or produced on that stream) and must stay valid and unmodified
- * until eppm_synchronize() or a later synchronous call on this context returns -- the prefilter may read them in place. */
+/* Device-resident RGBA (uchar4, alpha ignored/0) images, pitch in bytes: copies them into the context (device to device,
+ * in the order of the context's stream) and runs prepare.  The planes must be complete before the call (or produced on
+ * that stream) and stay valid until that copy has run (eppm_synchronize, or any later synchronous call on this
+ * context); they are never read in place by a kernel. */
 int  eppm_set_images_device(eppm_ctx* ctx, const void* d_rgba1, const void* d_rgba2, size_t pitch);
+
+/* ----------------------------------------------------------------------------------------
+ * batches of independent pairs of one size (BASELINE.json configs[2]: many pairs per GPU; SURVEY 7 "batch dimension
+ * in the kernel grid").  A batch context holds `npairs` pairs; every kernel launch of the path covers all active pairs
+ * (the quarter-resolution stages of ONE pair cannot fill 256 CUs, those of 8 pairs can).  Each pair's result is
+ * bit-identical to what a single-pair context computes for it.  The single-pair calls above and below work on a batch
+ * context too (they address pair 0 and make it the only active pair).
+ * -------------------------------------------------------------------------------------- */
+int  eppm_create_batch(eppm_ctx** out, int h, int w, int device, const eppm_params* params, int npairs);
+int  eppm_batch_size(const eppm_ctx* ctx);
+/* set_data for pairs 0..n-1 (n <= npairs; n becomes the number of active pairs): arrays of n host RGB image pointers */
+int  eppm_batch_set_images(eppm_ctx* ctx, int n, const uint8_t* const* rgb1, const uint8_t* const* rgb2, size_t row_stride);
+/* the same from device-resident RGBA planes (arrays of n device pointers); copied in stream order, never read in place */
+int  eppm_batch_set_images_device(eppm_ctx* ctx, int n, const void* const* d_rgba1, const void* const* d_rgba2, size_t pitch);
+/* compute_flow for every active pair.  u[k], v[k]: h*w floats of pair k (host); synchronous */
+int  eppm_batch_compute(eppm_ctx* ctx, float* const* u, float* const* v);
+/* asynchronous; d_flows: NULL, or n device pointers (NULL entries allowed) receiving the interleaved float2 flows */
+int  eppm_batch_compute_device(eppm_ctx* ctx, void* const* d_flows);
+/* second half of eppm_compute_begin for every active pair */
+int  eppm_batch_compute_end(eppm_ctx* ctx, float* const* u, float* const* v);
+/* eppm_get_plane of pair `pair` */
+int  eppm_batch_get_plane(eppm_ctx* ctx, int pair, const char* name, int level, void* dst, size_t dst_bytes);
 
 /* compute_flow (driver .cpp:217-306).  u, v: h*w floats each (host). Synchronous. */
 int  eppm_compute(eppm_ctx* ctx, float* u, float* v);

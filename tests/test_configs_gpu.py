@@ -83,6 +83,59 @@ def test_config3_eight_pairs_per_gpu_pipelined():
         _check_flow(n, out[i][0], out[i][1], man[n], crops)
 
 
+def test_config3_eight_pairs_in_one_batch_context():
+    """BASELINE configs[2] through the batch context (eppm_create_batch): the same 8 pairs share EVERY kernel launch
+    (blockIdx.z / .y = pair); each flow == the oracle's, i.e. == what a single-pair context computes.  Then a partial batch
+    (3 active pairs of 8) and the single-pair entry points on the same batch context."""
+    import eppm_amd
+    man = _manifest()
+    crops = np.load(os.path.join(GOLDEN, "large_crops.npz"))
+    names = [f"sintel_{s}" for s in range(1234, 1242)]
+    pairs = [_pair(man[n]) for n in names]
+    B = eppm_amd.EPPMBatch(436, 1024, 8)
+    B.set_data(pairs)
+    out = B.compute_flow()
+    assert len(out) == 8
+    for n, (u, v) in zip(names, out):
+        _check_flow(n, u, v, man[n], crops)
+    nnf3 = B.plane(3, "nnf1", 2)
+    B.set_data([pairs[5], pairs[0], pairs[3]])          # partial batch, other order
+    out = B.compute_flow()
+    assert len(out) == 3
+    for n, (u, v) in zip([names[5], names[0], names[3]], out):
+        _check_flow(n, u, v, man[n], crops)
+    assert np.array_equal(B.plane(2, "nnf1", 2).view(np.uint8), nnf3.view(np.uint8))      # pair 3's NNF, now in slot 2
+    B.close()
+
+
+def test_batch_context_small_sizes_against_oracle(crop, crop_stages):
+    """Batch contexts at small sizes and other parameters (split level-1 refine at n = 1 but not at n = 5, R = 17, jump flood,
+    odd sizes): every pair of the batch == the live oracle."""
+    import eppm_amd
+    from oracle import oracle as O
+    a, b = crop
+    st = crop_stages
+    B = eppm_amd.EPPMBatch(120, 160, 5)
+    B.set_data([(a, b), (b, a), (a, a), (a, b), (b, a)])
+    out = B.compute_flow()
+    want = {0: (st["u"], st["v"]), 3: (st["u"], st["v"])}
+    want[1] = want[4] = O.compute_flow(b, a)
+    want[2] = O.compute_flow(a, a)
+    for k, (u, v) in enumerate(out):
+        assert np.array_equal(u.view(np.uint32), want[k][0].view(np.uint32)) and np.array_equal(v.view(np.uint32), want[k][1].view(np.uint32)), k
+    B.close()
+    for params, (h, w) in ((dict(patch_r=17), (96, 128)), (dict(propagation=1, num_iter=3), (77, 101)), (dict(patch_r=5, levels=2, propagation=2, num_iter=2), (64, 90))):
+        pa, pb = a[:h, :w].copy(), b[:h, :w].copy()
+        B = eppm_amd.EPPMBatch(h, w, 3, params=eppm_amd.Params(**params))
+        B.set_data([(pa, pb), (pb, pa), (pa, pb)])
+        out = B.compute_flow()
+        w0 = O.compute_flow(pa, pb, O.default_params(**params))
+        w1 = O.compute_flow(pb, pa, O.default_params(**params))
+        for k, wk in enumerate((w0, w1, w0)):
+            assert np.array_equal(out[k][0].view(np.uint32), wk[0].view(np.uint32)) and np.array_equal(out[k][1].view(np.uint32), wk[1].view(np.uint32)), (params, k)
+        B.close()
+
+
 def test_config4_hd_pair_bit_exact():
     """BASELINE configs[3]: 1920x1080, full pyramid + bilateral refine (the non-split tiled refine with many tiles, XCD tile
     order, two-pixel-per-lane smoothing)."""

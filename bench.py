@@ -152,7 +152,8 @@ def worker(args):
         rgba = np.zeros((h, w, 4), np.uint8)
         rgba[..., :3] = img
         return torch.from_numpy(rgba).to(dev)
-    NP = max(S, 0 if args.no_extras else args.pairs_per_gpu)
+    NC3 = 0 if args.no_extras else args.pairs_per_gpu        # pairs of the config-3 leg
+    NP = max(S * max(1, args.batch), NC3)
     host_pairs, inputs = [], []
     for j in range(NP):
         img1, img2, gu_j, gv_j = synth.make_pair(h, w, seed=1234 + rank * NP + j)
@@ -201,7 +202,7 @@ def worker(args):
         for e in engs + bengs:
             e.synchronize()
 
-    run_steps(0, max(args.warmup, S * NB), NP)
+    run_steps(0, max(args.warmup, S * NB), S * NB)
     sync_all()
 
     # ---- the timed region: exactly --steps steps; events only around the dominant kernel, from a pool ----
@@ -210,7 +211,7 @@ def worker(args):
     teng.stage_times(clear=True)
     barrier()
     t0 = time.perf_counter()
-    run_steps(0, args.steps, S * NB if NB > 1 else S)
+    run_steps(0, args.steps, S * NB)
     sync_all()
     barrier()
     dt = all_max(time.perf_counter() - t0)
@@ -237,12 +238,12 @@ def worker(args):
                 barrier()
                 ts.append(all_max(time.perf_counter() - t0))
             return float(np.median(ts))
-        dt3 = timed(lambda: [step(i, NP) for i in range(NP)])
-        cb = eppm_amd.EPPMBatch(h, w, NP, device=local_rank, params=params)
+        dt3 = timed(lambda: [step(i, NC3) for i in range(NC3)])
+        cb = eppm_amd.EPPMBatch(h, w, NC3, device=local_rank, params=params)
 
         def batch_pass():
-            cb.set_data_device([x[0].data_ptr() for x in inputs[:NP]], [x[1].data_ptr() for x in inputs[:NP]], pitch)
-            cb.compute_flow_device([x[2].data_ptr() for x in inputs[:NP]])
+            cb.set_data_device([x[0].data_ptr() for x in inputs[:NC3]], [x[1].data_ptr() for x in inputs[:NC3]], pitch)
+            cb.compute_flow_device([x[2].data_ptr() for x in inputs[:NC3]])
             cb.synchronize()
         dt3b = timed(batch_pass)
         cb.enable_stage_timing(1)
@@ -250,12 +251,12 @@ def worker(args):
         batch_pass()
         bst = {}
         for name, ms in cb.stage_times(clear=True):
-            bst[name] = bst.get(name, 0.0) + ms / NP
+            bst[name] = bst.get(name, 0.0) + ms / NC3
         cb.close()
-        extras["config3"] = {"workload": f"{NP} distinct {w}x{h} pairs per GPU x {world} GPU(s), one pass (median of 3)",
-                             "pairs": NP * world, "unit": "Mflow-vectors/s",
-                             "streams": {"value": world * NP * w * h / dt3 / 1e6, "ms_per_pair": dt3 / NP * 1e3, "contexts_in_flight": S},
-                             "batch": {"value": world * NP * w * h / dt3b / 1e6, "ms_per_pair": dt3b / NP * 1e3, "pairs_per_launch": NP,
+        extras["config3"] = {"workload": f"{NC3} distinct {w}x{h} pairs per GPU x {world} GPU(s), one pass (median of 3)",
+                             "pairs": NC3 * world, "unit": "Mflow-vectors/s",
+                             "streams": {"value": world * NC3 * w * h / dt3 / 1e6, "ms_per_pair": dt3 / NC3 * 1e3, "contexts_in_flight": S},
+                             "batch": {"value": world * NC3 * w * h / dt3b / 1e6, "ms_per_pair": dt3b / NC3 * 1e3, "pairs_per_launch": NC3,
                                        "stage_ms_per_pair": bst}}
 
     if rank == 0:

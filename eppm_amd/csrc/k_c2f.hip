@@ -170,9 +170,13 @@ template <int R> __device__ __forceinline__ const C2fTables<R>& c2f_tables();
 template <> __device__ __forceinline__ const C2fTables<9>& c2f_tables<9>() { return c2f_tab9; }
 template <> __device__ __forceinline__ const C2fTables<17>& c2f_tables<17>() { return c2f_tab17; }
 
-template <int R, int PASS, bool RAW = false>
+// WIN: the target texels come from an LDS window of the target image instead of per-lane gathers (k_c2f_refine_win):
+// `s_win` is the window (row stride WW texels, cells pre-clamped to the image at load), `wbase` this lane's byte offset of
+// candidate (cx, ccy-1) with zero sample offset.  The sample's offset is a scalar, the three row candidates are WW texels apart.
+template <int R, int PASS, bool RAW = false, bool WIN = false, int WW = 0>
 __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLutT<R + 1>& L, const float4* __restrict__ s_src,
-                                         int TW, int tx, int ty, int cx16, int wmax16, int ccy, const rgbf c1, const rgbf (&c2)[3], float (&run)[3])
+                                         int TW, int tx, int ty, int cx16, int wmax16, int ccy, const rgbf c1, const rgbf (&c2)[3], float (&run)[3],
+                                         const float4* __restrict__ s_win = nullptr, int wbase = 0)
 {
     // candidates (cx, ccy-1), (cx, ccy), (cx, ccy+1): one x offset m, the three y offsets n
     constexpr int S = R + 1;
@@ -184,9 +188,12 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLutT<R + 1>
     for (int ii = 0; ii < S; ii++) {
         // clamped row offsets of the targets: rows ccy-1+dy .. ccy+1+dy (+1 more where dy steps inside the row)
         unsigned Rr[4];
-        const int rb = ccy - 1 + ((PASS == 0) ? 2 * ii - R : T.rowdy[TP][ii]);
+        const int rdy = (PASS == 0) ? 2 * ii - R : T.rowdy[TP][ii];
+        const int rb = ccy - 1 + rdy;
+        if (!WIN) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) Rr[k] = __umul24((unsigned)iclamp(rb + k, 0, P.h - 1), pitch16);
+            for (int k = 0; k < 4; k++) Rr[k] = __umul24((unsigned)iclamp(rb + k, 0, P.h - 1), pitch16);
+        }
 EPPM_UNROLL(EPPM_C2F_UNROLL)
         for (int jj = 0; jj < S; jj++) {
             const float4 q1 = s_src[(ty + 2 * ii) * TW + tx + 2 * jj];
@@ -197,14 +204,22 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
             const float gsp = L.gsp[ii * S + jj];
             // byte offsets of the three targets: clamped column (in bytes throughout: no shift) + clamped rows
             const int dx16 = (PASS == 0) ? (2 * jj - R) * 16 : T.off[TP][ii * S + jj].dx16;
-            const unsigned Xb = (unsigned)med3i(cx16 + dx16, 0, wmax16);
             float4 q2[3];                                 // the three gathers are issued back to back, then consumed
+            if (WIN) {
+                // one vector add (lane base + scalar sample offset), three LDS reads with immediate row offsets
+                const int soff = (rdy + ((PASS != 0) ? T.off[TP][ii * S + jj].up : 0)) * (WW * 16) + dx16;
+                const char* wp = reinterpret_cast<const char*>(s_win) + (wbase + soff);
+#pragma unroll
+                for (int n = 0; n < 3; n++) q2[n] = *reinterpret_cast<const float4*>(wp + n * (WW * 16));
+            } else {
+            const unsigned Xb = (unsigned)med3i(cx16 + dx16, 0, wmax16);
             if (PASS != 0 && T.off[TP][ii * S + jj].up) {         // wave-uniform; compiles to three selects on a scalar condition
 #pragma unroll
                 for (int n = 0; n < 3; n++) q2[n] = texel_at(P.pk2, Rr[n + 1] + Xb);
             } else {
 #pragma unroll
                 for (int n = 0; n < 3; n++) q2[n] = texel_at(P.pk2, Rr[n] + Xb);
+            }
             }
 #pragma unroll
             for (int n = 0; n < 3; n++) {
@@ -334,6 +349,165 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
     flow[(y * P.w + x) * 2 + 1] = (float)(by - y);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The same tile kernel with the TARGET texels staged in LDS as well.  After up-sampling, the flow of a 16x16 tile is
+// nearly constant, so the 3 600 target texels a pixel reads (9 candidates x 4 passes x 100 samples) and those of its
+// 255 neighbours fall into one small window of the target image: (tile + flow spread) + candidate +-1 + the sample and
+// warp offsets.  A workgroup whose candidate centres span at most WIN_SPAN_X x WIN_SPAN_Y pixels loads that window once
+// (rows clamped to the image at load, like the source tile) and every target fetch becomes ONE vector add and an LDS read
+// with an immediate offset -- no clamps, no per-candidate address arithmetic, no gather round trips through the texture
+// path (the 16-byte gathers kept its addresser ~58 % busy).  A tile whose flow is not coherent enough (motion boundaries)
+// takes the per-access path of k_c2f_refine_tiled inside the same workgroup.  Same arithmetic, same order: bit-identical.
+// ---------------------------------------------------------------------------------------------------
+template <int R>
+struct C2fWinGeom {
+    // extreme sample offsets over all four passes (pass 0: the plain +-R grid)
+    static constexpr int xlo() { int v = -R; const auto T = make_c2f_tables<R>(); for (int p = 0; p < 3; p++) for (int t = 0; t < (R + 1) * (R + 1); t++) v = T.off[p][t].dx16 / 16 < v ? T.off[p][t].dx16 / 16 : v; return v; }
+    static constexpr int xhi() { int v = R; const auto T = make_c2f_tables<R>(); for (int p = 0; p < 3; p++) for (int t = 0; t < (R + 1) * (R + 1); t++) v = T.off[p][t].dx16 / 16 > v ? T.off[p][t].dx16 / 16 : v; return v; }
+    static constexpr int ylo() { int v = -R; const auto T = make_c2f_tables<R>(); for (int p = 0; p < 3; p++) for (int i = 0; i <= R; i++) v = T.rowdy[p][i] < v ? T.rowdy[p][i] : v; return v; }
+    static constexpr int yhi() { int v = R; const auto T = make_c2f_tables<R>(); for (int p = 0; p < 3; p++) for (int i = 0; i <= R; i++) v = T.rowdy[p][i] + 1 > v ? T.rowdy[p][i] + 1 : v; return v; }
+};
+#ifndef EPPM_C2F_WIN_H
+#define EPPM_C2F_WIN_H 50
+#endif
+#ifndef EPPM_C2F_WIN_WAVES
+#define EPPM_C2F_WIN_WAVES 4
+#endif
+
+// Workgroup = 512 threads = the 256 pixels of the tile x 2 pass groups (threadIdx.z): group 0 evaluates the 4th and 3rd affine
+// pass of every candidate, group 1 the 2nd and the 1st; both read the same source tile and target window, so the LDS footprint
+// (78 KB) is shared by twice the waves: two workgroups per CU = 4 waves per SIMD (the one-group form ran at 2 and was 10 %
+// slower than the gather kernel).  Group 0 hands its nested minimum of passes 4 and 3 to group 1 through LDS (the source
+// tile's storage, after a barrier), which finishes __min(c1,__min(c2,.)) and the candidate loop.
+template <int R>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EPPM_C2F_WIN_WAVES, EPPM_C2F_WIN_WAVES)))
+void k_c2f_refine_win(PlanesH Ph, float* __restrict__ flow_, const float* __restrict__ lut, size_t pstride)
+{
+    constexpr int TWU = kBlock + 2 * R;
+    constexpr int TW = (TWU + 15) / 16 * 16;
+    constexpr int WW = 64, WH = EPPM_C2F_WIN_H;                      // window: row stride 64 texels = 1 KiB (conflict-free ds_read_b128)
+    constexpr int XLO = C2fWinGeom<R>::xlo(), XHI = C2fWinGeom<R>::xhi(), YLO = C2fWinGeom<R>::ylo(), YHI = C2fWinGeom<R>::yhi();
+    constexpr int SPAN_X = WW - 2 - (XHI - XLO), SPAN_Y = WH - 2 - (YHI - YLO);   // admissible spread of the candidate centres (max - min)
+    static_assert(SPAN_X >= kBlock && SPAN_Y >= kBlock, "window too small for a constant-flow tile");
+    static_assert(TWU * TW * 16 >= 9 * 256 * 4, "the exchange buffer aliases the source tile");
+    __shared__ PatchLutT<R + 1> L;
+    __shared__ float4 s_src[TWU * TW];
+    __shared__ float4 s_win[WH * WW];
+    __shared__ int s_mm[4];                                          // min ccx, max ccx, min ccy, max ccy of the tile's pixels
+    float* __restrict__ flow = pair_ptr(flow_, pstride, blockIdx.y);
+    const int ptid = threadIdx.y * kBlock + threadIdx.x;            // pixel of the tile
+    const int grp = threadIdx.z;                                     // pass group
+    const int tid = grp * 256 + ptid;
+    load_patch_lut(L, lut, R, tid, 512);
+    const Planes P = to_dev(Ph, pstride, blockIdx.y);
+    const int tiles_x = (P.w + kBlock - 1) / kBlock, tiles = tiles_x * ((P.h + kBlock - 1) / kBlock);
+    const int per_xcd = (tiles + 7) / 8;
+    const int slot = blockIdx.x >> 3;
+    const int tile = (blockIdx.x & 7) * per_xcd + slot;              // XCD-aware tile order, as k_c2f_refine_tiled
+    if (slot >= per_xcd || tile >= tiles) return;
+    const int x0 = (tile % tiles_x) * kBlock, y0 = (tile / tiles_x) * kBlock;
+    if (tid == 0) { s_mm[0] = 0x7fffffff; s_mm[1] = -0x7fffffff; s_mm[2] = 0x7fffffff; s_mm[3] = -0x7fffffff; }
+    for (int t = tid; t < TWU * TWU; t += 512) {
+        const int ry = t / TWU, rx = t % TWU;
+        const int sy = iclamp(y0 + ry - R, 0, P.h - 1), sx = iclamp(x0 + rx - R, 0, P.w - 1);
+        s_src[ry * TW + rx] = P.pk1[(unsigned)(sy * P.pitch + sx)];
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    const bool inimg = (x < P.w && y < P.h);
+    float fvx = 0.0f, fvy = 0.0f;
+    if (inimg) { fvx = flow[(y * P.w + x) * 2]; fvy = flow[(y * P.w + x) * 2 + 1]; }
+    const bool known = inimg && !(fvx > kUnknownFlowThresh || fvy > kUnknownFlowThresh);
+    const int ccx = (int)(int16_t)(f2short(fvx) + x);
+    const int ccy = (int)(int16_t)(f2short(fvy) + y);
+    if (known && grp == 0) {
+        atomicMin(&s_mm[0], ccx); atomicMax(&s_mm[1], ccx);
+        atomicMin(&s_mm[2], ccy); atomicMax(&s_mm[3], ccy);
+    }
+    __syncthreads();
+    const int mnx = s_mm[0], mxx = s_mm[1], mny = s_mm[2], mxy = s_mm[3];
+    const bool coherent = (mxx - mnx <= SPAN_X) && (mxy - mny <= SPAN_Y);       // workgroup-uniform (no known pixel: mxx < mnx, nobody reads)
+    const int wx0 = mnx - 1 + XLO, wy0 = mny - 1 + YLO;
+    if (coherent && mxx >= mnx) {
+        for (int t = tid; t < WH * WW; t += 512) {
+            const int sy = iclamp(wy0 + t / WW, 0, P.h - 1), sx = iclamp(wx0 + t % WW, 0, P.w - 1);
+            s_win[t] = P.pk2[(unsigned)(sy * P.pitch + sx)];
+        }
+    }
+    __syncthreads();
+    float res[9];                                   // group 0: __min(c3,c4) per candidate; group 1: c2 then the final cost
+    float res1[9];                                  // group 1: c1 (raw)
+    if (known) {
+        const rgbf c1 = texel_rgb(s_src[(threadIdx.y + R) * TW + threadIdx.x + R]);
+#pragma unroll
+        for (int m = 0; m < 3; m++) {               // x offset outer, as the reference's candidate loop (kernel.cu:2028)
+            const int cx = (int)(int16_t)(ccx + m - 1);
+            float run[3] = {0.0f, 0.0f, 0.0f}, raw[3] = {0.0f, 0.0f, 0.0f};
+            if (!(cx < 0 || cx >= P.w)) {            // else: every candidate of this column is skipped (:2030)
+                rgbf c2[3];
+                const int cx16 = cx << 4, wmax16 = (P.w - 1) << 4;
+                if (coherent) {
+                    const int wbase = ((ccy - 1 - wy0) * WW + (cx - wx0)) * 16;
+#pragma unroll
+                    for (int n = 0; n < 3; n++) c2[n] = texel_rgb(*reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_win) + wbase + n * (WW * 16)));
+                    if (grp == 0) {
+                        c2f_pass<R, 3, false, true, WW>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run, s_win, wbase);
+                        c2f_pass<R, 2, false, true, WW>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run, s_win, wbase);
+                    } else {
+                        c2f_pass<R, 1, true, true, WW>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run, s_win, wbase);
+                        c2f_pass<R, 0, true, true, WW>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, raw, s_win, wbase);
+                    }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 3; n++) c2[n] = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, cx, ccy + n - 1));
+                    if (grp == 0) {
+                        c2f_pass<R, 3>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+                        c2f_pass<R, 2>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+                    } else {
+                        c2f_pass<R, 1, true>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+                        c2f_pass<R, 0, true>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, raw);
+                    }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 3; n++) { res[m * 3 + n] = run[n]; res1[m * 3 + n] = raw[n]; }
+        }
+    }
+    __syncthreads();                                // every read of the source tile is done: its storage carries the exchange
+    float* __restrict__ xch = reinterpret_cast<float*>(s_src);
+    if (grp == 0 && known) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) xch[k * 256 + ptid] = res[k];
+    }
+    __syncthreads();
+    if (grp != 1 || !inimg) return;
+    if (!known) {
+        flow[(y * P.w + x) * 2] = 0.0f;
+        flow[(y * P.w + x) * 2 + 1] = 0.0f;
+        return;
+    }
+    int bx = ccx, by = ccy;
+    float min_cost = 999999;
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        const int cx = (int)(int16_t)(ccx + m - 1);
+        if (cx < 0 || cx >= P.w) continue;
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+            const int cy = (int)(int16_t)(ccy + n - 1);
+            if (cy < 0 || cy >= P.h) continue;
+            const float m34 = xch[(m * 3 + n) * 256 + ptid];
+            const float c_2 = res[m * 3 + n], c_1 = res1[m * 3 + n];
+            const float m234 = (c_2 < m34) ? c_2 : m34;                // __min(cost1,__min(cost2,__min(cost3,cost4))), kernel.cu:512
+            const float cv = (c_1 < m234) ? c_1 : m234;
+            if (cv < min_cost) { min_cost = cv; bx = cx; by = cy; }
+        }
+    }
+    flow[(y * P.w + x) * 2] = (float)(bx - x);
+    flow[(y * P.w + x) * 2 + 1] = (float)(by - y);
+}
+
 // the candidate loop of kernel.cu:2028-2040 over the 9 costs written by the split launch
 template <int SPLIT>
 __global__ __launch_bounds__(256) void k_c2f_select(float* __restrict__ flow_, const float* __restrict__ cost9_, int w, int h, size_t pstride)
@@ -406,7 +580,11 @@ void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, f
         }
         return;
     }
-    if (R == 9 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<9, 0>), grid1, block, 0, s, P, flow, lut, (float*)nullptr, bt.stride);
+#ifndef EPPM_C2F_WINDOW
+#define EPPM_C2F_WINDOW 1
+#endif
+    if (EPPM_C2F_WINDOW && R == 9 && table_ok) hipLaunchKernelGGL((k_c2f_refine_win<9>), grid1, dim3(kBlock, kBlock, 2), 0, s, P, flow, lut, bt.stride);
+    else if (R == 9 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<9, 0>), grid1, block, 0, s, P, flow, lut, (float*)nullptr, bt.stride);
     else if (R == 17 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<17, 0>), grid1, block, 0, s, P, flow, lut, (float*)nullptr, bt.stride);
     else hipLaunchKernelGGL(k_c2f_refine, grid, block, 0, s, P, flow, lut, R, bt.stride);
 }

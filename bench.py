@@ -4,9 +4,11 @@
 A step = one pass of the hot path (set_data's device part: prefilter + pyramid + census, then
 compute_flow: PatchMatch fwd/bwd at 1/4 res, L-R check, outlier removal, weighted median, hole fill,
 two coarse-to-fine levels, final smoothing) over ONE synthetic 1024x436 pair whose RGBA planes are
-already resident in HBM.  Steps are issued round robin over --inflight contexts (default 3), each on its
-own HIP stream, so the quarter-resolution stages of one pair (latency bound: too few pixels to fill 256
-CUs) overlap the full-resolution stages of another; every step's work runs inside the timed region.
+already resident in HBM.  Consecutive steps are issued in groups of --batch (default 4) to batch contexts
+(eppm_create_batch: every kernel launch covers the group's pairs -- the quarter-resolution stages of ONE pair
+are too few pixels to fill 256 CUs), round robin over --inflight such contexts (default 3), each on its own HIP
+stream, so that the tail of one launch overlaps the next context's work; every step's work runs inside the timed
+region; `--batch 1` issues one context per step.
 
 N > 1 (`--gpus N`): one process per GPU, each rank its own pairs (independent pairs, no data-path
 collective: SURVEY 8e); value = pairs of all ranks * W*H / max-over-ranks time.  When RANK is not in the
@@ -53,7 +55,7 @@ def parse_args(known_only=False):
     ap.add_argument("--patch-r", type=int, default=9)
     ap.add_argument("--inflight", type=int, default=3,
                     help="pairs in flight per GPU: steps are issued round robin over this many contexts, each on its own HIP stream")
-    ap.add_argument("--batch", type=int, default=1,
+    ap.add_argument("--batch", type=int, default=4,
                     help="pairs per launch sequence: > 1 groups consecutive steps into batch contexts (eppm_create_batch) whose every kernel launch "
                          "covers the whole group; --inflight such contexts are kept in flight")
     ap.add_argument("--pairs-per-gpu", type=int, default=8, help="size of the config-3 leg (distinct pairs per GPU)")

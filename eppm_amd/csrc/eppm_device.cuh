@@ -9,16 +9,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
+#include <type_traits>
 
 #include "eppm_internal.h"
 
 namespace eppm {
 
 // ---- batches of pairs: pair k's plane = pair 0's pointer + k * stride bytes (eppm_internal.h: Batch) ----------
+// (byte arithmetic on the pointer itself: a round trip through an integer would lose the global address space the
+// compiler infers for kernel arguments and turn every access into a flat_load / flat_store)
 template <class T>
 __device__ __forceinline__ T* pair_ptr(T* p, size_t stride, unsigned pair)
 {
-    return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + stride * pair);
+    using Byte = typename std::conditional<std::is_const<T>::value, const char, char>::type;
+    return reinterpret_cast<T*>(reinterpret_cast<Byte*>(p) + stride * pair);
 }
 template <class T>
 __device__ __forceinline__ T* pair_ptr_opt(T* p, size_t stride, unsigned pair)     // NULL stays NULL

@@ -295,6 +295,7 @@ def worker(args):
             out.update(single_stream_legs(args, eng, inputs, pitch, pmc, alg_bytes1))
             out["host_boundary"] = host_boundary(args, engs, host_pairs)
             out["cold_ms"] = cold_window(args, local_rank, params, host_pairs[0])
+            out["approx_exp_variant"] = approx_variant_leg(args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h)
         print(json.dumps(out), flush=True)
@@ -380,6 +381,26 @@ def cold_window(args, device, params, pair):
         ts.append((time.perf_counter() - t) * 1e3)
         e.close()
     return float(np.median(ts))
+
+
+def approx_variant_leg(args):
+    """The opt-in libeppm_hip_approx.so (v_exp_f32 instead of the shared exp formula; NOT bit-identical, never `value`): its
+    throughput on the same workload and its EPE against the oracle on the bundled pair, each in a child process."""
+    if os.environ.get("EPPM_HIP_VARIANT"):
+        return None
+    env = dict(os.environ, EPPM_HIP_VARIANT="approx")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        cmd = [sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", str(min(args.steps, 60)), "--warmup", str(args.warmup),
+               "--batch", str(args.batch), "--inflight", str(args.inflight), "--width", str(args.width), "--height", str(args.height), "--patch-r", str(args.patch_r)]
+        b = json.loads([ln for ln in subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600).stdout.splitlines() if ln.startswith("{")][-1])
+        e = json.loads([ln for ln in subprocess.run([sys.executable, os.path.join(ROOT, "tools", "approx_exp_epe.py")], env=env, capture_output=True,
+                                                    text=True, timeout=600).stdout.splitlines() if ln.startswith("{")][-1])
+        return {"value": b["value"], "unit": b["unit"], "ms_per_step": b["ms_per_step"], "epe_vs_oracle_px": e["epe_mean_px"], "epe_pair": e["pair"],
+                "tolerance_px": 1e-3, "library": e["library"], "note": "opt-in build, not bit-identical to the oracle; the headline value is the exact library"}
+    except Exception as ex:                      # a reported extra, never a reason to lose the line
+        return {"error": str(ex)[:200]}
 
 
 def cpu_baseline(w, h):

@@ -6,15 +6,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 
 
-def lib_path():
-    return os.path.join(_HERE, "lib", "libeppm_hip.so")
+def lib_path(variant=None):
+    """Default library, or the opt-in approx-exp build (variant="approx", or EPPM_HIP_VARIANT=approx in the environment)."""
+    variant = variant if variant is not None else os.environ.get("EPPM_HIP_VARIANT", "")
+    if variant not in ("", "exact", "approx"):
+        raise ValueError(f"unknown library variant {variant!r}")
+    return os.path.join(_HERE, "lib", "libeppm_hip_approx.so" if variant == "approx" else "libeppm_hip.so")
 
 
 def _stale():
-    out = lib_path()
-    if not os.path.exists(out):
+    outs = [lib_path(""), lib_path("approx")]
+    if not all(os.path.exists(o) for o in outs):
         return True
-    t = os.path.getmtime(out)
+    t = min(os.path.getmtime(o) for o in outs)
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("eppm.h", "bao_flow_patchmatch_multiscale_cuda.h")]
     srcs.append(os.path.join(_HERE, "..", "tools", "runeppm.cpp"))
@@ -24,13 +28,13 @@ def _stale():
 def build(force=False, verbose=False):
     """Compile every HIP kernel + the C ABI into eppm_amd/lib/libeppm_hip.so (and the runeppm CLI)."""
     if not force and not _stale():
-        return lib_path()
+        return lib_path("")
     if not os.path.exists("/opt/rocm/bin/hipcc"):
-        if os.path.exists(lib_path()):
-            return lib_path()
+        if os.path.exists(lib_path("")):
+            return lib_path("")
         raise RuntimeError("hipcc not found and no prebuilt libeppm_hip.so")
     cmd = ["make", "-C", _CSRC, "-j", str(min(8, os.cpu_count() or 1))]
     if force:
         subprocess.check_call(["make", "-C", _CSRC, "clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
-    return lib_path()
+    return lib_path("")

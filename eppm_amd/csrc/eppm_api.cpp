@@ -49,7 +49,11 @@ static int set_err(int code, const char* fmt, ...)
     } while (0)
 
 extern "C" const char* eppm_last_error(void) { return g_err; }
-extern "C" const char* eppm_version(void) { return "eppm-hip 0.1 (gfx950)"; }
+#ifdef EPPM_APPROX_EXP
+extern "C" const char* eppm_version(void) { return "eppm-hip 0.2 (gfx950, approx-exp: v_exp_f32, not bit-identical to the oracle)"; }
+#else
+extern "C" const char* eppm_version(void) { return "eppm-hip 0.2 (gfx950)"; }
+#endif
 
 extern "C" int eppm_default_params(eppm_params* p)
 {

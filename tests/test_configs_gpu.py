@@ -262,3 +262,22 @@ def test_bench_two_ranks_share_one_gpu():
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["roofline"]["frac"] > 0 and d["roofline"]["avg_launch_ms"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# opt-in approx-exp library (libeppm_hip_approx.so: v_exp_f32 instead of the shared exp formula)
+# ---------------------------------------------------------------------------------------------------
+def test_approx_exp_variant_within_tolerance():
+    """NOT bit-identical by design; BASELINE.json's tolerance for the flow on the bundled pair is 1e-3 px EPE (mean end-point
+    error against the oracle's flow): the variant must stay inside it, and must say what it is."""
+    env = dict(os.environ, EPPM_HIP_VARIANT="approx")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "approx_exp_epe.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "approx-exp" in d["library"], d
+    assert 0 < d["epe_mean_px"] <= 1e-3, d          # > 0: the variant really is a different arithmetic
+    env = dict(os.environ)
+    env.pop("EPPM_HIP_VARIANT", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "approx_exp_epe.py")], env=env, capture_output=True, text=True, timeout=600)
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "approx" not in d["library"] and d["epe_mean_px"] == 0.0 and d["pixels_differing"] == 0.0, d

@@ -109,6 +109,28 @@ def pmc_constants(w, h, patch_r):
     return None
 
 
+def pmc_levels(pmc, nb):
+    """(level-1, level-0) per-pair PMC records of the dominant kernel for launches of nb pairs, or None."""
+    if not pmc:
+        return None
+    pp = pmc["per_pair"]
+    if nb == 1:
+        return pp.get("refine_split4_L1"), pp.get("refine_win_L0")
+    if nb == 4:
+        return pp.get("refine_win_L1_batch4"), pp.get("refine_win_L0_batch4")
+    return None
+
+
+def pmc_traffic(pmc, nb, pairs_per_launch):
+    """HBM-side bytes per launch of the dominant kernel (mean of its level-1 and level-0 launches): 2 x FETCH_SIZE (gfx950
+    tallies the 128-B requests of 16-B-per-lane loads at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, from separate
+    --pmc passes (profiles/pmc_constants.json)."""
+    lv = pmc_levels(pmc, nb)
+    if not lv or not all(lv):
+        return None
+    return float(sum((2 * r["fetch_size_kb"] + r["write_size_kb"]) * 1024 for r in lv) / 2 * pairs_per_launch)
+
+
 def worker(args):
     import numpy as np
     rank = int(os.environ.get("RANK", "0"))
@@ -283,11 +305,12 @@ def worker(args):
                                    f"default defs.h parameters; {world} rank(s), independent pairs",
                        "pairs_per_step_per_gpu": 1, "pairs_in_flight_per_gpu": S * NB, "pairs_per_launch": NB, "contexts_in_flight": S,
                        "width": w, "height": h},
-            "roofline": {"bound": "hbm", "kernel": "k_c2f_refine_tiled (mean of its level-1 and level-0 launches, timed region, all streams busy)",
+            "roofline": {"bound": "hbm", "kernel": "k_c2f_refine_win (candidate refine; mean of its level-1 and level-0 launches over the timed region, all streams busy)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc["traffic_bytes_per_launch"] if (pmc and NB == 1) else None,
+                         "traffic": pmc_traffic(pmc, NB, float(np.mean(groups))),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
-                         "note": "the kernel is VALU-issue bound (3 600 patch samples x ~49 instructions per pixel against 26 bytes): see valu_roofline"},
+                         "pairs_per_launch": float(np.mean(groups)),
+                         "note": "the kernel is VALU-issue bound (3 600 patch samples x ~47 instructions per pixel against 26 bytes): see valu_roofline"},
             "epe_vs_synthetic_gt": epe_gt,
         }
         out.update(extras)
@@ -331,9 +354,10 @@ def single_stream_legs(args, eng, inputs, pitch, pmc, alg_bytes):
     out = {"latency_ms_per_pair": float(np.median(lat)), "stage_ms": stage_ms}
     dom1 = (stage_ms["c2f_refine_L0"] + stage_ms["c2f_refine_L1"]) / 2
     out["roofline_single_stream"] = {"achieved": alg_bytes / (dom1 * 1e-3) / 1e9, "unit": "GB/s", "avg_launch_ms": dom1}
-    if pmc:
-        v = pmc["valu_insts_per_launch"]
-        out["valu_roofline"] = {"bound": "valu", "kernel": "k_c2f_refine_tiled, single stream", "wave64_valu_insts_per_launch": v,
+    lv = pmc_levels(pmc, 1)
+    if lv and all(lv):
+        v = (lv[0]["valu_insts"] + lv[1]["valu_insts"]) / 2
+        out["valu_roofline"] = {"bound": "valu", "kernel": "k_c2f_refine_win (level 0) / k_c2f_refine_tiled<9,4> (level 1), one pair per launch, single stream", "wave64_valu_insts_per_launch": v,
                                 "achieved_insts_per_s": v / (dom1 * 1e-3), "peak_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
                                 "frac": v / (dom1 * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S, "avg_launch_ms": dom1, "source": pmc.get("source")}
     else:

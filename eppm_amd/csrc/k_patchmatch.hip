@@ -144,8 +144,13 @@ __device__ __forceinline__ float dpp_prev_lane(float v)
 }
 
 // LPC = lanes per chain (16, 32 or 64)
+#ifdef EPPM_SWEEP_WAVES
+#define EPPM_SWEEP_OCC __attribute__((amdgpu_waves_per_eu(EPPM_SWEEP_WAVES, EPPM_SWEEP_WAVES)))
+#else
+#define EPPM_SWEEP_OCC
+#endif
 template <int R, int LPC, bool IS_ROW, bool REVERSE>
-__global__ __launch_bounds__(256) void k_pm_sweep(PmBatch B, const float* __restrict__ lut, int L_, int nseg, int nseg_pad)
+__global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, const float* __restrict__ lut, int L_, int nseg, int nseg_pad)
 {
     constexpr int S = R + 1, NS = S * S, CH = (NS + LPC - 1) / LPC, CPB = 256 / LPC;
     __shared__ PatchLut L;
@@ -355,7 +360,10 @@ bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int
         // quarter-resolution level of a 1024x436 pair: 1.4) the chip is latency bound and 32 lanes per chain shorten
         // the dependent step (PatchMatch 1.78 -> 1.61 ms, no change in throughput with pairs in flight)
         const int chains = lines * ((nseg + 1) & ~1) * b.n * b.npairs;
-        if (chains * EPPM_LPC9 / 64 < 2 * 1024) launch_sweep_r<9, 2 * EPPM_LPC9>(b, lut, seg_len, dir, nseg, lines, s);
+#ifndef EPPM_LPC_SWITCH_WAVES
+#define EPPM_LPC_SWITCH_WAVES (2 * 1024)
+#endif
+        if (chains * EPPM_LPC9 / 64 < EPPM_LPC_SWITCH_WAVES) launch_sweep_r<9, 2 * EPPM_LPC9>(b, lut, seg_len, dir, nseg, lines, s);
         else launch_sweep_r<9, EPPM_LPC9>(b, lut, seg_len, dir, nseg, lines, s);
         return true;
     }

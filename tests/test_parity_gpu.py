@@ -173,6 +173,42 @@ def test_c2f(S, O, crop_stages):
     eq(S.c2f_refine(fl, P1), O.c2f_refine(fl, st["img1_L1"], st["img2_L1"], st["cen1_L1"], st["cen2_L1"]), "refine with unknown flow")
 
 
+def test_c2f_refine_window_and_fallback_paths(S, O, crop_stages):
+    """k_c2f_refine_win stages the target window of a tile in LDS when the tile's candidate centres are coherent and falls back
+    to per-access gathers otherwise.  Flows that exercise both inside one launch: constant, tiles at the exact admissible
+    spread (33 x 25) and one past it, per-pixel random jumps, vectors pointing far outside the image (window rows and columns
+    clamped at load), and unknown vectors mixed in."""
+    st = crop_stages
+    i1, i2, c1, c2 = st["img1_L0"], st["img2_L0"], st["cen1_L0"], st["cen2_L0"]
+    P0 = S.PlaneSet(i1, i2, c1, c2)
+    h, w = i1.shape
+    rng = np.random.default_rng(21)
+
+    def run(fx, fy, what):
+        f = np.zeros((h, w), O.float2)
+        f["x"], f["y"] = fx.astype(np.float32), fy.astype(np.float32)
+        eq(S.c2f_refine(f, P0), O.c2f_refine(f, i1, i2, c1, c2), what)
+
+    z = np.zeros((h, w))
+    run(z + 3.7, z - 2.2, "constant flow (coherent everywhere)")
+    fx, fy = z.copy(), z.copy()
+    fx[:, 8::16] = 17.0            # one column per tile shifted: centre spread = 15 + 17 = 32 <= 33 (coherent) ...
+    fy[8::16, :] = 9.0             # ... rows: 15 + 9 = 24 <= 25
+    run(fx, fy, "spread just inside the window")
+    fx[:, 8::16] = 19.0            # 15 + 19 = 34 > 33: those tiles take the fallback
+    fy[8::16, :] = 11.0
+    run(fx, fy, "spread just outside the window")
+    run(rng.integers(-40, 41, (h, w)), rng.integers(-40, 41, (h, w)), "random jumps (incoherent)")
+    run(z - 300.0, z + 250.0, "targets far outside the image")
+    fx, fy = rng.normal(0, 1.5, (h, w)) + 5, rng.normal(0, 1.5, (h, w)) - 4
+    m = rng.random((h, w)) < 0.1
+    fx[m] = 1e10
+    fy[m] = 1e10
+    fx[:16, :16] = 1e10            # a tile without any known pixel
+    fy[:16, :16] = 1e10
+    run(fx, fy, "noisy flow with unknown vectors")
+
+
 def test_end_to_end_crop(crop, crop_stages):
     import eppm_amd
     e = eppm_amd.EPPM()

@@ -19,11 +19,12 @@ if kt:
         g = str(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))
         dur[(name, g)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 ctrs = sorted({c for v in agg.values() for c in v})
-print("kernel,grid,calls,avg_us," + ",".join(ctrs))
+w = csv.writer(sys.stdout, lineterminator="\n")
+w.writerow(["kernel", "grid", "calls", "avg_us"] + ctrs)
 for key in sorted(agg, key=lambda k: -sum(dur.get(k, [0]))):
     if flt and flt not in key[0]:
         continue
     v = agg[key]
     n = len(next(iter(v.values())))
     du = dur.get(key, [0])
-    print(f"{key[0]},{key[1]},{n},{sum(du)/max(1,len(du)):.1f}," + ",".join(f"{sum(v[c])/len(v[c]):.4g}" if c in v else "" for c in ctrs))
+    w.writerow([key[0], key[1], n, f"{sum(du)/max(1,len(du)):.1f}"] + [f"{sum(v[c])/len(v[c]):.4g}" if c in v else "" for c in ctrs])

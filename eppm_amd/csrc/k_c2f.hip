@@ -371,9 +371,78 @@ struct C2fWinGeom {
 #ifndef EPPM_C2F_WIN_H
 #define EPPM_C2F_WIN_H 50
 #endif
+#ifndef EPPM_C2F_PASS2
+#define EPPM_C2F_PASS2 1
+#endif
 #ifndef EPPM_C2F_WIN_WAVES
 #define EPPM_C2F_WIN_WAVES 4
 #endif
+
+// Two affine passes of one candidate column evaluated together from the LDS window: the source sample, its range term a^2 and
+// the spatial weight are formed once per sample for the 6 (pass, row candidate) terms; each of the 6 pairs of running sums
+// still adds its terms in the reference's sample order.  outA / outB: raw costs of pass PA / PB for the three row candidates.
+template <int R, int PA, int PB, int WW>
+__device__ __forceinline__ void c2f_pass2_win(const PatchLutT<R + 1>& L, const float4* __restrict__ s_src, int TW, int tx, int ty,
+                                              const rgbf c1, const rgbf (&c2)[3], const float4* __restrict__ s_win, int wbase,
+                                              float (&outA)[3], float (&outB)[3])
+{
+    constexpr int S = R + 1;
+    constexpr int TA = (PA == 0) ? 0 : PA - 1, TB = (PB == 0) ? 0 : PB - 1;
+    const C2fTables<R>& T = c2f_tables<R>();
+    float csA[3] = {0.0f, 0.0f, 0.0f}, wsA[3] = {0.0f, 0.0f, 0.0f}, csB[3] = {0.0f, 0.0f, 0.0f}, wsB[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+    for (int ii = 0; ii < S; ii++) {
+        const int rdyA = (PA == 0) ? 2 * ii - R : T.rowdy[TA][ii];
+        const int rdyB = (PB == 0) ? 2 * ii - R : T.rowdy[TB][ii];
+EPPM_UNROLL(EPPM_C2F_UNROLL)
+        for (int jj = 0; jj < S; jj++) {
+            const float4 q1 = s_src[(ty + 2 * ii) * TW + tx + 2 * jj];
+            const rgbf p1 = texel_rgb(q1);
+            const uint32_t k1 = __float_as_uint(q1.w);
+            float a2 = max_abs_diff(c1, p1);
+            a2 *= a2;
+            const float gsp = L.gsp[ii * S + jj];
+            const int soffA = (rdyA + ((PA != 0) ? T.off[TA][ii * S + jj].up : 0)) * (WW * 16) + ((PA == 0) ? (2 * jj - R) * 16 : T.off[TA][ii * S + jj].dx16);
+            const int soffB = (rdyB + ((PB != 0) ? T.off[TB][ii * S + jj].up : 0)) * (WW * 16) + ((PB == 0) ? (2 * jj - R) * 16 : T.off[TB][ii * S + jj].dx16);
+            const char* wa = reinterpret_cast<const char*>(s_win) + (wbase + soffA);
+            const char* wb = reinterpret_cast<const char*>(s_win) + (wbase + soffB);
+            float4 qa[3], qb[3];
+#pragma unroll
+            for (int n = 0; n < 3; n++) { qa[n] = *reinterpret_cast<const float4*>(wa + n * (WW * 16)); qb[n] = *reinterpret_cast<const float4*>(wb + n * (WW * 16)); }
+#pragma unroll
+            for (int n = 0; n < 3; n++) {
+                {
+                    const rgbf p2 = texel_rgb(qa[n]);
+                    float cost = max_abs_diff(p1, p2);
+                    cost = one_minus_fast_exp(div_ad2(-(cost * cost)));
+                    cost += census_cost(L.cnx, k1, __float_as_uint(qa[n].w));
+                    float temp = max_abs_diff(c2[n], p2);
+                    temp *= temp;
+                    float weight = fast_exp(div_ad2(-(a2 + temp)));
+                    weight *= gsp;
+                    cost *= weight;
+                    csA[n] += cost;
+                    wsA[n] += weight;
+                }
+                {
+                    const rgbf p2 = texel_rgb(qb[n]);
+                    float cost = max_abs_diff(p1, p2);
+                    cost = one_minus_fast_exp(div_ad2(-(cost * cost)));
+                    cost += census_cost(L.cnx, k1, __float_as_uint(qb[n].w));
+                    float temp = max_abs_diff(c2[n], p2);
+                    temp *= temp;
+                    float weight = fast_exp(div_ad2(-(a2 + temp)));
+                    weight *= gsp;
+                    cost *= weight;
+                    csB[n] += cost;
+                    wsB[n] += weight;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 3; n++) { outA[n] = csA[n] / wsA[n]; outB[n] = csB[n] / wsB[n]; }
+}
 
 // Workgroup = 512 threads = the 256 pixels of the tile x 2 pass groups (threadIdx.z): group 0 evaluates the 4th and 3rd affine
 // pass of every candidate, group 1 the 2nd and the 1st; both read the same source tile and target window, so the LDS footprint
@@ -451,6 +520,16 @@ void k_c2f_refine_win(PlanesH Ph, float* __restrict__ flow_, const float* __rest
                     const int wbase = ((ccy - 1 - wy0) * WW + (cx - wx0)) * 16;
 #pragma unroll
                     for (int n = 0; n < 3; n++) c2[n] = texel_rgb(*reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_win) + wbase + n * (WW * 16)));
+#if EPPM_C2F_PASS2
+                    if (grp == 0) {
+                        float c4[3], c3[3];
+                        c2f_pass2_win<R, 3, 2, WW>(L, s_src, TW, threadIdx.x, threadIdx.y, c1, c2, s_win, wbase, c4, c3);
+#pragma unroll
+                        for (int n = 0; n < 3; n++) run[n] = (c3[n] < c4[n]) ? c3[n] : c4[n];       // __min(cost3, cost4)
+                    } else {
+                        c2f_pass2_win<R, 1, 0, WW>(L, s_src, TW, threadIdx.x, threadIdx.y, c1, c2, s_win, wbase, run, raw);
+                    }
+#else
                     if (grp == 0) {
                         c2f_pass<R, 3, false, true, WW>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run, s_win, wbase);
                         c2f_pass<R, 2, false, true, WW>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run, s_win, wbase);
@@ -458,6 +537,7 @@ void k_c2f_refine_win(PlanesH Ph, float* __restrict__ flow_, const float* __rest
                         c2f_pass<R, 1, true, true, WW>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run, s_win, wbase);
                         c2f_pass<R, 0, true, true, WW>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, raw, s_win, wbase);
                     }
+#endif
                 } else {
 #pragma unroll
                     for (int n = 0; n < 3; n++) c2[n] = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, cx, ccy + n - 1));

@@ -343,6 +343,8 @@ def test_cli_options(frames, tmp_path):
     e = eppm_amd.EPPM(params=eppm_amd.Params(levels=2, patch_r=5, num_iter=2, propagation=1, seed=77)); e.init(a, b, 480, 640)
     u, v = e.compute_flow()
     eq(fu, u, "CLI u with options"); eq(fv, v, "CLI v with options")
+    txt = subprocess.check_output([exe, "--size", "320x200", "--pairs", "7", "--batch", "3", "--out", out], text=True)      # batch contexts: 3 + 3 + 1
+    assert "3 pair(s) per launch" in txt and "Mflow-vectors/s" in txt, txt
     txt = subprocess.check_output([exe, "--size", "320x200", "--pairs", "3", "--out", out], text=True)
     m = re.search(r"EPE ([0-9.]+) px", txt)
     assert m and float(m.group(1)) < 0.5, txt

@@ -12,6 +12,8 @@
 //   --propagation M   0 segmented sweeps (live in the reference), 1 jump flood, 2 4-neighbour
 //   --pairs P         process the pair P times in steady state (set_data + compute_flow); throughput is printed
 //   --gpus G          G worker threads, one context per GPU; the P pairs are dealt round-robin (pair i -> GPU i mod G)
+//   --batch B         each worker runs its pairs B at a time through a batch context (eppm_create_batch: every kernel launch
+//                     covers the B pairs); default 1 = the drop-in class, one pair per launch
 //   --out file.flo    output name (same as the third positional argument)
 //   --gt file.flo     print EPE / AAE of the result against a ground-truth .flo (bao_flow_tools.cpp:64-111)
 #include <atomic>
@@ -42,7 +44,7 @@ struct Array3 {       // bao_alloc<T>(n,r,c): one contiguous block reachable thr
 
 struct Options {
     const char *f1 = "frame10.ppm", *f2 = "frame11.ppm", *fo = "flow.flo", *gt = nullptr;
-    int sw = 0, sh = 0, pairs = 1, gpus = 1;
+    int sw = 0, sh = 0, pairs = 1, gpus = 1, batch = 1;
     std::vector<std::pair<std::string, long long>> opts;
 };
 
@@ -76,10 +78,21 @@ static void synth_image(unsigned char* rgb, int h, int w, int ox, int oy, unsign
             }
 }
 
+static bool apply_opt(eppm_params& p, const std::string& name, long long v)
+{
+    if (name == "patch_r") p.patch_r = (int)v;
+    else if (name == "num_iter") p.num_iter = (int)v;
+    else if (name == "seed") p.seed = (unsigned long long)v;
+    else if (name == "propagation") p.propagation = (int)v;
+    else if (name == "levels") p.levels = (int)v;
+    else return false;
+    return true;
+}
+
 static int usage()
 {
     fprintf(stderr, "usage: runeppm [--size WxH] [--seed N] [--levels N] [--patch-r N] [--iters N] [--propagation M]\n"
-                    "               [--pairs P] [--gpus G] [--gt file.flo] [--out file.flo] [img1.ppm img2.ppm [out.flo]]\n");
+                    "               [--pairs P] [--gpus G] [--batch B] [--gt file.flo] [--out file.flo] [img1.ppm img2.ppm [out.flo]]\n");
     return 2;
 }
 
@@ -100,6 +113,7 @@ int main(int argc, char** argv)
         else if (!strcmp(a, "--propagation")) { if (!val(&v)) return usage(); o.opts.push_back({"propagation", v}); }
         else if (!strcmp(a, "--pairs")) { if (!val(&v) || v < 1) return usage(); o.pairs = (int)v; }
         else if (!strcmp(a, "--gpus")) { if (!val(&v) || v < 1) return usage(); o.gpus = (int)v; }
+        else if (!strcmp(a, "--batch")) { if (!val(&v) || v < 1) return usage(); o.batch = (int)v; }
         else if (!strcmp(a, "--gt")) { if (i + 1 >= argc) return usage(); o.gt = argv[++i]; }
         else if (!strcmp(a, "--out")) { if (i + 1 >= argc) return usage(); o.fo = argv[++i]; }
         else if (a[0] == '-' && a[1] == '-') return usage();
@@ -158,6 +172,35 @@ int main(int argc, char** argv)
         auto now = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - epoch).count(); };
         for (int g = 0; g < o.gpus; g++)
             workers.emplace_back([&, g]() {
+                if (o.batch > 1) {       // batch context through the C ABI: B pairs per launch sequence
+                    eppm_params prm;
+                    eppm_default_params(&prm);
+                    for (auto& kv : o.opts) apply_opt(prm, kv.first, kv.second);
+                    eppm_ctx* c = nullptr;
+                    if (eppm_create_batch(&c, h, w, g, &prm, o.batch) != EPPM_OK) { failed[g] = 1; ready++; return; }
+                    std::vector<std::vector<float>> bu(o.batch, std::vector<float>((size_t)h * w)), bv(o.batch, std::vector<float>((size_t)h * w));
+                    std::vector<const uint8_t*> a1(o.batch, img1.store.data()), a2(o.batch, img2.store.data());
+                    std::vector<float*> pu(o.batch), pv(o.batch);
+                    for (int k = 0; k < o.batch; k++) { pu[k] = bu[k].data(); pv[k] = bv[k].data(); }
+                    ready++;
+                    while (ready.load() < o.gpus) std::this_thread::yield();
+                    t_begin[g] = now();
+                    int mine = 0;
+                    for (int p = g; p < o.pairs; p += o.gpus) mine++;
+                    for (int done = 0; done < mine; done += o.batch) {
+                        const int n = (mine - done < o.batch) ? mine - done : o.batch;
+                        if (eppm_batch_set_images(c, n, a1.data(), a2.data(), (size_t)w * 3) != EPPM_OK || eppm_batch_compute(c, pu.data(), pv.data()) != EPPM_OK) {
+                            failed[g] = 1;
+                            eppm_destroy(c);
+                            return;
+                        }
+                        for (int k = 0; k < n; k++)
+                            if (bu[k] != u || bv[k] != v) failed[g] = 2;      // every pair of a batch == the single-pair flow
+                    }
+                    t_end[g] = now();
+                    eppm_destroy(c);
+                    return;
+                }
                 bao_flow_patchmatch_multiscale_cuda e;
                 e.set_device(g);
                 for (auto& kv : o.opts) e.set_option(kv.first.c_str(), kv.second);
@@ -182,8 +225,8 @@ int main(int argc, char** argv)
         const double dt = te - tb;
         for (int g = 0; g < o.gpus; g++)
             if (failed[g]) { fprintf(stderr, "worker %d failed (%s)\n", g, failed[g] == 2 ? "flow differs between runs" : eppm_last_error()); return 1; }
-        printf("GPU: %.3f s (%d x (set_data + compute_flow) on %d GPU(s), init hoisted): %.2f Mflow-vectors/s\n", dt,
-               o.pairs, o.gpus, (double)o.pairs * h * w / dt / 1e6);
+        printf("GPU: %.3f s (%d x (set_data + compute_flow) on %d GPU(s), %d pair(s) per launch, init hoisted): %.2f Mflow-vectors/s\n", dt,
+               o.pairs, o.gpus, o.batch, (double)o.pairs * h * w / dt / 1e6);
     }
 
     if (o.sw > 0) {

@@ -362,3 +362,77 @@ def test_flow_color_close_to_middlebury_cpu_routine():
     d = np.abs(ours - ref)
     assert d.max() <= 1, d.max()
     assert (d.max(axis=1) == 0).mean() > 0.995
+
+
+# ---------------------------------------------------------------- second, independent restatement of the patch costs
+def _np_patch_cost(img1, img2, c1, c2, x1, y1, x2, y2, R, coef):
+    """numpy/float32 restatement of _d_compute_patch_dist (coef None, bao_pmflow_kernel.cu:255-301) and of ONE pass of
+    _d_compute_patch_dist_planefitting (:353-391 with coef = (A, B, C, D) of :319-332), written from the .cu text, not from the
+    C oracle: IEEE float32 elementwise operations, the terms added one by one in the source's loop order.  Only __expf comes
+    from the shared formula (orc_fast_exp), as everywhere."""
+    f32 = np.float32
+    h, w = img1.shape
+    gs, cn = O.pm_luts(R)
+    fexp = O.lib().orc_fast_exp
+
+    def tex(img, x, y):                       # point sampling, clamp addressing, unorm8 -> float (SURVEY A.2)
+        p = img[min(max(int(y), 0), h - 1), min(max(int(x), 0), w - 1)]
+        return f32(p["x"]) / f32(255.0), f32(p["y"]) / f32(255.0), f32(p["z"]) / f32(255.0)
+
+    def cen(c, x, y):
+        return int(c[min(max(int(y), 0), h - 1), min(max(int(x), 0), w - 1)])
+
+    def maxdiff(a, b):
+        return max(max(abs(f32(a[0] - b[0])), abs(f32(a[1] - b[1]))), abs(f32(a[2] - b[2])))
+
+    cp1, cp2 = tex(img1, x1, y1), tex(img2, x2, y2)
+    uu, vv = f32(x2 - x1), f32(y2 - y1)
+    cost_sum, weight_sum = f32(0), f32(0)
+    lam2, sig2 = f32(f32(0.1) * f32(0.1)), f32(f32(0.1) * f32(0.1))
+    for i in range(-R, R + 1, 2):
+        for j in range(-R, R + 1, 2):
+            if coef is None:
+                sx1, sy1, sx2, sy2 = x1 + j, y1 + i, x2 + j, y2 + i
+            else:
+                cx1, cy1 = f32(x1 + j), f32(y1 + i)
+                cx2 = f32(f32(f32(cx1 + uu) + f32(f32(j) * f32(coef[0]))) + f32(f32(i) * f32(coef[1])))
+                cy2 = f32(f32(f32(cy1 + vv) + f32(f32(j) * f32(coef[2]))) + f32(f32(i) * f32(coef[3])))
+                sx1, sy1, sx2, sy2 = np.floor(cx1), np.floor(cy1), np.floor(cx2), np.floor(cy2)
+            p1, p2 = tex(img1, sx1, sy1), tex(img2, sx2, sy2)
+            k = bin(cen(c1, sx1, sy1) ^ cen(c2, sx2, sy2)).count("1")
+            cost = maxdiff(p1, p2)
+            cost = f32(f32(1) - f32(fexp(float(f32(-f32(cost * cost)) / lam2))))
+            cost = f32(cost + cn[k])
+            wgt = maxdiff(cp1, p1)
+            wgt = f32(wgt * wgt)
+            tmp = maxdiff(cp2, p2)
+            tmp = f32(tmp * tmp)
+            wgt = f32(fexp(float(f32(-f32(wgt + tmp)) / sig2)))
+            wgt = f32(wgt * f32(gs[abs(j)] * gs[abs(i)]))
+            cost = f32(cost * wgt)
+            cost_sum = f32(cost_sum + cost)
+            weight_sum = f32(weight_sum + wgt)
+    return f32(cost_sum / weight_sum)
+
+
+def test_patch_costs_against_a_second_restatement(crop_stages):
+    """The C oracle's orc_patch_dist / orc_patch_dist_planefit equal, bit for bit, a second restatement written in numpy from
+    the reference source (pins the oracle's reading of the sampling grid, the affine coordinate arithmetic, floor + clamp,
+    the term order and the nested __min against an independently written one)."""
+    st = crop_stages
+    i1, i2, c1, c2 = st["img1_L1"], st["img2_L1"], st["cen1_L1"], st["cen2_L1"]
+    h, w = i1.shape
+    rng = np.random.default_rng(17)
+    coefs = [(0.177, -0.011, -0.003, 0.301), (0.125, -0.357, 0.009, 0.308), (0.205, 0.370, 0.011, 0.296)]
+    pts = [(0, 0, w, h), (w - 1, h - 1, -3, -2), (5, 7, 5, 7)] + [tuple(int(v) for v in (rng.integers(0, w), rng.integers(0, h), rng.integers(-4, w + 4), rng.integers(-4, h + 4))) for _ in range(12)]
+    for (x1, y1, x2, y2) in pts:
+        for R in (9, 5):
+            want = _np_patch_cost(i1, i2, c1, c2, x1, y1, x2, y2, R, None)
+            got = np.float32(O.patch_dist(i1, i2, c1, c2, x1, y1, x2, y2, patch_r=R))
+            assert got.view(np.uint32) == want.view(np.uint32), ("plain", x1, y1, x2, y2, R, got, want)
+        c = [_np_patch_cost(i1, i2, c1, c2, x1, y1, x2, y2, 9, None)] + [_np_patch_cost(i1, i2, c1, c2, x1, y1, x2, y2, 9, k) for k in coefs]
+        m34 = c[2] if c[2] < c[3] else c[3]                       # __min(cost1,__min(cost2,__min(cost3,cost4))), :512
+        m234 = c[1] if c[1] < m34 else m34
+        want = c[0] if c[0] < m234 else m234
+        got = np.float32(O.patch_dist(i1, i2, c1, c2, x1, y1, x2, y2, patch_r=9, planefit=True))
+        assert got.view(np.uint32) == np.float32(want).view(np.uint32), ("planefit", x1, y1, x2, y2, got, want)

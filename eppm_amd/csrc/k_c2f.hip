@@ -588,6 +588,133 @@ void k_c2f_refine_win(PlanesH Ph, float* __restrict__ flow_, const float* __rest
     flow[(y * P.w + x) * 2 + 1] = (float)(by - y);
 }
 
+// The same for large radii (PATCH_R 17: source tile 50x64 texels = 51 KB, target window 80x72 texels = 92 KB: one workgroup per
+// CU): 1024 threads = 256 pixels x 4 pass groups, one affine pass each, so that the one resident workgroup still gives 4 waves
+// per SIMD.  Groups 1..3 hand their raw pass costs to group 0 through the source tile's storage.
+template <int R>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_c2f_refine_win4(PlanesH Ph, float* __restrict__ flow_, const float* __restrict__ lut, size_t pstride)
+{
+    constexpr int TWU = kBlock + 2 * R;
+    constexpr int TW = (TWU + 15) / 16 * 16;
+    constexpr int XLO = C2fWinGeom<R>::xlo(), XHI = C2fWinGeom<R>::xhi(), YLO = C2fWinGeom<R>::ylo(), YHI = C2fWinGeom<R>::yhi();
+    constexpr int WW = (kBlock + 2 + (XHI - XLO) + 8 + 15) / 16 * 16;            // >= 8 px of admissible flow spread, row stride a multiple of 256 B
+    constexpr int WH = kBlock + 2 + (YHI - YLO) + 7;
+    constexpr int SPAN_X = WW - 2 - (XHI - XLO), SPAN_Y = WH - 2 - (YHI - YLO);
+    static_assert(SPAN_X >= kBlock && SPAN_Y >= kBlock, "window too small for a constant-flow tile");
+    static_assert(TWU * TW * 16 >= 27 * 256 * 4, "the exchange buffer aliases the source tile");
+    static_assert(sizeof(PatchLutT<R + 1>) + (TWU * TW + WH * WW) * 16 + 16 <= 160 * 1024, "LDS budget of one CU");
+    __shared__ PatchLutT<R + 1> L;
+    __shared__ float4 s_src[TWU * TW];
+    __shared__ float4 s_win[WH * WW];
+    __shared__ int s_mm[4];
+    float* __restrict__ flow = pair_ptr(flow_, pstride, blockIdx.y);
+    const int ptid = threadIdx.y * kBlock + threadIdx.x;
+    const int grp = threadIdx.z;                                     // pass group: evaluates pass 3 - grp (0-based: 3 = the 4th pass)
+    const int tid = grp * 256 + ptid;
+    load_patch_lut(L, lut, R, tid, 1024);
+    const Planes P = to_dev(Ph, pstride, blockIdx.y);
+    const int tiles_x = (P.w + kBlock - 1) / kBlock, tiles = tiles_x * ((P.h + kBlock - 1) / kBlock);
+    const int per_xcd = (tiles + 7) / 8;
+    const int slot = blockIdx.x >> 3;
+    const int tile = (blockIdx.x & 7) * per_xcd + slot;
+    if (slot >= per_xcd || tile >= tiles) return;
+    const int x0 = (tile % tiles_x) * kBlock, y0 = (tile / tiles_x) * kBlock;
+    if (tid == 0) { s_mm[0] = 0x7fffffff; s_mm[1] = -0x7fffffff; s_mm[2] = 0x7fffffff; s_mm[3] = -0x7fffffff; }
+    for (int t = tid; t < TWU * TWU; t += 1024) {
+        const int ry = t / TWU, rx = t % TWU;
+        const int sy = iclamp(y0 + ry - R, 0, P.h - 1), sx = iclamp(x0 + rx - R, 0, P.w - 1);
+        s_src[ry * TW + rx] = P.pk1[(unsigned)(sy * P.pitch + sx)];
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    const bool inimg = (x < P.w && y < P.h);
+    float fvx = 0.0f, fvy = 0.0f;
+    if (inimg) { fvx = flow[(y * P.w + x) * 2]; fvy = flow[(y * P.w + x) * 2 + 1]; }
+    const bool known = inimg && !(fvx > kUnknownFlowThresh || fvy > kUnknownFlowThresh);
+    const int ccx = (int)(int16_t)(f2short(fvx) + x);
+    const int ccy = (int)(int16_t)(f2short(fvy) + y);
+    if (known && grp == 0) {
+        atomicMin(&s_mm[0], ccx); atomicMax(&s_mm[1], ccx);
+        atomicMin(&s_mm[2], ccy); atomicMax(&s_mm[3], ccy);
+    }
+    __syncthreads();
+    const int mnx = s_mm[0], mxx = s_mm[1], mny = s_mm[2], mxy = s_mm[3];
+    const bool coherent = (mxx - mnx <= SPAN_X) && (mxy - mny <= SPAN_Y);
+    const int wx0 = mnx - 1 + XLO, wy0 = mny - 1 + YLO;
+    if (coherent && mxx >= mnx) {
+        for (int t = tid; t < WH * WW; t += 1024) {
+            const int sy = iclamp(wy0 + t / WW, 0, P.h - 1), sx = iclamp(wx0 + t % WW, 0, P.w - 1);
+            s_win[t] = P.pk2[(unsigned)(sy * P.pitch + sx)];
+        }
+    }
+    __syncthreads();
+    float res[9];                                   // raw cost of this group's pass for the 9 candidates
+    if (known) {
+        const rgbf c1 = texel_rgb(s_src[(threadIdx.y + R) * TW + threadIdx.x + R]);
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            const int cx = (int)(int16_t)(ccx + m - 1);
+            float run[3] = {0.0f, 0.0f, 0.0f};
+            if (!(cx < 0 || cx >= P.w)) {
+                rgbf c2[3];
+                const int cx16 = cx << 4, wmax16 = (P.w - 1) << 4;
+                if (coherent) {
+                    const int wbase = ((ccy - 1 - wy0) * WW + (cx - wx0)) * 16;
+#pragma unroll
+                    for (int n = 0; n < 3; n++) c2[n] = texel_rgb(*reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_win) + wbase + n * (WW * 16)));
+                    if (grp == 0) c2f_pass<R, 3, true, true, WW>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run, s_win, wbase);
+                    else if (grp == 1) c2f_pass<R, 2, true, true, WW>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run, s_win, wbase);
+                    else if (grp == 2) c2f_pass<R, 1, true, true, WW>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run, s_win, wbase);
+                    else c2f_pass<R, 0, true, true, WW>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run, s_win, wbase);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 3; n++) c2[n] = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, cx, ccy + n - 1));
+                    if (grp == 0) c2f_pass<R, 3, true>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+                    else if (grp == 1) c2f_pass<R, 2, true>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+                    else if (grp == 2) c2f_pass<R, 1, true>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+                    else c2f_pass<R, 0, true>(P, L, s_src, TW, threadIdx.x, threadIdx.y, cx16, wmax16, ccy, c1, c2, run);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 3; n++) res[m * 3 + n] = run[n];
+        }
+    }
+    __syncthreads();                                // every read of the source tile is done: its storage carries the exchange
+    float* __restrict__ xch = reinterpret_cast<float*>(s_src);
+    if (grp != 0 && known) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) xch[((grp - 1) * 9 + k) * 256 + ptid] = res[k];
+    }
+    __syncthreads();
+    if (grp != 0 || !inimg) return;
+    if (!known) {
+        flow[(y * P.w + x) * 2] = 0.0f;
+        flow[(y * P.w + x) * 2 + 1] = 0.0f;
+        return;
+    }
+    int bx = ccx, by = ccy;
+    float min_cost = 999999;
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        const int cx = (int)(int16_t)(ccx + m - 1);
+        if (cx < 0 || cx >= P.w) continue;
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+            const int cy = (int)(int16_t)(ccy + n - 1);
+            if (cy < 0 || cy >= P.h) continue;
+            const int k = m * 3 + n;
+            const float c_4 = res[k], c_3 = xch[k * 256 + ptid], c_2 = xch[(9 + k) * 256 + ptid], c_1 = xch[(18 + k) * 256 + ptid];
+            const float m34 = (c_3 < c_4) ? c_3 : c_4;                // __min(cost1,__min(cost2,__min(cost3,cost4))), kernel.cu:512
+            const float m234 = (c_2 < m34) ? c_2 : m34;
+            const float cv = (c_1 < m234) ? c_1 : m234;
+            if (cv < min_cost) { min_cost = cv; bx = cx; by = cy; }
+        }
+    }
+    flow[(y * P.w + x) * 2] = (float)(bx - x);
+    flow[(y * P.w + x) * 2 + 1] = (float)(by - y);
+}
+
 // the candidate loop of kernel.cu:2028-2040 over the 9 costs written by the split launch
 template <int SPLIT>
 __global__ __launch_bounds__(256) void k_c2f_select(float* __restrict__ flow_, const float* __restrict__ cost9_, int w, int h, size_t pstride)
@@ -665,6 +792,10 @@ void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, f
 #endif
     if (EPPM_C2F_WINDOW && R == 9 && table_ok) hipLaunchKernelGGL((k_c2f_refine_win<9>), grid1, dim3(kBlock, kBlock, 2), 0, s, P, flow, lut, bt.stride);
     else if (R == 9 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<9, 0>), grid1, block, 0, s, P, flow, lut, (float*)nullptr, bt.stride);
+#ifndef EPPM_C2F_WINDOW17
+#define EPPM_C2F_WINDOW17 1
+#endif
+    else if (EPPM_C2F_WINDOW17 && R == 17 && table_ok) hipLaunchKernelGGL((k_c2f_refine_win4<17>), grid1, dim3(kBlock, kBlock, 4), 0, s, P, flow, lut, bt.stride);
     else if (R == 17 && table_ok) hipLaunchKernelGGL((k_c2f_refine_tiled<17, 0>), grid1, block, 0, s, P, flow, lut, (float*)nullptr, bt.stride);
     else hipLaunchKernelGGL(k_c2f_refine, grid, block, 0, s, P, flow, lut, R, bt.stride);
 }

@@ -207,6 +207,18 @@ def test_c2f_refine_window_and_fallback_paths(S, O, crop_stages):
     fx[:16, :16] = 1e10            # a tile without any known pixel
     fy[:16, :16] = 1e10
     run(fx, fy, "noisy flow with unknown vectors")
+    # patch radius 17: k_c2f_refine_win4 (1024-thread workgroups, four pass groups, 80x72-texel window)
+    import eppm_amd
+    p17 = eppm_amd.Params(patch_r=17)
+    S.set_params(p17)
+    try:
+        for fx, fy, what in ((z + 2.0, z - 1.0, "R=17 constant flow"), (rng.integers(-30, 31, (h, w)), rng.integers(-30, 31, (h, w)), "R=17 random jumps"),
+                             (rng.normal(0, 2.5, (h, w)) + 6, rng.normal(0, 2.5, (h, w)) - 3, "R=17 noisy flow")):
+            f = np.zeros((h, w), O.float2)
+            f["x"], f["y"] = fx.astype(np.float32), fy.astype(np.float32)
+            eq(S.c2f_refine(f, P0), O.c2f_refine(f, i1, i2, c1, c2, O.default_params(patch_r=17)), what)
+    finally:
+        S.set_params(None)
 
 
 def test_end_to_end_crop(crop, crop_stages):

@@ -38,3 +38,17 @@ def run_pairs_pipelined(engines, pairs, indices):
         if i is not None:
             out[i] = engines[k].compute_flow_end()
     return out
+
+
+def run_pairs_batched(batch_engine, pairs, indices):
+    """The same through ONE batch engine (eppm_amd.EPPMBatch): the rank's pairs go through the context `npairs` at a time,
+    every kernel launch covering the whole group (the last group may be smaller).  Returns {i: (u, v)}."""
+    out = {}
+    idx = list(indices)
+    n = batch_engine.npairs
+    for g in range(0, len(idx), n):
+        group = idx[g:g + n]
+        batch_engine.set_data([pairs[i] for i in group])
+        for i, uv in zip(group, batch_engine.compute_flow()):
+            out[i] = uv
+    return out

@@ -98,6 +98,12 @@ def test_config3_eight_pairs_in_one_batch_context():
     assert len(out) == 8
     for n, (u, v) in zip(names, out):
         _check_flow(n, u, v, man[n], crops)
+    from eppm_amd import shard
+    again = shard.run_pairs_batched(B, pairs, [6, 1])     # the sharded runner's batched form
+    for i in (6, 1):
+        _check_flow(names[i], again[i][0], again[i][1], man[names[i]], crops)
+    B.set_data(pairs)
+    B.compute_flow()
     nnf3 = B.plane(3, "nnf1", 2)
     B.set_data([pairs[5], pairs[0], pairs[3]])          # partial batch, other order
     out = B.compute_flow()

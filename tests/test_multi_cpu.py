@@ -45,6 +45,37 @@ def test_pipelined_runner_bookkeeping():
         assert all(out[i] == (10 * i, -10 * i) for i in out)
 
 
+def test_batched_runner_bookkeeping():
+    """run_pairs_batched on a fake batch engine: groups of npairs, a smaller last group, every pair's result under its own index."""
+    from eppm_amd.shard import run_pairs_batched
+
+    class FakeBatch:
+        npairs = 4
+
+        def __init__(self):
+            self.cur, self.sizes = None, []
+
+        def set_data(self, pairs):
+            assert 1 <= len(pairs) <= self.npairs
+            self.cur = list(pairs)
+            self.sizes.append(len(pairs))
+
+        def compute_flow(self):
+            return [(a * 10, b * 10) for a, b in self.cur]
+
+    pairs = [(i, -i) for i in range(23)]
+    for world in (1, 2, 8):
+        seen = {}
+        for r in range(world):
+            fb = FakeBatch()
+            mine = pairs_for_rank(len(pairs), r, world)
+            out = run_pairs_batched(fb, pairs, mine)
+            assert sorted(out) == mine and all(out[i] == (10 * i, -10 * i) for i in out)
+            assert fb.sizes == [4] * (len(mine) // 4) + ([len(mine) % 4] if len(mine) % 4 else [])
+            seen.update(out)
+        assert sorted(seen) == list(range(len(pairs)))
+
+
 WORKER = textwrap.dedent("""
     import os, sys, time
     sys.path.insert(0, %r)

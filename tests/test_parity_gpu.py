@@ -483,6 +483,20 @@ def test_error_paths_on_gpu():
     e.set_data(z, z)
     u, v = e.compute_flow()
     assert u.shape == (32, 48) and np.isfinite(u).all()
+    # batch API: argument errors, and an allocation that cannot succeed (4096 slabs of a 4K pair) fails cleanly
+    assert L.eppm_create_batch(C.byref(ctx), 64, 64, 0, None, 0) == 1
+    assert L.eppm_create_batch(C.byref(ctx), 2160, 3840, 0, None, 4096) == 2 and b"hipMalloc" in L.eppm_last_error()
+    B = eppm_amd.EPPMBatch(32, 48, 2)
+    with pytest.raises(eppm_amd.EppmError):
+        B.set_data([(z, z), (z, z), (z, z)])             # 3 pairs into a 2-pair context
+    with pytest.raises(eppm_amd.EppmError):
+        B.compute_flow_device()                           # no images yet
+    B.set_data([(z, z)])
+    out = B.compute_flow()
+    assert len(out) == 1 and np.array_equal(out[0][0].view(np.uint32), u.view(np.uint32))
+    with pytest.raises(eppm_amd.EppmError):
+        B.plane(5, "flow", 0)
+    B.close()
 
 
 def test_contexts_on_host_threads(crop, crop_stages):

@@ -113,7 +113,7 @@ int  eppm_compute_begin(eppm_ctx* ctx);
 int  eppm_compute_end(eppm_ctx* ctx, float* u, float* v);
 /* Optional colour-coded flow of the last eppm_compute* (compute_flow's color_flow argument, driver .cpp:308-314):
  * Middlebury colour wheel on the device flow (basic/bao_basic_cuda.cuh:776-845), h rows of w R,G,B triplets,
- * row_stride bytes apart.  The reference calls it with max_disp (20,20). */
+ * row_stride bytes apart.  The reference calls it with max_disp (20,20).  On a batch context: pair 0. */
 int  eppm_compute_color(eppm_ctx* ctx, uint8_t* rgb, size_t row_stride, float max_disp_x, float max_disp_y);
 /* Same, asynchronous on the context's stream; the interleaved float2 flow stays in HBM.
  * d_flow may be NULL (result kept in the context; fetch with eppm_get_plane("flow",0)). */

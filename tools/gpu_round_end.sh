@@ -10,6 +10,8 @@ python bench.py > gpurun_out/$T/bench_default.json 2> gpurun_out/$T/bench_defaul
 python bench.py --batch 1 --inflight 3 --no-cpu-baseline --no-extras > gpurun_out/$T/bench_streams3.json 2>/dev/null
 python bench.py --width 1920 --height 1080 --steps 24 --warmup 3 --no-cpu-baseline --no-extras --batch 1 --inflight 3 > gpurun_out/$T/bench_hd.json 2>/dev/null
 python bench.py --width 3840 --height 2160 --patch-r 17 --steps 4 --warmup 1 --batch 1 --inflight 1 --no-cpu-baseline --no-extras > gpurun_out/$T/bench_4k_r17.json 2>/dev/null
+# the driver's N > 1 launch form, two ranks sharing this box's one GPU (gloo for the barrier; RCCL refuses two ranks per device)
+EPPM_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 16 --warmup 4 --dist-backend gloo --no-cpu-baseline > gpurun_out/$T/bench_torchrun_2ranks_1gpu.json 2> gpurun_out/$T/bench_torchrun.err; cut -c1-160 gpurun_out/$T/bench_torchrun_2ranks_1gpu.json
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/$T
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_VMEM"

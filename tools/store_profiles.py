@@ -8,7 +8,7 @@ src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 for f in glob.glob(f"{dst}/{tag}_*"):
     os.remove(f)
-for name in ("bench_default.json", "bench_streams3.json", "bench_hd.json", "bench_4k_r17.json", "bench_under_rocprof.json", "gpu_tests.txt"):
+for name in ("bench_default.json", "bench_streams3.json", "bench_hd.json", "bench_4k_r17.json", "bench_under_rocprof.json", "bench_torchrun_2ranks_1gpu.json", "gpu_tests.txt"):
     if os.path.exists(f"{src}/{name}") and os.path.getsize(f"{src}/{name}") > 0:
         shutil.copy(f"{src}/{name}", f"{dst}/{tag}_{name}")
 for d in ("stats_default", "stats_single"):

@@ -75,12 +75,24 @@ bool bao_flow_patchmatch_multiscale_cuda::set_data(unsigned char*** img1, unsign
     if (!m_ctx || !img1 || !img2) return false;
     unsigned char* a = m_stage;
     unsigned char* b = m_stage + (size_t)m_h * m_w * 3;
-    for (int i = 0; i < m_h; i++)
-        for (int j = 0; j < m_w; j++)
-            for (int c = 0; c < 3; c++) {
-                a[((size_t)i * m_w + j) * 3 + c] = img1[i][j][c];
-                b[((size_t)i * m_w + j) * 3 + c] = img2[i][j][c];
-            }
+    // img[i][j] points at pixel (i,j)'s three bytes; bao_alloc lays a row out contiguously (bao_basic.h:146-162), which is
+    // checked per row -- then the row is one memcpy; any other layout goes through the pointers as bao_rgb2rgba does
+    auto gather = [&](unsigned char* dst, unsigned char*** img) {
+        for (int i = 0; i < m_h; i++) {
+            unsigned char** row = img[i];
+            const unsigned char* base = row[0];
+            bool contiguous = true;
+            for (int j = 1; j < m_w; j++)
+                if (row[j] != base + (size_t)3 * j) { contiguous = false; break; }
+            unsigned char* d = dst + (size_t)i * m_w * 3;
+            if (contiguous) memcpy(d, base, (size_t)m_w * 3);
+            else
+                for (int j = 0; j < m_w; j++)
+                    for (int c = 0; c < 3; c++) d[(size_t)j * 3 + c] = row[j][c];
+        }
+    };
+    gather(a, img1);
+    gather(b, img2);
     if (eppm_set_images(m_ctx, a, b, (size_t)m_w * 3) != EPPM_OK) {
         fprintf(stderr, "bao_flow_patchmatch_multiscale_cuda::set_data: %s\n", eppm_last_error());
         return false;
@@ -96,11 +108,10 @@ void bao_flow_patchmatch_multiscale_cuda::compute_flow(float** disp1_x, float** 
         fprintf(stderr, "bao_flow_patchmatch_multiscale_cuda::compute_flow: %s\n", eppm_last_error());
         return;
     }
-    for (int i = 0; i < m_h; i++)
-        for (int j = 0; j < m_w; j++) {
-            disp1_x[i][j] = m_u[(size_t)i * m_w + j];
-            disp1_y[i][j] = m_v[(size_t)i * m_w + j];
-        }
+    for (int i = 0; i < m_h; i++) {                          // disp[i] is a row of w floats (bao_alloc<float>(h,w), bao_basic.h:124-133)
+        memcpy(disp1_x[i], m_u + (size_t)i * m_w, sizeof(float) * m_w);
+        memcpy(disp1_y[i], m_v + (size_t)i * m_w, sizeof(float) * m_w);
+    }
     if (color_flow != NULL) {
         // bao_cuda_convert_flow_to_colorshow(d_colorflow, flow, h, w, 20, 20) on the device flow, D2H, bao_rgba2rgb: driver .cpp:308-314
         unsigned char* rgb = m_stage;          // h*w*3 of the RGB staging buffer

@@ -220,11 +220,12 @@ struct eppm_ctx {
     float* c2f_cost9[kMaxLevels] = {};  // 9 candidates x 4 passes costs per pixel, only for levels whose refine launch is split
     float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
     eppm_pm_rng* rng = nullptr;
+    float* d_uv = nullptr;              // planar u | v of the final flow (host-pointer boundary), in the slab
     uint32_t* d_color = nullptr;        // colour-coded flow (optional output), in the slab
     uint32_t* h_color = nullptr;        // pinned, allocated on first use
     uint8_t* d_rgb = nullptr;           // staging for host RGB input (both frames), in the slab
     uint8_t* h_rgb = nullptr;           // pinned, npairs x both frames
-    float* h_flow = nullptr;            // pinned, npairs x h*w float2
+    float* h_flow = nullptr;            // pinned, npairs x (u plane | v plane)
     bool have_images = false, have_flow = false;
     int timing = 0;                     // 0 off, 1 every stage, 2 only the dominant kernel (the candidate refine)
     std::vector<StageEv> ev;
@@ -339,6 +340,7 @@ static int ctx_alloc(eppm_ctx* c)
     plane((void**)&c->wmf_ws, wmf_workspace_words(c->W[L], c->H[L], c->prm.wmf_iters) * 4);
     plane((void**)&c->d_rgb, (size_t)h * w * 3 * 2);
     plane((void**)&c->d_color, (size_t)h * w * 4);
+    plane((void**)&c->d_uv, (size_t)h * w * 8);
     CHK(rng_create(&c->rng, c->W[L], c->H[L], c->prm, false));
     const size_t rng_bytes = (size_t)c->rng->gx * c->rng->gy * 64 * 6 * 4;
     for (int k = 0; k < 2; k++)
@@ -668,8 +670,9 @@ extern "C" int eppm_compute_begin(eppm_ctx* c)
     if (!c) return set_err(EPPM_ERR_ARG, "eppm_compute_begin: NULL ctx");
     CHK(compute_all(c));
     const size_t n = (size_t)c->h * c->w;
+    launch_split_flow(c->d_uv, c->flow[0], (int)n, c->stream, c->bt());                                                          // driver :302-306, on the device
     for (int k = 0; k < c->n_active; k++)                                                                                         // driver :299
-        HIPCHK(hipMemcpyAsync(c->h_flow + (size_t)k * n * 2, c->of_pair(c->flow[0], k), n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_flow + (size_t)k * n * 2, c->of_pair(c->d_uv, k), n * 8, hipMemcpyDeviceToHost, c->stream));
     c->flow_pending = true;
     return EPPM_OK;
 }
@@ -683,8 +686,9 @@ static int compute_end(eppm_ctx* c, int n_out, float* const* u, float* const* v)
     const size_t n = (size_t)c->h * c->w;
     for (int k = 0; k < n_out; k++) {
         if (!u[k] || !v[k]) continue;
-        const float* f = c->h_flow + (size_t)k * n * 2;
-        for (size_t i = 0; i < n; i++) { u[k][i] = f[2 * i]; v[k][i] = f[2 * i + 1]; }    // driver :302-306
+        const float* f = c->h_flow + (size_t)k * n * 2;          // u plane, then v plane (k_split_flow)
+        memcpy(u[k], f, n * sizeof(float));
+        memcpy(v[k], f + n, n * sizeof(float));
     }
     return EPPM_OK;
 }

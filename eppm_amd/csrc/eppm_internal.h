@@ -112,6 +112,9 @@ void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, f
 void launch_flow_blf(float* out, const float* in, const uint32_t* img, int ipitch, int w, int h, int flow_pitch,
                      const float* blf_lut, hipStream_t s, Batch bt = kOnePair);
 
+// interleaved float2 flow -> planar u | v (2*n floats) on the device: compute_flow's de-interleave, driver :302-306
+void launch_split_flow(float* uv, const float* flow, int n, hipStream_t s, Batch bt = kOnePair);
+
 // ---- flow colour coding (k_color.hip) ----
 // rgba: h*w packed R | G<<8 | B<<16 (alpha 0); flow: h*w float2
 void launch_flow_to_color(uint32_t* rgba, const float* flow, int h, int w, float max_disp_x, float max_disp_y, hipStream_t s, Batch bt = kOnePair);

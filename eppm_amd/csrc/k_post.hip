@@ -371,4 +371,21 @@ void launch_nnf2flow(float* flow, int flow_pitch, const int16_t* nnf, int nnf_pi
     hipLaunchKernelGGL(k_nnf2flow, grid, block, 0, s, flow, flow_pitch, nnf, nnf_pitch, w, h, bt.stride);
 }
 
+// compute_flow's epilogue (driver :302-306) on the device: interleaved float2 flow -> planar u then v (h*w floats each), so
+// that the host only copies two contiguous planes after the D2H instead of de-interleaving 2*h*w floats in a scalar loop
+__global__ __launch_bounds__(256) void k_split_flow(float* __restrict__ uv_, const float2* __restrict__ flow_, int n, size_t pstride)
+{
+    float* __restrict__ uv = pair_ptr(uv_, pstride, blockIdx.y);
+    const float2* __restrict__ flow = pair_ptr(flow_, pstride, blockIdx.y);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 f = flow[i];
+    uv[i] = f.x;
+    uv[n + i] = f.y;
+}
+void launch_split_flow(float* uv, const float* flow, int n, hipStream_t s, Batch bt)
+{
+    hipLaunchKernelGGL(k_split_flow, dim3((n + 255) / 256, bt.n), dim3(256), 0, s, uv, (const float2*)flow, n, bt.stride);
+}
+
 }  // namespace eppm

@@ -207,6 +207,21 @@ def test_c2f_refine_window_and_fallback_paths(S, O, crop_stages):
     fx[:16, :16] = 1e10            # a tile without any known pixel
     fy[:16, :16] = 1e10
     run(fx, fy, "noisy flow with unknown vectors")
+    # ragged sizes (no dimension a multiple of 16, images smaller than a window): tiles cut by the image edge, windows
+    # clamped on every side
+    for (hh, ww) in ((77, 101), (33, 250), (130, 47), (17, 19)):
+        a = np.zeros((hh, ww), O.uchar4)
+        b = np.zeros((hh, ww), O.uchar4)
+        for ch in ("x", "y", "z"):
+            base = rng.integers(0, 256, (hh, ww))
+            a[ch] = base
+            b[ch] = np.roll(base, (2, -3), axis=(0, 1))
+        ca, cb = O.census(a), O.census(b)
+        Pr = S.PlaneSet(a, b, ca, cb)
+        f = np.zeros((hh, ww), O.float2)
+        f["x"] = (rng.normal(0, 2.0, (hh, ww)) - 3).astype(np.float32)
+        f["y"] = (rng.normal(0, 2.0, (hh, ww)) + 2).astype(np.float32)
+        eq(S.c2f_refine(f, Pr), O.c2f_refine(f, a, b, ca, cb), "ragged %dx%d" % (ww, hh))
     # patch radius 17: k_c2f_refine_win4 (1024-thread workgroups, four pass groups, 80x72-texel window)
     import eppm_amd
     p17 = eppm_amd.Params(patch_r=17)

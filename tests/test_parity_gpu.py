@@ -222,6 +222,20 @@ def test_c2f_refine_window_and_fallback_paths(S, O, crop_stages):
         f["x"] = (rng.normal(0, 2.0, (hh, ww)) - 3).astype(np.float32)
         f["y"] = (rng.normal(0, 2.0, (hh, ww)) + 2).astype(np.float32)
         eq(S.c2f_refine(f, Pr), O.c2f_refine(f, a, b, ca, cb), "ragged %dx%d" % (ww, hh))
+    # NaN costs (black source, white target: every range weight underflows to 0, cost = 0/0): the nested __min and the strict <
+    # of the candidate loop must treat them as the reference's expressions do
+    a = np.zeros((64, 96), O.uchar4)
+    b = np.zeros((64, 96), O.uchar4)
+    for ch in ("x", "y", "z"):
+        b[ch] = 255
+    b["x"][20:40, 30:60] = 0          # a patch where some candidates do get finite costs
+    b["y"][20:40, 30:60] = 0
+    b["z"][20:40, 30:60] = 0
+    ca, cb = O.census(a), O.census(b)
+    f = np.zeros((64, 96), O.float2)
+    f["x"] = rng.integers(-2, 3, (64, 96)).astype(np.float32)
+    f["y"] = rng.integers(-2, 3, (64, 96)).astype(np.float32)
+    eq(S.c2f_refine(f, S.PlaneSet(a, b, ca, cb)), O.c2f_refine(f, a, b, ca, cb), "NaN costs")
     # patch radius 17: k_c2f_refine_win4 (1024-thread workgroups, four pass groups, 80x72-texel window)
     import eppm_amd
     p17 = eppm_amd.Params(patch_r=17)

@@ -436,3 +436,246 @@ def test_patch_costs_against_a_second_restatement(crop_stages):
         want = c[0] if c[0] < m234 else m234
         got = np.float32(O.patch_dist(i1, i2, c1, c2, x1, y1, x2, y2, patch_r=9, planefit=True))
         assert got.view(np.uint32) == np.float32(want).view(np.uint32), ("planefit", x1, y1, x2, y2, got, want)
+
+
+# ---------------------------------------------------------------- second restatements of the remaining stages (numpy, from the .cu text)
+def _f32(x):
+    return np.float32(x)
+
+
+def _unorm(p):
+    return _f32(p["x"]) / _f32(255.0), _f32(p["y"]) / _f32(255.0), _f32(p["z"]) / _f32(255.0)
+
+
+def _maxdiff(a, b):
+    return max(max(abs(_f32(b[0] - a[0])), abs(_f32(b[1] - a[1]))), abs(_f32(b[2] - a[2])))
+
+
+def _fexp(x):
+    return _f32(O.lib().orc_fast_exp(float(_f32(x))))
+
+
+def test_second_restatement_prepare_stages(crop_stages):
+    """census (bao_pmflow_census_kernel.cu:39-90), dense Gaussian (.cuh:437-467), uchar4 and float2 bilinear resize
+    (.cuh:565-601, :511-537) restated in numpy on a sub-plane: byte / bit identical to the C oracle."""
+    st = crop_stages
+    img = st["img1_L1"][10:34, 20:52].copy()
+    h, w = img.shape
+    # census: bit k = lum(neighbour k) > lum(centre), clamp addressing, .3R + .6G + .1B evaluated left to right
+    def lum(p):
+        r, g, b = _unorm(p)
+        return _f32(_f32(_f32(_f32(0.3) * r) + _f32(_f32(0.6) * g)) + _f32(_f32(0.1) * b))
+    cen = np.zeros((h, w), np.uint8)
+    offs = [(-1, -1), (0, -1), (1, -1), (-1, 0), (1, 0), (-1, 1), (0, 1), (1, 1)]
+    for y in range(h):
+        for x in range(w):
+            c = lum(img[y, x])
+            v = 0
+            for k, (dx, dy) in enumerate(offs):
+                if lum(img[min(max(y + dy, 0), h - 1), min(max(x + dx, 0), w - 1)]) > c:
+                    v += 1 << k
+            cen[y, x] = v
+    assert np.array_equal(cen, O.census(img))
+    # Gaussian, sigma .5 radius 2 and sigma 1 radius 3: weight = __expf(-(dy^2+dx^2)/(2 sigma^2)), float sums in tap order, truncation
+    for sigma, radius in ((0.5, 2), (1.0, 3)):
+        s2 = _f32(_f32(_f32(sigma) * _f32(sigma)) * _f32(2))
+        out = np.zeros((h, w), O.uchar4)
+        for y in range(h):
+            for x in range(w):
+                val = [_f32(0)] * 4
+                tot = _f32(0)
+                for dy in range(-radius, radius + 1):
+                    for dx in range(-radius, radius + 1):
+                        p = img[max(0, min(h - 1, y + dy)), max(0, min(w - 1, x + dx))]
+                        wgt = _fexp(_f32(-_f32(dy * dy + dx * dx)) / s2)
+                        for k, ch in enumerate("xyzw"):
+                            val[k] = _f32(val[k] + _f32(_f32(p[ch]) * wgt))
+                        tot = _f32(tot + wgt)
+                for k, ch in enumerate("xyzw"):
+                    out[ch][y, x] = int(_f32(val[k] / tot))
+        assert np.array_equal(out.view(np.uint8), O.gauss_filter_rgba(img, sigma, radius).view(np.uint8)), (sigma, radius)
+    # bilinear resizes: fx = (x+1)/ratio - 1, truncation, weights |1-m-dx| |1-n-dy|, m outer n inner
+    def resize(get, put, oh, ow, ih, iw, ratio, nch):
+        div = _f32(_f32(1.0) / _f32(ratio))
+        for y in range(oh):
+            for x in range(ow):
+                fx = _f32(_f32(_f32(x + 1) * div) - _f32(1))
+                fy = _f32(_f32(_f32(y + 1) * div) - _f32(1))
+                xx, yy = int(fx), int(fy)
+                dx = max(min(_f32(fx - _f32(xx)), _f32(1)), _f32(0))
+                dy = max(min(_f32(fy - _f32(yy)), _f32(1)), _f32(0))
+                res = [_f32(0)] * nch
+                for m in (0, 1):
+                    for n in (0, 1):
+                        u, v = max(0, min(iw - 1, xx + m)), max(0, min(ih - 1, yy + n))
+                        s = _f32(abs(_f32(_f32(1 - m) - dx)) * abs(_f32(_f32(1 - n) - dy)))
+                        src = get(v, u)
+                        for k in range(nch):
+                            res[k] = _f32(res[k] + _f32(_f32(src[k]) * s))
+                put(y, x, res)
+    for (oh, ow, ratio) in ((h // 2, w // 2, 0.5), (7, 11, 0.37)):
+        out = np.zeros((oh, ow), O.uchar4)
+        resize(lambda v, u: [img[v, u][c] for c in "xyzw"],
+               lambda y, x, r: [out[c].__setitem__((y, x), int(r[k])) for k, c in enumerate("xyzw")], oh, ow, h, w, ratio, 4)
+        assert np.array_equal(out.view(np.uint8), O.resize_rgba(img, oh, ow, ratio).view(np.uint8)), ratio
+    fl = st["flow_L2"][5:17, 8:26].copy()
+    fl["x"][3, 4] = 1e10                      # unknown vectors are averaged in like any number (SURVEY A.7)
+    fh, fw = fl.shape
+    out = np.zeros((2 * fh, 2 * fw), O.float2)
+    resize(lambda v, u: [fl["x"][v, u], fl["y"][v, u]],
+           lambda y, x, r: (out["x"].__setitem__((y, x), r[0]), out["y"].__setitem__((y, x), r[1])), 2 * fh, 2 * fw, fh, fw, 2.0, 2)
+    assert np.array_equal(out.view(np.uint32), O.resize_flow(fl, 2 * fh, 2 * fw, 2.0).view(np.uint32))
+
+
+def test_second_restatement_level2_post_and_smoothing(crop_stages):
+    """Left-right check, outlier vote, one weighted-median launch, hole filling, NNF->flow (bao_pmflow_refine_kernel.cu:53-76,
+    :149-182, :198-259, :297-371, :636-655) and the joint-bilateral flow smoothing (:756-799), restated in numpy with the
+    oracle's Jacobi order (read the input plane, write the output plane): identical to the C oracle on a sub-plane."""
+    st = crop_stages
+    ys, xs = slice(0, 30), slice(0, 40)
+    img = st["img1_L2"][ys, xs].copy()
+    h, w = img.shape
+    INV = -10000
+    rng = np.random.default_rng(4)
+    # --- left-right check on synthetic NNFs (absolute coordinates inside / outside the sub-plane)
+    n1 = np.zeros((h, w), O.short2)
+    n2 = np.zeros((h, w), O.short2)
+    gx, gy = np.meshgrid(np.arange(w), np.arange(h))
+    n1["x"], n1["y"] = gx + 2, gy + 1                      # a consistent field: 1->2 shifts by (+2,+1), 2->1 by (-2,-1) ...
+    n2["x"], n2["y"] = gx - 2, gy - 1
+    pert = rng.random((h, w)) < 0.08                       # ... with some inconsistent matches and some targets outside the plane
+    n1["x"][pert] += rng.integers(-3, 4, int(pert.sum())).astype(np.int16)
+    n1["y"][pert] += rng.integers(-3, 4, int(pert.sum())).astype(np.int16)
+    c1 = rng.random((h, w)).astype(np.float32)
+    c2 = rng.random((h, w)).astype(np.float32)
+    want, wc = n1.copy(), c1.copy()
+    for y in range(h):
+        for x in range(w):
+            dx, dy = int(n1["x"][y, x]), int(n1["y"][y, x])
+            bad = dy < 0 or dy >= h or dx < 0 or dx >= w
+            if not bad:
+                bad = abs(int(n2["x"][dy, dx]) - x) > 0 or abs(int(n2["y"][dy, dx]) - y) > 0
+            if bad:
+                want["x"][y, x] = want["y"][y, x] = INV
+                wc[y, x] = np.finfo(np.float32).max
+    got = O.left_right_check(n1, c1, n2, c2)
+    assert np.array_equal(got[0].view(np.int16), want.view(np.int16)) and np.array_equal(got[1], wc)
+    assert 0.05 < (want["x"] < 0).mean() < 0.5             # the check rejected some matches and kept most
+    lr = got[0]
+    # --- outlier vote: 13x13, |dflow| <= 2 in both components, self included, < 84 -> invalid
+    want, wc = lr.copy(), got[1].copy()
+    for y in range(h):
+        for x in range(w):
+            cx, cy = int(lr["x"][y, x]), int(lr["y"][y, x])
+            if cx < 0 and cy < 0:
+                continue
+            fx, fy = np.int16(cx - x), np.int16(cy - y)
+            cnt = 0
+            for dy in range(-6, 7):
+                for dx in range(-6, 7):
+                    yy, xx = y + dy, x + dx
+                    if xx < 0 or yy < 0 or xx >= w or yy >= h:
+                        continue
+                    nx, ny = np.int16(int(lr["x"][yy, xx]) - xx), np.int16(int(lr["y"][yy, xx]) - yy)
+                    if abs(int(nx) - int(fx)) <= 2 and abs(int(ny) - int(fy)) <= 2:
+                        cnt += 1
+            if cnt < 84:
+                want["x"][y, x] = want["y"][y, x] = INV
+                wc[y, x] = np.finfo(np.float32).max
+    got = O.outlier_removal(lr, wc * 0 + c1)      # (the cost plane's marks are not compared here)
+    assert np.array_equal(got[0].view(np.int16), want.view(np.int16))
+    assert ((want["x"] < 0) & (lr["x"] >= 0)).sum() > 10 and (want["x"] >= 0).mean() > 0.3      # some votes failed (borders), most of the interior stands
+    holes = got[0].copy()
+    holes["x"][12:17, 14:22] = INV
+    holes["y"][12:17, 14:22] = INV
+    # --- one weighted-median launch, occlusion only
+    g = O.wmf_lut()
+    sig2 = _f32(_f32(0.02) * _f32(0.02))
+    want = holes.copy()
+    for y in range(h):
+        for x in range(w):
+            if holes["x"][y, x] >= 0 and holes["y"][y, x] >= 0:
+                continue
+            centre = _unorm(img[y, x])
+            best, ox, oy = np.finfo(np.float32).max, int(holes["x"][y, x]), int(holes["y"][y, x])
+            taps = []
+            for dy2 in range(-4, 5):
+                for dx2 in range(-4, 5):
+                    yy, xx = y + dy2, x + dx2
+                    if xx < 0 or yy < 0 or xx >= w or yy >= h:
+                        continue
+                    dx_, dy_ = int(holes["x"][yy, xx]), int(holes["y"][yy, xx])
+                    if dx_ < 0 or dy_ < 0:
+                        continue
+                    d = _maxdiff(centre, _unorm(img[yy, xx]))
+                    wgt = _f32(_fexp(_f32(-_f32(d * d)) / sig2) * _f32(g[abs(dx2)] * g[abs(dy2)]))
+                    taps.append((np.int16(dx_ - xx), np.int16(dy_ - yy), wgt))
+            for (cfx, cfy, _) in taps:                # candidates = the same valid taps, row-major
+                cs, ws = _f32(0), _f32(0)
+                for (tfx, tfy, wgt) in taps:
+                    cs = _f32(cs + _f32(wgt * _f32(max(abs(int(cfx) - int(tfx)), abs(int(cfy) - int(tfy))))))
+                    ws = _f32(ws + wgt)
+                if ws > 0 and cs < best:
+                    best, ox, oy = cs, int(np.int16(int(cfx) + x)), int(np.int16(int(cfy) + y))
+            if not (ox < 0 or oy < 0):
+                want["x"][y, x], want["y"][y, x] = ox, oy
+    assert np.array_equal(O.weighted_median(holes, img, 1, True).view(np.int16), want.view(np.int16))
+    assert ((want["x"] >= 0) & (holes["x"] < 0)).sum() > 20                                       # the launch did fill pixels
+    # --- hole filling: nearest valid left, right, up, down; closest colour, strict <
+    want = holes.copy()
+    for y in range(h):
+        for x in range(w):
+            cx, cy = int(holes["x"][y, x]), int(holes["y"][y, x])
+            if cx >= 0 and cy >= 0:
+                continue
+            nd = [(cx, cy)] * 4
+            npos = [(x, y)] * 4
+            for k, rngk in enumerate((range(x - 1, -1, -1), range(x + 1, w), range(y - 1, -1, -1), range(y + 1, h))):
+                for c in rngk:
+                    yy, xx = (y, c) if k < 2 else (c, x)
+                    nd[k] = (int(holes["x"][yy, xx]), int(holes["y"][yy, xx]))
+                    if nd[k][0] >= 0 and nd[k][1] >= 0:
+                        npos[k] = (xx, yy)
+                        break
+            cur = _unorm(img[y, x])
+            bestd, fx, fy = np.finfo(np.float32).max, cx, cy
+            for k in range(4):
+                d = _maxdiff(cur, _unorm(img[npos[k][1], npos[k][0]]))
+                if d < bestd and nd[k][0] >= 0 and nd[k][1] >= 0:
+                    bestd, fx, fy = d, int(np.int16(nd[k][0] - npos[k][0])), int(np.int16(nd[k][1] - npos[k][1]))
+            want["x"][y, x], want["y"][y, x] = np.int16(fx + x), np.int16(fy + y)
+    filled = O.fill_holes(holes, img)
+    assert np.array_equal(filled.view(np.int16), want.view(np.int16))
+    assert ((want["x"] >= 0) & (holes["x"] < 0)).sum() > 20
+    # --- NNF -> flow
+    fl = O.nnf2flow(holes)
+    for y in range(h):
+        for x in range(w):
+            dx, dy = int(holes["x"][y, x]), int(holes["y"][y, x])
+            e = (1e10, 1e10) if (dx <= INV or dy <= INV) else (float(dx - x), float(dy - y))
+            assert (fl["x"][y, x], fl["y"][y, x]) == (np.float32(e[0]), np.float32(e[1]))
+    # --- joint-bilateral smoothing of the flow (21x21, unknown vectors skipped, written only when the weight sum is non-zero)
+    b = O.blf_lut()
+    hh, ww = 14, 18
+    sub = img[:hh, :ww].copy()
+    f = fl[:hh, :ww].copy()
+    want = f.copy()
+    for y in range(hh):
+        for x in range(ww):
+            centre = _unorm(sub[y, x])
+            nx, ny, wsum = _f32(0), _f32(0), _f32(0)
+            for dy in range(-10, 11):
+                for dx in range(-10, 11):
+                    yy, xx = y + dy, x + dx
+                    if xx < 0 or yy < 0 or xx >= ww or yy >= hh:
+                        continue
+                    if f["x"][yy, xx] > 1e9 or f["y"][yy, xx] > 1e9:
+                        continue
+                    d = _maxdiff(centre, _unorm(sub[yy, xx]))
+                    wgt = _f32(_fexp(_f32(-_f32(d * d)) / sig2) * _f32(b[abs(dx)] * b[abs(dy)]))
+                    nx = _f32(nx + _f32(wgt * f["x"][yy, xx]))
+                    ny = _f32(ny + _f32(wgt * f["y"][yy, xx]))
+                    wsum = _f32(wsum + wgt)
+            if wsum != 0:
+                want["x"][y, x], want["y"][y, x] = _f32(nx / wsum), _f32(ny / wsum)
+    assert np.array_equal(O.flow_smoothing(f, sub).view(np.uint32), want.view(np.uint32))

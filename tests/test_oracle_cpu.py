@@ -679,3 +679,150 @@ def test_second_restatement_level2_post_and_smoothing(crop_stages):
             if wsum != 0:
                 want["x"][y, x], want["y"][y, x] = _f32(nx / wsum), _f32(ny / wsum)
     assert np.array_equal(O.flow_smoothing(f, sub).view(np.uint32), want.view(np.uint32))
+
+
+def test_second_restatement_patchmatch_steps(crop_stages):
+    """Random initial NNF, the four segmented sweeps and the random search restated in numpy from bao_pmflow_kernel.cu
+    (:73-109, :1049-1165, :1519-1586) with the order DESIGN.md 3.2 defines (all segments advance in lockstep, seeds read before
+    step 0, the doubly visited forward pixel 10 seen by segment 1 first): NNF, cost and generator positions equal the C
+    oracle's.  Patch costs come from orc_patch_dist, which test_patch_costs_against_a_second_restatement pins."""
+    st = crop_stages
+    i1, i2, c1, c2 = (st[k][:30, :40].copy() for k in ("img1_L2", "img2_L2", "cen1_L2", "cen2_L2"))
+    h, w = i1.shape
+    L = 10
+    seed = 1234
+    gx, gy = (w + 15) // 16, (h + 15) // 16
+
+    def pd(x1, y1, x2, y2):
+        return np.float32(O.patch_dist(i1, i2, c1, c2, int(x1), int(y1), int(x2), int(y2)))
+
+    # ---- random field: thread (0,0) of each block draws r1, r2 per pixel, row-major over the FULL 16x16 block (:90-101)
+    nnf = np.zeros((h, w), O.short2)
+    for by in range(gy):
+        for bx in range(gx):
+            r = O.xorwow_stream(seed, by * gx + bx, 512)
+            for i in range(16):
+                for j in range(16):
+                    x, y = bx * 16 + j, by * 16 + i
+                    if x < w and y < h:
+                        nnf["x"][y, x] = np.int16(int(r[2 * (16 * i + j)]) % (w + 1))
+                        nnf["y"][y, x] = np.int16(int(r[2 * (16 * i + j) + 1]) % (h + 1))
+    onnf, states = O.gen_rand_field(w, h, seed)
+    assert np.array_equal(nnf.view(np.int16), onnf.view(np.int16))
+    cost = O.cost_field(nnf, i1, i2, c1, c2)
+    assert cost[3, 5].view(np.uint32) == pd(5, 3, nnf["x"][3, 5], nnf["y"][3, 5]).view(np.uint32)
+
+    # ---- one sweep in lockstep
+    def sweep(cost, nnf, direction):
+        cost, nnf = cost.copy(), nnf.copy()
+        is_row, rev = direction in (0, 2), direction in (2, 3)
+        length, lines = (w, h) if is_row else (h, w)
+        nseg = (length + L - 1) // L
+        P = lambda line, i: (line, i) if is_row else (i, line)          # (y, x) index of position i on a line
+        for line in range(lines):
+            segs = []
+            for k in range(nseg):
+                if not rev:
+                    start = 0 if k == 0 else k * L - 1
+                    end = min(length - 1, start + L)
+                    walk = list(range(start + 1, end + 1))
+                else:
+                    start = min((k + 1) * L, length - 1)
+                    walk = list(range(start - 1, k * L - 1, -1))
+                y, x = P(line, start)
+                segs.append({"prev": [int(nnf["x"][y, x]), int(nnf["y"][y, x])], "walk": walk})     # seeds: before step 0
+            for s in range(max(len(g["walk"]) for g in segs)):
+                # forward: segment 1's first step precedes segment 0's last one on the shared pixel -- different steps, so the
+                # order of the segments inside one step is immaterial (each step touches distinct pixels)
+                for g in segs:
+                    if s >= len(g["walk"]):
+                        continue
+                    i = g["walk"][s]
+                    y, x = P(line, i)
+                    px, py = g["prev"]
+                    if is_row:
+                        px = max(px - 1, 0) if rev else min(px + 1, w - 1)
+                    else:
+                        py = max(py - 1, 0) if rev else min(py + 1, h - 1)
+                    cv = pd(x, y, px, py)
+                    if cv < cost[y, x]:
+                        nnf["x"][y, x], nnf["y"][y, x], cost[y, x] = px, py, cv
+                        g["prev"] = [px, py]
+                    else:
+                        g["prev"] = [int(nnf["x"][y, x]), int(nnf["y"][y, x])]
+        return cost, nnf
+
+    cc, nn = cost, nnf
+    for direction in range(4):
+        wc, wn = sweep(cc, nn, direction)
+        oc, on = O.seg_propagate_dir(cc, nn, i1, i2, c1, c2, direction)
+        assert np.array_equal(wn.view(np.int16), on.view(np.int16)) and np.array_equal(wc.view(np.uint32), oc.view(np.uint32)), direction
+        assert (wn.view(np.int16) != nn.view(np.int16)).any()            # the sweep changed something
+        cc, nn = wc, wn
+
+    # ---- random search: six guesses from the pre-search best, radii 30,15,7,3,1,1; block stream continues after the 512 init draws
+    wc, wn = cc.copy(), nn.copy()
+    for by in range(gy):
+        for bx in range(gx):
+            r = O.xorwow_stream(seed, by * gx + bx, 6 * 512, skip=512)
+            for ty in range(16):
+                for tx in range(16):
+                    x, y = bx * 16 + tx, by * 16 + ty
+                    if x >= w or y >= h:
+                        continue
+                    bxy = (int(nn["x"][y, x]), int(nn["y"][y, x]))
+                    mag, guesses = 30, []
+                    for k in range(6):
+                        r1 = int(np.int16(np.uint16(int(r[512 * k + 2 * (16 * ty + tx)]) & 0xffff))) & 0xffffffff      # short(rdn) -> unsigned int
+                        r2 = int(np.int16(np.uint16(int(r[512 * k + 2 * (16 * ty + tx) + 1]) & 0xffff))) & 0xffffffff
+                        xmin, xmax = max(bxy[0] - mag, 0), min(bxy[0] + mag + 1, w + 1)
+                        ymin, ymax = max(bxy[1] - mag, 0), min(bxy[1] + mag + 1, h + 1)
+                        gxv = int(np.int16(np.uint16((xmin + r1 % (xmax - xmin)) & 0xffff)))
+                        gyv = int(np.int16(np.uint16((ymin + r2 % (ymax - ymin)) & 0xffff)))
+                        guesses.append((gxv, gyv))
+                        if mag // 2 >= 1:
+                            mag //= 2
+                    best, bc = bxy, wc[y, x]
+                    for g in guesses:
+                        cv = pd(x, y, g[0], g[1])
+                        if cv < bc:
+                            best, bc = g, cv
+                    wn["x"][y, x], wn["y"][y, x], wc[y, x] = best[0], best[1], bc
+    os_, oc, on = O.random_search(states, cc, nn, i1, i2, c1, c2)
+    assert np.array_equal(wn.view(np.int16), on.view(np.int16)) and np.array_equal(wc.view(np.uint32), oc.view(np.uint32))
+    assert (wn.view(np.int16) != nn.view(np.int16)).any()
+    for b in range(gx * gy):                                             # generator positions: 512 + 6*512 draws in
+        assert np.array_equal(os_[b], O.xorwow_state(seed, b, skip=512 + 6 * 512))
+
+
+def test_second_restatement_candidate_refine(crop_stages):
+    """d_bilateral_refine_flow_planefitting (bao_pmflow_kernel.cu:2005-2041) in numpy: truncation of the up-sampled flow toward
+    zero, 3x3 candidates with the x offset as the outer loop, out-of-image candidates skipped, strict <, unknown flow -> (0,0)."""
+    st = crop_stages
+    i1, i2, c1, c2 = (st[k][:22, :28].copy() for k in ("img1_L1", "img2_L1", "cen1_L1", "cen2_L1"))
+    h, w = i1.shape
+    rng = np.random.default_rng(8)
+    f = np.zeros((h, w), O.float2)
+    f["x"] = rng.normal(0, 2.5, (h, w)).astype(np.float32)
+    f["y"] = rng.normal(0, 2.5, (h, w)).astype(np.float32)
+    f["x"][3, 4] = f["y"][3, 4] = 1e10
+    f["x"][0, 0], f["y"][0, 0] = -3.7, -2.2          # candidates outside the image
+    want = f.copy()
+    for y in range(h):
+        for x in range(w):
+            fx, fy = f["x"][y, x], f["y"][y, x]
+            if fx > 1e9 or fy > 1e9:
+                want["x"][y, x] = want["y"][y, x] = 0
+                continue
+            cx1, cy1 = int(fx) + x, int(fy) + y       # short(flow) truncates toward zero
+            best, bc = (cx1, cy1), np.float32(999999)
+            for m in (-1, 0, 1):
+                for n in (-1, 0, 1):
+                    cx, cy = cx1 + m, cy1 + n
+                    if cx < 0 or cy < 0 or cx >= w or cy >= h:
+                        continue
+                    cv = np.float32(O.patch_dist(i1, i2, c1, c2, x, y, cx, cy, planefit=True))
+                    if cv < bc:
+                        best, bc = (cx, cy), cv
+            want["x"][y, x], want["y"][y, x] = best[0] - x, best[1] - y
+    assert np.array_equal(O.c2f_refine(f, i1, i2, c1, c2).view(np.uint32), want.view(np.uint32))

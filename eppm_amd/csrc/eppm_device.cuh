@@ -75,8 +75,13 @@ __device__ __forceinline__ float div_const(float x, float c, float rc)
     return __builtin_fmaf(r, rc, q0);
 }
 static_assert(kPmSigR2 == kLambdaAd2 && kBlfSigR2 == kWmfSigR2, "one helper per distinct constant");
+#ifdef EPPM_APPROX_EXP       // the opt-in tolerance build: the argument of the hardware exp needs no correctly rounded quotient either
+__device__ __forceinline__ float div_ad2(float x) { return x * (1.0f / kLambdaAd2); }
+__device__ __forceinline__ float div_wmf2(float x) { return x * (1.0f / kWmfSigR2); }
+#else
 __device__ __forceinline__ float div_ad2(float x) { return div_const(x, kLambdaAd2, 1.0f / kLambdaAd2); }   // also PM_SIG_R^2
 __device__ __forceinline__ float div_wmf2(float x) { return div_const(x, kWmfSigR2, 1.0f / kWmfSigR2); }    // also POSTPROC_BLF_SIG_R^2
+#endif
 
 // unorm8 -> float exactly as c/255.0f (cudaReadModeNormalizedFloat)
 __device__ __forceinline__ float unorm8(float c) { return div_const(c, 255.0f, 1.0f / 255.0f); }

@@ -20,13 +20,13 @@ def _stale():
         return True
     t = min(os.path.getmtime(o) for o in outs)
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)]
-    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("eppm.h", "bao_flow_patchmatch_multiscale_cuda.h")]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("eppm.h", "bao_flow_patchmatch_multiscale_cuda.h", "bao_basic_cuda.h")]
     srcs.append(os.path.join(_HERE, "..", "tools", "runeppm.cpp"))
     return any(os.path.getmtime(s) > t for s in srcs if os.path.isfile(s))
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP kernel + the C ABI into eppm_amd/lib/libeppm_hip.so (and the runeppm CLI)."""
+    """Compile every HIP kernel + the C ABI into eppm_amd/lib/libeppm_hip.so, the opt-in libeppm_hip_approx.so and the runeppm CLI."""
     if not force and not _stale():
         return lib_path("")
     if not os.path.exists("/opt/rocm/bin/hipcc"):

@@ -230,17 +230,20 @@ def worker(args):
     sync_all()
 
     # ---- the timed region: exactly --steps steps; events only around the dominant kernel, from a pool ----
-    teng = bengs[0] if NB > 1 else eng
-    teng.enable_stage_timing(2)
-    teng.stage_times(clear=True)
+    tengs = bengs if NB > 1 else engs          # every context in flight records its own launches of the dominant kernel
+    for e in tengs:
+        e.enable_stage_timing(2)
+        e.stage_times(clear=True)
     barrier()
     t0 = time.perf_counter()
     run_steps(0, args.steps, S * NB)
     sync_all()
     barrier()
     dt = all_max(time.perf_counter() - t0)
-    dom = teng.stage_times(clear=True)
-    teng.enable_stage_timing(0)
+    dom = []
+    for e in tengs:
+        dom += e.stage_times(clear=True)
+        e.enable_stage_timing(0)
 
     # sanity: the flow is finite and close to the synthetic ground truth (not a parity check)
     flow = d_flow.cpu().numpy()
@@ -293,7 +296,7 @@ def worker(args):
         dom_ms = (float(np.mean(agg["c2f_refine_L0"])) + float(np.mean(agg["c2f_refine_L1"]))) / 2
         alg_bytes1 = REFINE_BYTES_PER_PX * (lv[0][0] * lv[0][1] + lv[1][0] * lv[1][1]) / 2      # one pair
         # pairs per timed launch: NB, except in a last partial group
-        groups = [min(NB, args.steps - i0) for i0 in range(0, args.steps, NB)][0::S] if NB > 1 else [1]
+        groups = [min(NB, args.steps - i0) for i0 in range(0, args.steps, NB)] if NB > 1 else [1]
         alg_bytes = alg_bytes1 * float(np.mean(groups))
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         pmc = pmc_constants(w, h, args.patch_r)

@@ -142,6 +142,37 @@ def test_batch_context_small_sizes_against_oracle(crop, crop_stages):
         B.close()
 
 
+def test_batch_device_entry_points_and_begin_end(crop, crop_stages):
+    """eppm_batch_set_images_device / eppm_batch_compute_device (device-resident RGBA in, float2 flows left in HBM) and the
+    two-halves form eppm_compute_begin / eppm_batch_compute_end on a batch context: same flows as the host-pointer calls."""
+    import eppm_amd
+    from eppm_amd import stages as S
+    from oracle import oracle as O
+    a, b = crop
+    st = crop_stages
+    h, w = 120, 160
+    ra, rb = O.rgb2rgba(a), O.rgb2rgba(b)
+    d = [S.Dev(ra, pitched=True), S.Dev(rb, pitched=True)]
+    outs = [S.Dev(shape=(h, w), dtype=eppm_amd.api.float2) for _ in range(3)]
+    B = eppm_amd.EPPMBatch(h, w, 3)
+    B.set_data_device([d[0].ptr.value, d[1].ptr.value, d[0].ptr.value], [d[1].ptr.value, d[0].ptr.value, d[1].ptr.value], d[0].pitch)
+    B.compute_flow_device([o.ptr.value for o in outs])
+    B.synchronize()
+    rev = O.compute_flow(b, a)
+    for k, want in enumerate(((st["u"], st["v"]), rev, (st["u"], st["v"]))):
+        f = outs[k].get()
+        assert np.array_equal(f["x"].copy().view(np.uint32), want[0].view(np.uint32)) and np.array_equal(f["y"].copy().view(np.uint32), want[1].view(np.uint32)), k
+    B.set_data([(b, a), (a, b)])
+    B.compute_flow_begin()
+    got = B.compute_flow_end()
+    assert len(got) == 2
+    for (u, v), want in zip(got, (rev, (st["u"], st["v"]))):
+        assert np.array_equal(u.view(np.uint32), want[0].view(np.uint32)) and np.array_equal(v.view(np.uint32), want[1].view(np.uint32))
+    with pytest.raises(eppm_amd.EppmError):
+        B.compute_flow_end()                                # end without begin
+    B.close()
+
+
 def test_config4_hd_pair_bit_exact():
     """BASELINE configs[3]: 1920x1080, full pyramid + bilateral refine (the non-split tiled refine with many tiles, XCD tile
     order, two-pixel-per-lane smoothing)."""

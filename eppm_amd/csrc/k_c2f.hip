@@ -1,6 +1,8 @@
 // k_c2f.hip -- coarse-to-fine step (reference: basic/bao_basic_cuda.cuh:511-537 float2 bilinear resize,
 // :135-142 scalar multiply; bao_pmflow_kernel.cu:2005-2041 plane-fitting candidate refine;
 // bao_pmflow_refine_kernel.cu:756-799 joint-bilateral flow smoothing).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "eppm_device.cuh"
@@ -756,6 +758,9 @@ __global__ __launch_bounds__(256) void k_c2f_select(float* __restrict__ flow_, c
 
 bool c2f_refine_wants_split(int w, int h, int R, int npairs)
 {
+    // EPPM_C2F_NO_SPLIT=1 (tests): never split, so that small images go through the LDS-window kernels too
+    static const bool no_split = getenv("EPPM_C2F_NO_SPLIT") != nullptr;
+    if (no_split) return false;
     const int tiles = ((w + kBlock - 1) / kBlock) * ((h + kBlock - 1) / kBlock) * npairs;
 #ifndef EPPM_C2F_SPLIT_BELOW_WAVES
 #define EPPM_C2F_SPLIT_BELOW_WAVES (3 * 1024)        // fewer than 3 waves per SIMD on 256 CUs

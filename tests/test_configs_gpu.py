@@ -227,6 +227,16 @@ def test_fuzz_parity_fixed_seeds(seed):
         assert same, f"fuzz seed {seed} case {t}: {w}x{h} {params}"
 
 
+def test_fuzz_parity_window_kernels_at_small_sizes():
+    """The fuzz sweep again in a child process with EPPM_C2F_NO_SPLIT=1: the candidate refine of small images then runs the
+    LDS-window kernels (k_c2f_refine_win / _win4) instead of the split gather kernel they normally get, at ragged sizes,
+    radii 9 and 17, every propagation mode and pyramid depth."""
+    env = dict(os.environ, EPPM_C2F_NO_SPLIT="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "test_fuzz_parity_fixed_seeds"],
+                         env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0 and "3 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
 # ---------------------------------------------------------------------------------------------------
 # n4: flow colour coding on the device
 # ---------------------------------------------------------------------------------------------------

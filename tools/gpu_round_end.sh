@@ -24,6 +24,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- pyth
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_single -- python3 $R/bench.py --steps 30 --warmup 3 --batch 1 --inflight 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 fi
 for m in "1 single" "4 batch4"; do set -- $m
+  rm -rf $O/pmc_sq_$2 $O/pmc_sq2_$2 $O/pmc_fetch_$2 $O/pmc_write_$2
   rocprofv3 --kernel-trace --pmc $SQ GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_$2 -- python3 $R/bench.py --steps 8 --warmup 4 --batch $1 --inflight 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $O/pmc_sq2_$2 -- python3 $R/bench.py --steps 8 --warmup 4 --batch $1 --inflight 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$2 -- python3 $R/bench.py --steps 4 --warmup 4 --batch $1 --inflight 1 --no-cpu-baseline --no-extras > /dev/null 2>&1

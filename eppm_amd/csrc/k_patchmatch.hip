@@ -155,14 +155,17 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
     constexpr int S = R + 1, NS = S * S, CH = (NS + LPC - 1) / LPC, CPB = 256 / LPC;
     __shared__ PatchLut L;
     load_patch_lut(L, lut, R, threadIdx.x, 256);
-    const PmProblem pr = pm_problem(B, blockIdx.y);
+    // 1-D grid, problem = id mod nprob: workgroups are dealt to the 8 XCDs by id mod 8, so with 8 problems (4 pairs x 2 directions)
+    // each problem's planes stay in ONE XCD's L2 instead of all problems' planes competing for every L2
+    const unsigned nprob = B.n * B.npairs, bq = blockIdx.x % nprob, bxx = blockIdx.x / nprob;
+    const PmProblem pr = pm_problem(B, bq);
     const Planes P = to_dev(pr.P);
     const int16_t* __restrict__ nin = pr.nnf;
     int16_t* __restrict__ nout = pr.nnf_alt;
     float* __restrict__ cost = pr.cost;
     const int len = IS_ROW ? P.w : P.h, lines = IS_ROW ? P.h : P.w;
     const int grp = threadIdx.x / LPC, r = threadIdx.x % LPC;
-    const int chain = blockIdx.x * CPB + grp;
+    const int chain = bxx * CPB + grp;
     const int line = chain / nseg_pad, seg = chain % nseg_pad;
     const bool active = (line < lines) && (seg < nseg);
     int start, count, i, step;
@@ -340,7 +343,7 @@ static void launch_sweep_r(const PmBatch& b, const float* lut, int seg_len, int 
     const int nseg_pad = (nseg + 1) & ~1;
     const int chains = lines * nseg_pad;
     constexpr int CPB = 256 / LPC;
-    dim3 grid((chains + CPB - 1) / CPB, b.n * b.npairs), block(256);
+    dim3 grid(((chains + CPB - 1) / CPB) * (b.n * b.npairs)), block(256);
     switch (dir) {
         case 0: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, false>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
         case 1: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, false>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
@@ -530,10 +533,13 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     __shared__ float s_cost[8][64];
     __shared__ int s_guess[8][64];
     __shared__ uint32_t s_state[64 * 6];
-    const PmProblem pr = pm_problem(B, blockIdx.z);
+    // problem = id mod nprob (one problem per XCD L2, see k_pm_sweep); the rest of the id walks the quarter-blocks row by row
+    const unsigned nprob = B.n * B.npairs, bq = blockIdx.x % nprob, brest = blockIdx.x / nprob;
+    const int bxx = brest % rng.gx, byy = brest / rng.gx;
+    const PmProblem pr = pm_problem(B, bq);
     const int tid = threadIdx.x;
-    const int tile_y = blockIdx.y >> 2, quarter = blockIdx.y & 3;
-    const int block_id = tile_y * rng.gx + blockIdx.x;
+    const int tile_y = byy >> 2, quarter = byy & 3;
+    const int block_id = tile_y * rng.gx + bxx;
     load_patch_lut(L, lut, R, tid, blockDim.x);
     if (tid < 64) {
         const size_t so = ((size_t)block_id * 64 + tid) * 6;
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     }
     const Planes P = to_dev(pr.P);
     if (RT != 0) {
-        const int x0 = blockIdx.x * kBlock - RT, y0 = tile_y * kBlock + quarter * 4 - RT;
+        const int x0 = bxx * kBlock - RT, y0 = tile_y * kBlock + quarter * 4 - RT;
         for (int t = tid; t < TW * TH; t += blockDim.x) {
             const int sy = iclamp(y0 + t / TW, 0, P.h - 1), sx = iclamp(x0 + t % TW, 0, P.w - 1);
             s_src[t] = P.pk1[(unsigned)(sy * P.pitch + sx)];
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
         }
     }
     const int pix = quarter * 64 + lane;                         // row-major index inside the 16x16 block
-    const int x = blockIdx.x * kBlock + (pix & 15), y = tile_y * kBlock + (pix >> 4);
+    const int x = bxx * kBlock + (pix & 15), y = tile_y * kBlock + (pix >> 4);
     const bool inimg = (k < G) && (x < P.w && y < P.h);
     const int nidx = y * B.npitch + x, cidx = y * B.cpitch + x;
     int bx = 0, by = 0;
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
 void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float* lut, int R, int search_range, int num_guess,
                              hipStream_t s)
 {
-    dim3 grid(rng.gx, rng.gy * 4, b.n * b.npairs), block(64 * (num_guess + 1));      // + the wave that advances the RNG states
+    dim3 grid(rng.gx * rng.gy * 4 * b.n * b.npairs), block(64 * (num_guess + 1));      // + the wave that advances the RNG states
     if (R == 9) hipLaunchKernelGGL(k_pm_random_search<9>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else if (R == 17) hipLaunchKernelGGL(k_pm_random_search<17>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else hipLaunchKernelGGL(k_pm_random_search<0>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);

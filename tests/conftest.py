@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# The oracle's lockstep sweeps synchronise every step: on the GPU box (256 hardware threads) OpenMP's default of one
+# thread per CPU makes a 160x120 run take 19 s instead of 0.15 s with 16 threads (tools/orc_threads.py).  Set before
+# libgomp loads; child processes (bench.py, the CLI tests) inherit it.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

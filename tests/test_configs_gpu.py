@@ -211,7 +211,7 @@ def _fuzz_case(seed, t):
     return a, b, params
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13])
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
 def test_fuzz_parity_fixed_seeds(seed):
     import eppm_amd
     from oracle import oracle as O
@@ -234,7 +234,85 @@ def test_fuzz_parity_window_kernels_at_small_sizes():
     env = dict(os.environ, EPPM_C2F_NO_SPLIT="1")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "test_fuzz_parity_fixed_seeds"],
                          env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
-    assert out.returncode == 0 and "3 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+    assert out.returncode == 0 and "8 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
+# ---------------------------------------------------------------------------------------------------
+# live oracle at BASELINE's full sizes (the oracle takes 2.5 s at 1024x436 and ~13 s at 1920x1080 on 16 threads): pairs that
+# are in no committed fixture, other image statistics than the fixtures', single-pair and batch contexts
+# ---------------------------------------------------------------------------------------------------
+def _same(got, want):
+    return np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32)) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+
+
+def _full_size_pairs():
+    from eppm_amd import synth
+    h, w = 436, 1024
+    rng = np.random.default_rng(20260)
+    pairs = {}
+    pairs["synth_4321_flow40"] = synth.make_pair(h, w, seed=4321, max_flow=40.0)[:2]           # flows beyond the search range
+    pairs["synth_4322_flow3"] = synth.make_pair(h, w, seed=4322, max_flow=3.0)[:2]              # near-static
+    n1, n2 = rng.integers(0, 256, (h, w, 3), dtype=np.uint8), rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    pairs["noise_unrelated"] = (n1, n2)                                                           # incoherent matches everywhere: refine fallback path
+    flat = np.full((h, w, 3), 117, np.uint8)
+    flat[100:300, 200:700] = (250, 3, 90)
+    pairs["flat_with_block"] = (flat, np.roll(flat, (7, -11), axis=(0, 1)))                       # zero weights' complement: constant patches
+    return pairs
+
+
+@pytest.mark.parametrize("name", ["synth_4321_flow40", "synth_4322_flow3", "noise_unrelated", "flat_with_block"])
+def test_config2_full_size_against_live_oracle(name):
+    """1024x436 (BASELINE configs[1]) against the oracle run live on the same inputs: large and tiny flows, unrelated noise images,
+    flat images -- none of them in the committed fixtures."""
+    import eppm_amd
+    from oracle import oracle as O
+    a, b = _full_size_pairs()[name]
+    e = eppm_amd.EPPM()
+    e.init(a, b, 436, 1024)
+    got = e.compute_flow()
+    e.close()
+    assert _same(got, O.compute_flow(a, b)), name
+
+
+def test_config3_batch_of_mixed_pairs_against_live_oracle():
+    """The four pairs above in ONE batch context (every launch covers all four: coherent and incoherent tiles, flat and textured
+    images side by side) == four live oracle runs."""
+    import eppm_amd
+    from oracle import oracle as O
+    pairs = list(_full_size_pairs().values())
+    B = eppm_amd.EPPMBatch(436, 1024, 4)
+    B.set_data(pairs)
+    out = B.compute_flow()
+    B.close()
+    for k, (a, b) in enumerate(pairs):
+        assert _same(out[k], O.compute_flow(a, b)), k
+
+
+def test_config4_hd_against_live_oracle():
+    """1920x1080 (BASELINE configs[3]) on a pair that is in no fixture, against the live oracle."""
+    import eppm_amd
+    from eppm_amd import synth
+    from oracle import oracle as O
+    a, b = synth.make_pair(1080, 1920, seed=777, max_flow=25.0)[:2]
+    e = eppm_amd.EPPM()
+    e.init(a, b, 1080, 1920)
+    got = e.compute_flow()
+    e.close()
+    assert _same(got, O.compute_flow(a, b))
+
+
+def test_bundled_pair_both_directions_and_odd_crops(frames):
+    """The reference's bundled Middlebury pair: backward direction at full size, and crops at odd offsets / ragged sizes."""
+    import eppm_amd
+    from oracle import oracle as O
+    a, b = frames
+    for (y0, x0, h, w) in ((0, 0, 480, 640), (3, 5, 431, 577), (100, 37, 255, 333)):
+        pa, pb = b[y0:y0 + h, x0:x0 + w].copy(), a[y0:y0 + h, x0:x0 + w].copy()       # frame11 -> frame10
+        e = eppm_amd.EPPM()
+        e.init(pa, pb, h, w)
+        got = e.compute_flow()
+        e.close()
+        assert _same(got, O.compute_flow(pa, pb)), (y0, x0, h, w)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -149,10 +149,19 @@ __device__ __forceinline__ float dpp_prev_lane(float v)
 #else
 #define EPPM_SWEEP_OCC
 #endif
-template <int R, int LPC, bool IS_ROW, bool REVERSE>
-__global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, const float* __restrict__ lut, int L_, int nseg, int nseg_pad)
+// TILE: the workgroup's CPB chains are SEGS consecutive segments of LINES lines of equal parity (y, y+2, ..): the sampled rows of
+// neighbouring lines of one parity coincide (offsets -R, -R+2, .. R), so S + LINES - 1 rows of SEGS*L + 2R texels, plus the LINES
+// lines themselves (patch centres), hold every source texel the workgroup's patches can touch.  They are staged in LDS once,
+// clamped at load; the source half of the sample gathers then never reaches the L1 (which these launches load to 60 % at one
+// 16-byte lane-fetch per clock, tools/ubench/gather_rate.hip).  TW = tile row length (odd: spreads a chain's ds_read_b128 over the banks).
+template <int LPC> struct SweepTile { static constexpr int CPB = 256 / LPC, SEGS = (CPB >= 16) ? 4 : 2, LINES = CPB / SEGS; };
+
+template <int R, int LPC, bool IS_ROW, bool REVERSE, bool TILE>
+__global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, const float* __restrict__ lut, int L_, int nseg, int nseg_pad, int TW)
 {
     constexpr int S = R + 1, NS = S * S, CH = (NS + LPC - 1) / LPC, CPB = 256 / LPC;
+    constexpr int SEGS = SweepTile<LPC>::SEGS, LINES = SweepTile<LPC>::LINES, TROWS = S + LINES - 1;
+    extern __shared__ float4 s_tile[];          // TILE: TROWS sample rows + LINES centre rows of TW texels
     __shared__ PatchLut L;
     load_patch_lut(L, lut, R, threadIdx.x, 256);
     // 1-D grid, problem = id mod nprob: workgroups are dealt to the 8 XCDs by id mod 8, so with 8 problems (4 pairs x 2 directions)
@@ -165,8 +174,20 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
     float* __restrict__ cost = pr.cost;
     const int len = IS_ROW ? P.w : P.h, lines = IS_ROW ? P.h : P.w;
     const int grp = threadIdx.x / LPC, r = threadIdx.x % LPC;
-    const int chain = bxx * CPB + grp;
-    const int line = chain / nseg_pad, seg = chain % nseg_pad;
+    int line, seg, li = 0, line0 = 0, seg0 = 0;
+    if (TILE) {
+        // workgroup -> (group of 2*LINES lines, parity, group of SEGS segments); chain grp -> line li of the group, segment grp % SEGS
+        const int nsg = nseg_pad / SEGS, sg = bxx % nsg, lp = bxx / nsg;
+        line0 = (lp >> 1) * (2 * LINES) + (lp & 1);
+        seg0 = sg * SEGS;
+        li = grp / SEGS;
+        line = line0 + 2 * li;
+        seg = seg0 + grp % SEGS;
+    } else {
+        const int chain = bxx * CPB + grp;
+        line = chain / nseg_pad;
+        seg = chain % nseg_pad;
+    }
     const bool active = (line < lines) && (seg < nseg);
     int start, count, i, step;
     if (!REVERSE) {
@@ -181,6 +202,16 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
         count = start - seg * L_;
         i = start - 1;
         step = -1;
+    }
+    const int abase = seg0 * L_ - R;                                  // TILE: along-line coordinate of tile column 0
+    if (TILE) {
+        if (line0 >= lines) return;                                   // the whole workgroup is past the last line
+        for (int t = threadIdx.x; t < (TROWS + LINES) * TW; t += 256) {
+            const int row = t / TW, c = t - row * TW;
+            const int across = iclamp(row < TROWS ? line0 - R + 2 * row : line0 + 2 * (row - TROWS), 0, lines - 1);
+            const int along = iclamp(abase + c, 0, len - 1);
+            s_tile[t] = P.pk1[(unsigned)(IS_ROW ? across * P.pitch + along : along * P.pitch + across)];
+        }
     }
     int px = 0, py = 0;
     if (active) {
@@ -200,12 +231,15 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
     const int t0 = r * CH;
     const int pitch16 = P.pitch << 4, wmax16 = (P.w - 1) << 4;
     int dj16[CH], di_[CH];                 // this lane's sample offsets (column in bytes): the same at every step
+    int lo_[CH];                           // TILE: tile index of the sample when the chain stands at along-line coordinate 0
 #pragma unroll
     for (int k = 0; k < CH; k++) {
         const int t = min(t0 + k, NS - 1);
         di_[k] = 2 * (t / S) - R;
         dj16[k] = (2 * (t % S) - R) * 16;
+        lo_[k] = IS_ROW ? (li + t / S) * TW + (2 * (t % S) - R) - abase : (li + t % S) * TW + (2 * (t / S) - R) - abase;
     }
+    const int lc = (TROWS + li) * TW - abase;                          // TILE: the same for the patch centre
     for (int s = 0; s < L_; s++) {
         if (active && s < count) {
             const int x = IS_ROW ? i : line, y = IS_ROW ? line : i;
@@ -220,7 +254,7 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             // neighbours sharing one offset -- make this the common case after the first iterations.
             float cv = cur_best;
             if (!(px == ox && py == oy)) {
-            const rgbf c1 = texel_rgb(tex_px(P.pk1, P.pitch, P.w, P.h, x, y));
+            const rgbf c1 = texel_rgb(TILE ? s_tile[lc + i] : tex_px(P.pk1, P.pitch, P.w, P.h, x, y));
             const rgbf c2 = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, px, py));
             float tc[CH], tw[CH];
             constexpr int GB = (CH < EPPM_SWEEP_GB) ? CH : EPPM_SWEEP_GB;           // gathers in flight per lane
@@ -229,7 +263,8 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
                 float4 q1[GB], q2[GB];
 #pragma unroll
                 for (int k = 0; k < GB; k++) {
-                    q1[k] = texel_at(P.pk1, texel_off16(pitch16, wmax16, P.h - 1, (x << 4) + dj16[q0 + k], y + di_[q0 + k]));
+                    q1[k] = TILE ? s_tile[lo_[q0 + k] + i]
+                                 : texel_at(P.pk1, texel_off16(pitch16, wmax16, P.h - 1, (x << 4) + dj16[q0 + k], y + di_[q0 + k]));
                     q2[k] = texel_at(P.pk2, texel_off16(pitch16, wmax16, P.h - 1, (px << 4) + dj16[q0 + k], py + di_[q0 + k]));
                 }
 #pragma unroll
@@ -337,19 +372,32 @@ __global__ __launch_bounds__(1024) void k_pm_seg_propagate(PmBatch B, const floa
     }
 }
 
+template <int R, int LPC, bool TILE>
+static void launch_sweep_t(const PmBatch& b, const float* lut, int seg_len, int dir, int nseg, int lines, hipStream_t s)
+{
+    constexpr int CPB = 256 / LPC, SEGS = SweepTile<LPC>::SEGS, LINES = SweepTile<LPC>::LINES;
+    const int nseg_pad = TILE ? (nseg + SEGS - 1) / SEGS * SEGS : (nseg + 1) & ~1;
+    const int wgs = TILE ? ((lines + 2 * LINES - 1) / (2 * LINES)) * 2 * (nseg_pad / SEGS) : (lines * nseg_pad + CPB - 1) / CPB;
+    const int TW = (SEGS * seg_len + 2 * R) | 1;
+    const size_t lds = TILE ? (size_t)(R + 1 + 2 * LINES - 1) * TW * 16 : 0;
+    dim3 grid(wgs * (b.n * b.npairs)), block(256);
+    switch (dir) {
+        case 0: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, false, TILE>), grid, block, lds, s, b, lut, seg_len, nseg, nseg_pad, TW); break;
+        case 1: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, false, TILE>), grid, block, lds, s, b, lut, seg_len, nseg, nseg_pad, TW); break;
+        case 2: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, true, TILE>), grid, block, lds, s, b, lut, seg_len, nseg, nseg_pad, TW); break;
+        default: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, true, TILE>), grid, block, lds, s, b, lut, seg_len, nseg, nseg_pad, TW); break;
+    }
+}
+#ifndef EPPM_SWEEP_TILE
+#define EPPM_SWEEP_TILE 1
+#endif
+// source tile in LDS while it stays small (16 KiB at R = 9 and the default segment length of 10); very long segments gather
 template <int R, int LPC>
 static void launch_sweep_r(const PmBatch& b, const float* lut, int seg_len, int dir, int nseg, int lines, hipStream_t s)
 {
-    const int nseg_pad = (nseg + 1) & ~1;
-    const int chains = lines * nseg_pad;
-    constexpr int CPB = 256 / LPC;
-    dim3 grid(((chains + CPB - 1) / CPB) * (b.n * b.npairs)), block(256);
-    switch (dir) {
-        case 0: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, false>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
-        case 1: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, false>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
-        case 2: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
-        default: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad); break;
-    }
+    const size_t lds = (size_t)(R + 2 * SweepTile<LPC>::LINES) * ((SweepTile<LPC>::SEGS * seg_len + 2 * R) | 1) * 16;
+    if (EPPM_SWEEP_TILE && lds <= 32 * 1024) launch_sweep_t<R, LPC, true>(b, lut, seg_len, dir, nseg, lines, s);
+    else launch_sweep_t<R, LPC, false>(b, lut, seg_len, dir, nseg, lines, s);
 }
 
 bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s)

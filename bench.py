@@ -137,6 +137,7 @@ def worker(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the HIP runtime starts: RCCL needs dmabuf IPC on this pool
     import torch
     import torch.distributed as dist
     if os.environ.get("EPPM_BENCH_SHARE_GPU"):      # test hook: several ranks on one GPU (gloo only)
@@ -145,13 +146,19 @@ def worker(args):
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = args.dist_backend
         if backend == "nccl":                        # RCCL: used only for the barrier and the MAX of the wall time
             try:
                 dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+                probe = torch.ones(1, device=dev)    # communicators are created lazily: fail here, not inside the timed region
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce probe returned {probe.item()} for {world} ranks")
             except Exception as e:                   # the data path needs no collective: gloo is as good for timing
-                print(f"[bench] nccl init failed ({e}); falling back to gloo", file=sys.stderr)
+                print(f"[bench] nccl unusable ({e}); falling back to gloo", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
                 backend = "gloo"
         if backend == "gloo":
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)

@@ -376,10 +376,13 @@ def test_reference_main_cpp_unmodified_writes_the_same_flo(tmp_path):
 # ---------------------------------------------------------------------------------------------------
 # bench.py --gpus N without a launcher (two ranks share the one GPU of the test box; gloo for the barrier)
 # ---------------------------------------------------------------------------------------------------
-def test_bench_two_ranks_share_one_gpu():
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_bench_two_ranks_share_one_gpu(backend):
+    """backend nccl: RCCL refuses two ranks on one device, at the first collective -- the probe all-reduce after
+    init_process_group must catch that and every rank must fall back to gloo (the data path has no collective)."""
     env = dict(os.environ, EPPM_BENCH_SHARE_GPU="1")
     env.pop("RANK", None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--dist-backend", "gloo",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--dist-backend", backend,
                           "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -387,6 +390,7 @@ def test_bench_two_ranks_share_one_gpu():
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["roofline"]["frac"] > 0 and d["roofline"]["avg_launch_ms"] > 0
+    assert ("falling back to gloo" in out.stderr) == (backend == "nccl")
 
 
 # ---------------------------------------------------------------------------------------------------

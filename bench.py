@@ -109,6 +109,25 @@ def pmc_constants(w, h, patch_r):
     return None
 
 
+def path_valu_roofline(pmc, nb, s_per_step):
+    """The WHOLE path against the bound that limits it: wave64 VALU instructions of every kernel per pair (SQ_INSTS_VALU summed
+    over all dispatches of the 4-pairs-per-launch counter pass, profiles/pmc_constants.json "path", valid only for the device
+    sources it was measured on) / the nominal issue peak = the time per pair below which this instruction stream cannot run."""
+    try:
+        p = pmc["path"]
+        srcs = b"".join(open(os.path.join(ROOT, f), "rb").read() for f in p["kernel_sources"])
+        if hashlib.sha256(srcs).hexdigest() != p["sources_sha256"] or nb != p["pairs_per_launch"]:
+            return None
+        floor_ms = p["valu_insts_per_pair"] / VALU_PEAK_WAVE_INSTS_PER_S * 1e3
+        return {"bound": "valu", "scope": "every kernel of one pair (set_data device part + compute_flow), 4 pairs per launch",
+                "wave64_valu_insts_per_pair": p["valu_insts_per_pair"], "peak_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
+                "floor_ms_per_pair": floor_ms, "ms_per_step": s_per_step * 1e3, "frac": floor_ms / (s_per_step * 1e3),
+                "note": "nominal peak = 256 CUs x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction; the clock under this load is "
+                        "2.2-2.3 GHz and about a tenth of the instructions are half rate", "source": pmc.get("source")}
+    except Exception:
+        return None
+
+
 def pmc_levels(pmc, nb):
     """(level-1, level-0) per-pair PMC records of the dominant kernel for launches of nb pairs, or None."""
     if not pmc:
@@ -324,6 +343,7 @@ def worker(args):
             "epe_vs_synthetic_gt": epe_gt,
         }
         out.update(extras)
+        out["path_valu_roofline"] = path_valu_roofline(pmc, NB, dt / args.steps)
         if world == 1 and not args.no_extras:
             out.update(single_stream_legs(args, eng, inputs, pitch, pmc, alg_bytes1))
             out["host_boundary"] = host_boundary(args, engs, host_pairs)

@@ -45,8 +45,17 @@ for key, d_sfx, kern, grid, div in (("refine_win_L0", "single", "k_c2f_refine_wi
                      "avg_us_under_pmc": val(f"pmc_sq_{d_sfx}", kern, grid, "avg_us") / div}
 srcs = ["eppm_amd/csrc/k_c2f.hip", "eppm_amd/csrc/eppm_device.cuh"]
 sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, f), "rb").read() for f in srcs)).hexdigest()
+# the whole path: wave64 VALU instructions of EVERY kernel per pair, from the 4-pairs-per-launch SQ pass (k_pm_init_field runs
+# once per batch: its call count gives the number of batches the profiled command processed); keyed by ALL device sources
+all_srcs = sorted(os.path.relpath(f, ROOT) for f in glob.glob(f"{ROOT}/eppm_amd/csrc/*.hip") + glob.glob(f"{ROOT}/eppm_amd/csrc/*.cuh"))
+sha_all = hashlib.sha256(b"".join(open(os.path.join(ROOT, f), "rb").read() for f in all_srcs)).hexdigest()
+rows4 = summ["pmc_sq_batch4"]
+batches = sum(float(r["calls"]) for r in rows4 if "k_pm_init_field" in r["kernel"])
+path = {"sources_sha256": sha_all, "kernel_sources": all_srcs, "pairs_per_launch": 4,
+        "valu_insts_per_pair": sum(float(r["SQ_INSTS_VALU"]) * float(r["calls"]) for r in rows4) / (batches * 4),
+        "kernel_us_per_pair_one_context": sum(float(r["avg_us"]) * float(r["calls"]) for r in rows4) / (batches * 4)}
 entry = {"width": W, "height": H, "patch_r": 9, "source": f"profiles/{tag}_pmc_*.csv (tools/gpu_round_end.sh, tools/store_profiles.py)",
-         "kernel_sources": srcs, "per_pair": per_pair,
+         "kernel_sources": srcs, "per_pair": per_pair, "path": path,
          "note": "FETCH_SIZE counts the 128-B requests of 16-B-per-lane loads at 64 B on gfx950 (MI355X_MICROARCH.md, HBM): traffic = 2*FETCH + WRITE"}
 json.dump({sha: entry}, open(f"{dst}/pmc_constants.json", "w"), indent=1)
 print(json.dumps(per_pair, indent=1))

@@ -313,6 +313,47 @@ def test_tiny_and_degenerate_inputs():
     eq(u, ou, "u black/white"); eq(v, ov, "v black/white")
 
 
+@pytest.mark.parametrize("h,w,params", [
+    (24, 4000, {}),                                  # 1 x 250-pixel... quarter level 6 x 1000: 100 segments per row, 6 lines
+    (4000, 24, {}),                                  # the transpose: column sweeps with 100 segments
+    (17, 2051, dict(levels=2)),                      # odd sizes, two levels
+    (2051, 17, dict(levels=1, seg_len=3)),           # single scale, 684 segments per column
+    (64, 3000, dict(patch_r=17, num_iter=2)),        # radius 17 on a strip: the patch is taller than the image at every level
+    (33, 1500, dict(propagation=1, num_iter=2)),     # jump flood on a strip
+])
+def test_extreme_aspect_ratios(h, w, params):
+    """Strips: many segments per line and few lines (and the transpose) -- grid and tile-mapping edge cases of the sweeps, the
+    search and the refine; patches larger than the image."""
+    import eppm_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng([h, w])
+    a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    b = np.roll(a, (1, -3), axis=(0, 1))
+    b[::7] = rng.integers(0, 256, b[::7].shape, dtype=np.uint8)
+    e = eppm_amd.EPPM(params=eppm_amd.Params(**params))
+    e.init(a, b, h, w)
+    u, v = e.compute_flow()
+    e.close()
+    ou, ov = O.compute_flow(a, b, O.default_params(**params))
+    eq(u, ou, f"u {w}x{h} {params}"); eq(v, ov, f"v {w}x{h} {params}")
+
+
+@pytest.mark.parametrize("params", [
+    dict(seg_len=24),                      # the longest segments whose source tile (17 rows x 115 texels) still fits the LDS budget
+    dict(seg_len=25),                      # one more: the sweeps gather their source samples
+    dict(seg_len=64, patch_r=17),          # radius 17, long segments (gather path), 64-lane chains
+    dict(seg_len=2),                       # shortest segments: two steps per chain
+    dict(seg_len=200),                     # one segment per line at this size
+    dict(num_guess=8, search_range=1),     # eight guesses, all at radius 1
+    dict(num_guess=1, search_range=200),   # one guess anywhere in the image
+    dict(wmf_iters=0, num_iter=1),
+])
+def test_sweep_and_search_parameter_extremes(frames, params):
+    a, b = frames
+    u, v, ou, ov = _run_both(a[40:231, 100:421].copy(), b[40:231, 100:421].copy(), **params)
+    eq(u, ou, f"u {params}"); eq(v, ov, f"v {params}")
+
+
 def test_bundled_pair_full_size(frames):
     """BASELINE config 1: frame10/frame11 (640x480), default parameters.  HIP flow == oracle flow bit for bit
     (EPE 0 <= 1e-3 px), and the oracle's flow matches the committed sha256."""

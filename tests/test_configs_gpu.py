@@ -315,6 +315,43 @@ def test_bundled_pair_both_directions_and_odd_crops(frames):
         assert _same(got, O.compute_flow(pa, pb)), (y0, x0, h, w)
 
 
+def test_soak_contexts_in_flight_are_deterministic():
+    """Race hunt: three single-pair contexts and one 4-pair batch context kept in flight together (begin/end, each on its own
+    stream, kernels of all four interleaving on the GPU) for 40 rounds at 1024x436 -- every flow of every round must hash like the
+    first one of its pair, which is compared with the live oracle."""
+    import hashlib
+    import eppm_amd
+    from eppm_amd import synth
+    from oracle import oracle as O
+    h, w = 436, 1024
+    pairs = [synth.make_pair(h, w, seed=9000 + i)[:2] for i in range(4)]
+    engs = []
+    for i in range(3):
+        e = eppm_amd.EPPM()
+        e.init(h, w)
+        engs.append(e)
+    B = eppm_amd.EPPMBatch(h, w, 4)
+    digest = lambda uv: hashlib.sha256(uv[0].tobytes() + uv[1].tobytes()).hexdigest()
+    first = {}
+    for rnd in range(40):
+        for k, e in enumerate(engs):
+            e.set_data(*pairs[(rnd + k) % 4])
+            e.compute_flow_begin()
+        B.set_data([pairs[(rnd + j) % 4] for j in range(4)])
+        B.compute_flow_begin()
+        got = [((rnd + k) % 4, e.compute_flow_end()) for k, e in enumerate(engs)]
+        got += [((rnd + j) % 4, uv) for j, uv in enumerate(B.compute_flow_end())]
+        for i, uv in got:
+            d = digest(uv)
+            if i not in first:
+                first[i] = d
+                assert _same(uv, O.compute_flow(*pairs[i])), i
+            assert d == first[i], (rnd, i)
+    for e in engs:
+        e.close()
+    B.close()
+
+
 # ---------------------------------------------------------------------------------------------------
 # n4: flow colour coding on the device
 # ---------------------------------------------------------------------------------------------------

@@ -645,7 +645,14 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
         const int ymin = max(by - mag, 0), ymax = min(by + mag + 1, P.h + 1);
         const int gx = (int)(int16_t)((uint32_t)xmin + rdn1 % (uint32_t)(xmax - xmin));
         const int gy = (int)(int16_t)((uint32_t)ymin + rdn2 % (uint32_t)(ymax - ymin));
-        s_cost[k][lane] = search_patch_dist<RT>(P, L, R, s_src, TW, lane & 15, lane >> 4, x, y, gx, gy);
+#ifndef EPPM_SEARCH_SKIP_SAME
+#define EPPM_SEARCH_SKIP_SAME 1
+#endif
+        // A guess equal to the pixel's current match would reproduce the stored cost bit for bit (the skip rule of the sweeps): the
+        // reference evaluates and rejects it ("<"), here the lane sits the evaluation out -- a ninth of the radius-1 guesses, and
+        // in a kernel that runs at one L1 lane-fetch per clock an idle lane is time saved.
+        if (EPPM_SEARCH_SKIP_SAME && gx == bx && gy == by) s_cost[k][lane] = INFINITY;
+        else s_cost[k][lane] = search_patch_dist<RT>(P, L, R, s_src, TW, lane & 15, lane >> 4, x, y, gx, gy);
         s_guess[k][lane] = (gx & 0xffff) | (gy << 16);
     }
     __syncthreads();

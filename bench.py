@@ -42,7 +42,6 @@ W, H = 1024, 436               # BASELINE.json configs[1]
 REFINE_BYTES_PER_PX = 26
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2      # 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
-KERNEL_SOURCES = ["eppm_amd/csrc/k_c2f.hip", "eppm_amd/csrc/eppm_device.cuh"]
 
 
 def parse_args(known_only=False):
@@ -60,6 +59,11 @@ def parse_args(known_only=False):
                          "covers the whole group; --inflight such contexts are kept in flight")
     ap.add_argument("--pairs-per-gpu", type=int, default=8, help="size of the config-3 leg (distinct pairs per GPU)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed window of exactly --steps steps is run this many times back to back; the median is reported (min/max beside it)")
+    ap.add_argument("--verify-config3", action="store_true",
+                    help="BASELINE configs[2] with a correctness bit: this rank's share of the 64 pairs (pair i -> rank i mod N, seeds 1234+i) through the "
+                         "host boundary, every flow checked against tests/golden/MANIFEST_config3.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip host_boundary / cold / config3 / single-stream legs (profiling runs)")
     return ap.parse_known_args()[0] if known_only else ap.parse_args()
@@ -95,14 +99,16 @@ def spawn_ranks(args, script=None):
         sys.exit(1)
 
 
+def _sha(files):
+    return hashlib.sha256(b"".join(open(os.path.join(ROOT, f), "rb").read() for f in files)).hexdigest()
+
+
 def pmc_constants(w, h, patch_r):
-    """PMC-derived constants of the dominant kernel, valid only for the kernel sources they were measured on
-    (profiles/pmc_constants.json is keyed by the sha256 of those sources); None when nothing matches."""
+    """PMC-derived constants for this shape (profiles/pmc_constants.json, written by tools/store_profiles.py from separate
+    rocprofv3 --pmc passes): valid only for the device sources they were measured on (sha256 inside the entry); None otherwise."""
     try:
-        hsh = hashlib.sha256(b"".join(open(os.path.join(ROOT, f), "rb").read() for f in KERNEL_SOURCES)).hexdigest()
-        tab = json.load(open(PMC_FILE))
-        e = tab.get(hsh)
-        if e and (e["width"], e["height"], e["patch_r"]) == (w, h, patch_r):
+        e = json.load(open(PMC_FILE))["shapes"].get(f"{w}x{h}_r{patch_r}")
+        if e and _sha(e["kernel_sources"]) == e["sources_sha256"]:
             return e
     except Exception:
         pass
@@ -111,43 +117,28 @@ def pmc_constants(w, h, patch_r):
 
 def path_valu_roofline(pmc, nb, s_per_step):
     """The WHOLE path against the bound that limits it: wave64 VALU instructions of every kernel per pair (SQ_INSTS_VALU summed
-    over all dispatches of the 4-pairs-per-launch counter pass, profiles/pmc_constants.json "path", valid only for the device
-    sources it was measured on) / the nominal issue peak = the time per pair below which this instruction stream cannot run."""
+    over all dispatches of a one-context counter pass) / the nominal issue peak = the time per pair below which this
+    instruction stream cannot run."""
     try:
         p = pmc["path"]
-        srcs = b"".join(open(os.path.join(ROOT, f), "rb").read() for f in p["kernel_sources"])
-        if hashlib.sha256(srcs).hexdigest() != p["sources_sha256"] or nb != p["pairs_per_launch"]:
-            return None
         floor_ms = p["valu_insts_per_pair"] / VALU_PEAK_WAVE_INSTS_PER_S * 1e3
-        return {"bound": "valu", "scope": "every kernel of one pair (set_data device part + compute_flow), 4 pairs per launch",
+        return {"bound": "valu", "scope": f"every kernel of one pair (set_data device part + compute_flow), counters taken at {p['pairs_per_launch']} pair(s) per launch",
                 "wave64_valu_insts_per_pair": p["valu_insts_per_pair"], "peak_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
                 "floor_ms_per_pair": floor_ms, "ms_per_step": s_per_step * 1e3, "frac": floor_ms / (s_per_step * 1e3),
+                "by_kernel_group": p.get("by_kernel_group"),
                 "note": "nominal peak = 256 CUs x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction; the clock under this load is "
                         "2.2-2.3 GHz and about a tenth of the instructions are half rate", "source": pmc.get("source")}
     except Exception:
         return None
 
 
-def pmc_levels(pmc, nb):
-    """(level-1, level-0) per-pair PMC records of the dominant kernel for launches of nb pairs, or None."""
-    if not pmc:
+def dominant_pmc(pmc, nb):
+    """per-launch PMC record {valu_insts, fetch_size_kb, write_size_kb} of the dominant kernel (sum over its level-1 and level-0
+    launches, per PAIR) for launches of nb pairs, or None"""
+    try:
+        return pmc["dominant"][str(nb)]
+    except Exception:
         return None
-    pp = pmc["per_pair"]
-    if nb == 1:
-        return pp.get("refine_split4_L1"), pp.get("refine_win_L0")
-    if nb == 4:
-        return pp.get("refine_win_L1_batch4"), pp.get("refine_win_L0_batch4")
-    return None
-
-
-def pmc_traffic(pmc, nb, pairs_per_launch):
-    """HBM-side bytes per launch of the dominant kernel (mean of its level-1 and level-0 launches): 2 x FETCH_SIZE (gfx950
-    tallies the 128-B requests of 16-B-per-lane loads at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, from separate
-    --pmc passes (profiles/pmc_constants.json)."""
-    lv = pmc_levels(pmc, nb)
-    if not lv or not all(lv):
-        return None
-    return float(sum((2 * r["fetch_size_kb"] + r["write_size_kb"]) * 1024 for r in lv) / 2 * pairs_per_launch)
 
 
 def worker(args):
@@ -163,25 +154,33 @@ def worker(args):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ctl = None                      # gloo group: control plane (backend agreement); `grp` carries the barrier and the MAX of the wall time
+    grp = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = args.dist_backend
-        if backend == "nccl":                        # RCCL: used only for the barrier and the MAX of the wall time
+        # The data path needs no collective; the process group only carries the barrier and one MAX.  gloo always comes up
+        # first, RCCL is probed on top of it, and the ranks AGREE (a MIN over gloo) before any of them uses it: a rank whose
+        # RCCL init fails can never sit in a gloo barrier while the others wait in an RCCL one.
+        import datetime
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        ctl = dist.group.WORLD
+        ok = 0
+        if args.dist_backend == "nccl":
             try:
-                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-                probe = torch.ones(1, device=dev)    # communicators are created lazily: fail here, not inside the timed region
-                dist.all_reduce(probe)
+                grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe, group=grp)
                 torch.cuda.synchronize()
-                if int(probe.item()) != world:
-                    raise RuntimeError(f"all_reduce probe returned {probe.item()} for {world} ranks")
-            except Exception as e:                   # the data path needs no collective: gloo is as good for timing
-                print(f"[bench] nccl unusable ({e}); falling back to gloo", file=sys.stderr)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = "gloo"
-        if backend == "gloo":
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    tdev = dev if (world > 1 and dist.get_backend() == "nccl") else torch.device("cpu")
+                ok = int(int(probe.item()) == world)
+            except Exception as e:
+                print(f"[bench] rank {rank}: nccl unusable ({e})", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)
+        if not int(flag.item()):
+            if args.dist_backend == "nccl" and rank == 0:
+                print("[bench] RCCL not usable on every rank; barrier and MAX go over gloo", file=sys.stderr)
+            grp = ctl
+    tdev = dev if (world > 1 and grp is not ctl) else torch.device("cpu")
 
     import eppm_amd
     from eppm_amd import synth
@@ -217,13 +216,13 @@ def worker(args):
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=grp)
         torch.cuda.synchronize()
 
     def all_max(x):
         if world > 1:
             t = torch.tensor([x], dtype=torch.float64, device=tdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
             return float(t.item())
         return x
 
@@ -255,21 +254,41 @@ def worker(args):
     run_steps(0, max(args.warmup, S * NB), S * NB)
     sync_all()
 
-    # ---- the timed region: exactly --steps steps; events only around the dominant kernel, from a pool ----
-    tengs = bengs if NB > 1 else engs          # every context in flight records its own launches of the dominant kernel
-    for e in tengs:
+    # ---- the timed region: exactly --steps steps, bracketed by barrier + synchronize; run --repeats times, median reported ----
+    tengs = bengs if NB > 1 else engs
+    for e in tengs:                            # HIP events around the dominant kernel only, from a per-context pool
         e.enable_stage_timing(2)
         e.stage_times(clear=True)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(0, args.steps, S * NB)
-    sync_all()
-    barrier()
-    dt = all_max(time.perf_counter() - t0)
-    dom = []
+    dts = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(0, args.steps, S * NB)
+        sync_all()
+        barrier()
+        dts.append(all_max(time.perf_counter() - t0))
+    dt = float(np.median(dts))
+    dom_timed = []
     for e in tengs:
-        dom += e.stage_times(clear=True)
+        dom_timed += e.stage_times(clear=True)
         e.enable_stage_timing(0)
+    # the dominant kernel's launch duration WITHOUT other contexts' kernels interleaved between the event pair: the same
+    # launches (NB pairs per launch) issued to ONE context with nothing else in flight
+    te = tengs[0]
+    te.enable_stage_timing(2)
+    te.stage_times(clear=True)
+    for r in range(6):
+        if NB > 1:
+            idx = list(range(NB))
+            te.set_data_device([inputs[j][0].data_ptr() for j in idx], [inputs[j][1].data_ptr() for j in idx], pitch)
+            te.compute_flow_device([inputs[j][2].data_ptr() for j in idx])
+        else:
+            a, b, f = inputs[0]
+            te.set_data_device(a.data_ptr(), b.data_ptr(), pitch)
+            te.compute_flow_device(f.data_ptr())
+        te.synchronize()
+    dom = te.stage_times(clear=True)
+    te.enable_stage_timing(0)
 
     # sanity: the flow is finite and close to the synthetic ground truth (not a parity check)
     flow = d_flow.cpu().numpy()
@@ -312,34 +331,57 @@ def worker(args):
                              "batch": {"value": world * NC3 * w * h / dt3b / 1e6, "ms_per_pair": dt3b / NC3 * 1e3, "pairs_per_launch": NC3,
                                        "stage_ms_per_pair": bst}}
 
+    if args.verify_config3:
+        extras["config3_verified"] = verify_config3(args, rank, world, local_rank, params, dist, ctl)
+
     if rank == 0:
-        agg = {}
-        for name, ms in dom:
-            agg.setdefault(name, []).append(ms)
+        def per_launch(records):
+            agg = {}
+            for name, ms in records:
+                agg.setdefault(name, []).append(ms)
+            # per launch = mean over the kernel's two launches per group (levels 1 and 0): what rocprofv3 --stats averages for it
+            return (float(np.mean(agg["c2f_refine_L0"])) + float(np.mean(agg["c2f_refine_L1"]))) / 2
         lv = eng.level_dims()
-        # dominant kernel = k_c2f_refine_tiled; per launch = mean over its two launches per pair (levels 1 and 0),
-        # which is what rocprofv3 --stats averages for that kernel name family
-        dom_ms = (float(np.mean(agg["c2f_refine_L0"])) + float(np.mean(agg["c2f_refine_L1"]))) / 2
-        alg_bytes1 = REFINE_BYTES_PER_PX * (lv[0][0] * lv[0][1] + lv[1][0] * lv[1][1]) / 2      # one pair
-        # pairs per timed launch: NB, except in a last partial group
-        groups = [min(NB, args.steps - i0) for i0 in range(0, args.steps, NB)] if NB > 1 else [1]
-        alg_bytes = alg_bytes1 * float(np.mean(groups))
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        dom_ms = per_launch(dom)                                   # one context, nothing else in flight
+        dom_ms_timed = per_launch(dom_timed)                       # inside the timed region: event pairs also span other contexts' kernels
+        alg_bytes1 = REFINE_BYTES_PER_PX * (lv[0][0] * lv[0][1] + lv[1][0] * lv[1][1]) / 2      # one pair, per launch
+        alg_bytes = alg_bytes1 * NB
+        hbm = {"bound": "hbm", "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "algorithmic_bytes_per_launch": alg_bytes}
+        hbm["frac"] = hbm["achieved"] / HBM_PEAK_GBS
         pmc = pmc_constants(w, h, args.patch_r)
+        dp = dominant_pmc(pmc, NB)
+        kern = ("k_c2f_refine_win / _win4 (candidate refine, bao_pmflow_kernel.cu:2005-2041); per launch = mean of its level-1 and level-0 launches of "
+                f"{NB} pair(s), HIP events on the context's stream, ONE context with nothing else in flight (same launches as the timed region)")
+        if dp:
+            insts = dp["valu_insts"] / 2 * NB                      # wave64 VALU instructions per launch
+            roof = {"bound": "valu", "kernel": kern, "achieved": insts / (dom_ms * 1e-3) / 1e9, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e9,
+                    "unit": "G wave64-inst/s", "frac": insts / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S,
+                    "traffic": (2 * dp["fetch_size_kb"] + dp["write_size_kb"]) * 1024 / 2 * NB,
+                    "wave64_valu_insts_per_launch": insts, "hbm": hbm, "source": pmc.get("source"),
+                    "note": "the path has no dense contraction and is not HBM bound (3 600 patch samples x ~46 VALU instructions per pixel against 26 "
+                            "algorithmic bytes): the bound that applies is vector-ALU issue, peak = 256 CUs x 4 SIMD x 2.4 GHz / 2 cycles per wave64 "
+                            "instruction; the HBM form the contract names is in `hbm`; `traffic` = HBM bytes per launch from separate --pmc passes "
+                            "(2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction)"}
+        else:
+            roof = dict(hbm, kernel=kern, traffic=None,
+                        note="profiles/pmc_constants.json has no entry measured on these device sources: VALU instruction count and HBM traffic unknown")
+        roof.update({"avg_launch_ms": dom_ms, "avg_launch_ms_timed_region": dom_ms_timed, "pairs_per_launch": NB,
+                     "dominant_kernel_ms_per_step": 2 * dom_ms / NB})
+        vals = sorted(world * args.steps * w * h / d / 1e6 for d in dts)
         out = {
             "metric": "Mflow-vectors/sec", "value": world * args.steps * w * h / dt / 1e6, "unit": "Mflow-vectors/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": len(dts), "value_min": vals[0], "value_max": vals[-1], "ms_per_step_by_repeat": [d / args.steps * 1e3 for d in dts],
             "config": {"workload": f"single {w}x{h} Sintel-shape synthetic pair per step, full 3-level pyramid, patch_r={args.patch_r}, "
-                                   f"default defs.h parameters; {world} rank(s), independent pairs",
+                                   f"default defs.h parameters; {world} rank(s), independent pairs; inputs: RGBA planes resident in HBM before the "
+                                   "timed region; outputs: interleaved float2 flow left in HBM (the PCIe-inclusive window of the reference API -- host "
+                                   "RGB in, host u/v out -- is `host_boundary`)",
+                       "inputs": "device-resident RGBA", "outputs": "device-resident float2 flow",
                        "pairs_per_step_per_gpu": 1, "pairs_in_flight_per_gpu": S * NB, "pairs_per_launch": NB, "contexts_in_flight": S,
                        "width": w, "height": h},
-            "roofline": {"bound": "hbm", "kernel": "k_c2f_refine_win (candidate refine; mean of its level-1 and level-0 launches over the timed region, all streams busy)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(pmc, NB, float(np.mean(groups))),
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
-                         "pairs_per_launch": float(np.mean(groups)),
-                         "note": "the kernel is VALU-issue bound (3 600 patch samples x ~47 instructions per pixel against 26 bytes): see valu_roofline"},
+            "roofline": roof,
             "epe_vs_synthetic_gt": epe_gt,
         }
         out.update(extras)
@@ -347,6 +389,8 @@ def worker(args):
         if world == 1 and not args.no_extras:
             out.update(single_stream_legs(args, eng, inputs, pitch, pmc, alg_bytes1))
             out["host_boundary"] = host_boundary(args, engs, host_pairs)
+            if isinstance(out["host_boundary"], dict) and "pipelined" in out["host_boundary"]:
+                out["host_boundary"]["pipelined_over_value"] = out["host_boundary"]["pipelined"] / out["value"]
             out["cold_ms"] = cold_window(args, local_rank, params, host_pairs[0])
             out["approx_exp_variant"] = approx_variant_leg(args)
         if world == 1 and not args.no_cpu_baseline:
@@ -354,6 +398,45 @@ def worker(args):
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def verify_config3(args, rank, world, local_rank, params, dist, ctl):
+    """BASELINE configs[2] with a correctness bit: this rank's share of the 64 pairs (pair i -> rank i mod world: eppm_amd/shard.py;
+    seeds 1234 + i) goes through the host boundary of a batch context (eppm_batch_set_images / eppm_batch_compute) and the
+    sha256 of every flow is compared with tests/golden/MANIFEST_config3.json (the CPU oracle's flows, computed once in the build
+    container).  Rank 0 reports how many of the 64 verified; a mismatch is named on stderr."""
+    import hashlib as H
+    import numpy as np
+    import torch
+    import eppm_amd
+    from eppm_amd import shard, synth
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "MANIFEST_config3.json")))
+    w, h = man["w"], man["h"]
+    mine = shard.pairs_for_rank(man["n_pairs"], rank, world)
+    if (args.width, args.height, args.patch_r) != (w, h, 9):
+        return {"error": "the config-3 goldens are for 1024x436, patch_r 9"}
+    B = eppm_amd.EPPMBatch(h, w, 8, device=local_rank, params=params)
+    ok = bad_inputs = 0
+    t0 = time.perf_counter()
+    for g in range(0, len(mine), 8):
+        idx = mine[g:g + 8]
+        pairs = [synth.make_pair(h, w, seed=man["seed0"] + i)[:2] for i in idx]
+        B.set_data(pairs)
+        for i, (a, b), (u, v) in zip(idx, pairs, B.compute_flow()):
+            rec = man["pairs"][str(i)]
+            if H.sha256(a.tobytes()).hexdigest() != rec["img1_sha256"] or H.sha256(b.tobytes()).hexdigest() != rec["img2_sha256"]:
+                bad_inputs += 1          # numpy / libm of this host generates other images than the build container's: not a flow error
+            elif H.sha256(u.tobytes() + v.tobytes()).hexdigest() == rec["flow_sha256"]:
+                ok += 1
+            else:
+                print(f"[bench] rank {rank}: config-3 pair {i} (seed {man['seed0'] + i}): flow differs from the golden", file=sys.stderr)
+    dt = time.perf_counter() - t0
+    B.close()
+    t = torch.tensor([ok, bad_inputs, len(mine)], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(t, group=ctl)
+    return {"verified_pairs": int(t[0]), "pairs": int(t[2]), "inputs_differ_on_this_host": int(t[1]), "all_ok": int(t[0]) + int(t[1]) == int(t[2]) and int(t[2]) == man["n_pairs"],
+            "seconds_rank0_incl_synthesis": dt}
 
 
 def single_stream_legs(args, eng, inputs, pitch, pmc, alg_bytes):
@@ -384,11 +467,11 @@ def single_stream_legs(args, eng, inputs, pitch, pmc, alg_bytes):
     out = {"latency_ms_per_pair": float(np.median(lat)), "stage_ms": stage_ms}
     dom1 = (stage_ms["c2f_refine_L0"] + stage_ms["c2f_refine_L1"]) / 2
     out["roofline_single_stream"] = {"achieved": alg_bytes / (dom1 * 1e-3) / 1e9, "unit": "GB/s", "avg_launch_ms": dom1}
-    lv = pmc_levels(pmc, 1)
-    if lv and all(lv):
-        v = (lv[0]["valu_insts"] + lv[1]["valu_insts"]) / 2
-        out["valu_roofline"] = {"bound": "valu", "kernel": "k_c2f_refine_win (level 0) / k_c2f_refine_tiled<9,4> (level 1), one pair per launch, single stream", "wave64_valu_insts_per_launch": v,
-                                "achieved_insts_per_s": v / (dom1 * 1e-3), "peak_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
+    dp = dominant_pmc(pmc, 1)
+    if dp:
+        v = dp["valu_insts"] / 2
+        out["valu_roofline"] = {"bound": "valu", "kernel": "the candidate refine at one pair per launch, single stream (mean of its level-1 and level-0 launches)",
+                                "wave64_valu_insts_per_launch": v, "achieved_insts_per_s": v / (dom1 * 1e-3), "peak_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
                                 "frac": v / (dom1 * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S, "avg_launch_ms": dom1, "source": pmc.get("source")}
     else:
         out["valu_roofline"] = None
@@ -465,7 +548,13 @@ def cpu_baseline(w, h):
         O.compute_flow(a, b)
         tried[n] = time.perf_counter() - t0
     n_best = min(tried, key=tried.get)
-    dt = tried[n_best]
+    O.set_num_threads(n_best)
+    runs = [tried[n_best]]
+    for _ in range(4):                       # median of 5 runs at the best thread count
+        t0 = time.perf_counter()
+        O.compute_flow(a, b)
+        runs.append(time.perf_counter() - t0)
+    dt = float(sorted(runs)[len(runs) // 2])
     qh, qw = h // 2, w // 2
     qa, qb = a[h // 4:h // 4 + qh, w // 4:w // 4 + qw].copy(), b[h // 4:h // 4 + qh, w // 4:w // 4 + qw].copy()
     O.set_num_threads(1)
@@ -474,8 +563,9 @@ def cpu_baseline(w, h):
     dt1 = time.perf_counter() - t0
     O.set_num_threads(n_all)
     return {"value": w * h / dt / 1e6, "unit": "Mflow-vectors/s", "cores": n_best, "kind": "port",
-            "sample": f"1 pair {w}x{h} (the workload's own pair, seed 1234), whole path once, {dt:.1f} s, OpenMP oracle on {n_best} of "
-                      f"{ncpu} hardware threads (seconds by thread count: " + ", ".join(f"{k}: {v:.1f}" for k, v in tried.items()) + ")",
+            "sample": f"1 pair {w}x{h} (the workload's own pair, seed 1234), whole path, median of {len(runs)} runs = {dt:.2f} s (min {min(runs):.2f}, max "
+                      f"{max(runs):.2f}), OpenMP oracle on {n_best} of {ncpu} hardware threads (one run each by thread count: "
+                      + ", ".join(f"{k}: {v:.1f} s" for k, v in tried.items()) + ")",
             "single_thread": {"value": qw * qh / dt1 / 1e6, "unit": "Mflow-vectors/s", "cores": 1,
                               "sample": f"centre {qw}x{qh} crop of the same pair, whole path once, {dt1:.1f} s, one thread"}}
 

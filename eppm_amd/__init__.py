@@ -11,5 +11,5 @@ when the library is missing.
 """
 from .build import build, lib_path  # noqa: F401
 from ._lib import EppmError, lib  # noqa: F401
-from .api import EPPM, EPPMBatch, Params  # noqa: F401
+from .api import EPPM, EPPMBatch, Params, host_register, host_unregister, pinned_empty  # noqa: F401
 from . import io, stages  # noqa: F401

@@ -31,7 +31,9 @@ SYMBOLS = [
     "baoCudaBLFCostFilterRefine", "baoCudaFlowSmoothing", "eppm_flow_to_color", "eppm_compute_color",
     "eppm_pm_rng_create", "eppm_pm_rng_reset", "eppm_pm_rng_destroy", "eppm_pm_rng_block_states", "eppm_pm_gen_rand_field",
     "eppm_pm_cost_field", "eppm_pm_seg_propagate", "eppm_pm_jump_propagate", "eppm_pm_parallel_propagate", "eppm_pm_random_search", "eppm_gauss_filter_rgba", "eppm_resize_rgba",
-    "eppm_resize_flow", "eppm_probe_fast_exp", "eppm_probe_div_const",
+    "eppm_resize_flow", "eppm_probe_fast_exp", "eppm_probe_div_const", "eppm_test_set_option", "eppm_probe_c2f_window",
+    "eppm_host_register", "eppm_host_unregister", "eppm_host_is_registered", "eppm_host_alloc", "eppm_host_free",
+    "eppm_compute_begin_into", "eppm_batch_compute_begin_into",
     "eppm_load_ppm", "eppm_ppm_size", "eppm_save_flo", "eppm_load_flo", "eppm_flo_size", "eppm_flow_error",
 ]
 

@@ -24,6 +24,36 @@ def Params(**kw):
     return p
 
 
+def host_register(arr):
+    """Pin a numpy array's memory for DMA (eppm_host_register): set_data reads registered images, and compute_flow(out=...)
+    writes registered planes, over PCIe directly -- no staging copy.  Keep the array alive until host_unregister."""
+    check(lib().eppm_host_register(C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes)), "eppm_host_register")
+    return arr
+
+
+def host_unregister(arr):
+    check(lib().eppm_host_unregister(C.c_void_p(arr.ctypes.data)), "eppm_host_unregister")
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """A numpy array in pinned host memory from eppm_host_alloc (counts as registered); freed with the array."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    p = C.c_void_p()
+    check(lib().eppm_host_alloc(C.byref(p), C.c_size_t(max(n, 1))), "eppm_host_alloc")
+    addr = p.value
+
+    class _Owner:
+        def __del__(self):
+            try:
+                lib().eppm_host_free(C.c_void_p(addr))
+            except Exception:
+                pass
+    buf = (C.c_char * max(n, 1)).from_address(addr)
+    buf._owner = _Owner()
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 class EPPM:
     """``init`` / ``set_data`` / ``compute_flow`` as in bao_flow_patchmatch_multiscale_cuda.h:36-44.
 
@@ -63,11 +93,20 @@ class EPPM:
                                     C.c_size_t(self.w * 3)), "eppm_set_images")
         return True
 
-    def compute_flow(self):
-        """Returns (disp1_x, disp1_y) (driver .cpp:217-306)."""
+    def _out(self, out):
+        if out is None:
+            return np.empty((self.h, self.w), np.float32), np.empty((self.h, self.w), np.float32)
+        u, v = out
+        for a in (u, v):
+            if a.shape != (self.h, self.w) or a.dtype != np.float32 or not a.flags.c_contiguous:
+                raise EppmError(f"out planes must be C-contiguous ({self.h},{self.w}) float32")
+        return u, v
+
+    def compute_flow(self, out=None):
+        """Returns (disp1_x, disp1_y) (driver .cpp:217-306); out=(u, v): write into these planes (registered planes are written
+        by DMA directly, see host_register)."""
         self._need()
-        u = np.empty((self.h, self.w), np.float32)
-        v = np.empty((self.h, self.w), np.float32)
+        u, v = self._out(out)
         check(lib().eppm_compute(self._ctx, u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "eppm_compute")
         return u, v
 
@@ -79,16 +118,20 @@ class EPPM:
                                        C.c_float(max_disp[0]), C.c_float(max_disp[1])), "eppm_compute_color")
         return rgb
 
-    def compute_flow_begin(self):
-        """Enqueue compute_flow and its device-to-host copy, return at once (eppm_compute_begin)."""
+    def compute_flow_begin(self, out=None):
+        """Enqueue compute_flow and its device-to-host copy, return at once (eppm_compute_begin; with out=(u, v):
+        eppm_compute_begin_into, which lets registered planes receive the copy directly)."""
         self._need()
-        check(lib().eppm_compute_begin(self._ctx), "eppm_compute_begin")
+        if out is None:
+            check(lib().eppm_compute_begin(self._ctx), "eppm_compute_begin")
+        else:
+            u, v = self._out(out)
+            check(lib().eppm_compute_begin_into(self._ctx, u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "eppm_compute_begin_into")
 
-    def compute_flow_end(self):
+    def compute_flow_end(self, out=None):
         """Wait for compute_flow_begin; returns (disp1_x, disp1_y)."""
         self._need()
-        u = np.empty((self.h, self.w), np.float32)
-        v = np.empty((self.h, self.w), np.float32)
+        u, v = self._out(out)
         check(lib().eppm_compute_end(self._ctx, u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "eppm_compute_end")
         return u, v
 
@@ -194,25 +237,37 @@ class EPPMBatch:
               "eppm_batch_set_images_device")
         self.n = len(d1)
 
-    def _outs(self):
+    def _outs(self, out=None):
+        if out is not None:
+            u, v = [o[0] for o in out], [o[1] for o in out]
+            for a in u + v:
+                if a.shape != (self.h, self.w) or a.dtype != np.float32 or not a.flags.c_contiguous:
+                    raise EppmError(f"out planes must be C-contiguous ({self.h},{self.w}) float32")
+            if len(u) < self.n:
+                raise EppmError("out: one (u, v) per active pair")
+            return u[:self.n], v[:self.n]
         u = [np.empty((self.h, self.w), np.float32) for _ in range(self.n)]
         v = [np.empty((self.h, self.w), np.float32) for _ in range(self.n)]
         return u, v
 
-    def compute_flow(self):
-        """[(u, v)] for the active pairs."""
-        u, v = self._outs()
+    def compute_flow(self, out=None):
+        """[(u, v)] for the active pairs; out: list of (u, v) planes to write into (registered planes receive the DMA directly)."""
+        u, v = self._outs(out)
         check(lib().eppm_batch_compute(self._ctx, self._ptrs(u), self._ptrs(v)), "eppm_batch_compute")
         return list(zip(u, v))
 
     def compute_flow_device(self, d_flows=None):
         check(lib().eppm_batch_compute_device(self._ctx, self._ptrs(list(d_flows)) if d_flows is not None else None), "eppm_batch_compute_device")
 
-    def compute_flow_begin(self):
-        check(lib().eppm_compute_begin(self._ctx), "eppm_compute_begin")
+    def compute_flow_begin(self, out=None):
+        if out is None:
+            check(lib().eppm_compute_begin(self._ctx), "eppm_compute_begin")
+        else:
+            u, v = self._outs(out)
+            check(lib().eppm_batch_compute_begin_into(self._ctx, self._ptrs(u), self._ptrs(v)), "eppm_batch_compute_begin_into")
 
-    def compute_flow_end(self):
-        u, v = self._outs()
+    def compute_flow_end(self, out=None):
+        u, v = self._outs(out)
         check(lib().eppm_batch_compute_end(self._ctx, self._ptrs(u), self._ptrs(v)), "eppm_batch_compute_end")
         return list(zip(u, v))
 

@@ -8,8 +8,38 @@
 #include "../../include/bao_flow_patchmatch_multiscale_cuda.h"
 #include "../../include/eppm.h"
 
+// Caller blocks the object has seen (bao_alloc lays an image / a flow plane out as ONE contiguous block reachable through
+// row-pointer tables, bao_basic.h:124-162).  A block whose tables were verified pixel by pixel once is re-checked through its row
+// ends only; with set_option("pin_caller_buffers", 1) it is also registered for DMA (eppm_host_register), so that the copy
+// engine reads / writes the caller's memory and no host copy remains.
+namespace {
+struct SeenBlock { const void* table; const void* base; size_t bytes; bool pinned; };
+struct ClassPriv {
+    SeenBlock blk[8];
+    int n = 0, next = 0;
+    bool pin = false;
+};
+void release_block(SeenBlock& b)
+{
+    if (b.pinned) eppm_host_unregister((void*)b.base);
+    b = SeenBlock{NULL, NULL, 0, false};
+}
+// remembers (table, base); registers the block when pinning is on.  Returns true when the block was verified before.
+bool seen(ClassPriv* pr, const void* table, const void* base, size_t bytes, bool add)
+{
+    for (int i = 0; i < pr->n; i++)
+        if (pr->blk[i].table == table && pr->blk[i].base == base && pr->blk[i].bytes == bytes) return true;
+    if (!add) return false;
+    int slot = pr->n < 8 ? pr->n++ : (pr->next++ & 7);
+    if (pr->blk[slot].base) release_block(pr->blk[slot]);
+    pr->blk[slot] = SeenBlock{table, base, bytes, false};
+    if (pr->pin && eppm_host_register((void*)base, bytes) == EPPM_OK) pr->blk[slot].pinned = true;
+    return false;
+}
+}  // namespace
+
 bao_flow_patchmatch_multiscale_cuda::bao_flow_patchmatch_multiscale_cuda()
-    : m_h(0), m_w(0), m_device(0), m_ctx(NULL), m_params(NULL), m_stage(NULL), m_u(NULL), m_v(NULL)
+    : m_h(0), m_w(0), m_device(0), m_ctx(NULL), m_params(NULL), m_stage(NULL), m_u(NULL), m_v(NULL), m_priv(new ClassPriv())
 {
     eppm_params* p = (eppm_params*)malloc(sizeof(eppm_params));
     if (p) eppm_default_params(p);
@@ -20,6 +50,7 @@ bao_flow_patchmatch_multiscale_cuda::~bao_flow_patchmatch_multiscale_cuda()
 {
     _destroy();
     free(m_params);
+    delete (ClassPriv*)m_priv;
 }
 
 bool bao_flow_patchmatch_multiscale_cuda::set_option(const char* name, long long value)
@@ -35,6 +66,7 @@ bool bao_flow_patchmatch_multiscale_cuda::set_option(const char* name, long long
     else if (!strcmp(name, "seed")) p->seed = (unsigned long long)value;
     else if (!strcmp(name, "propagation")) p->propagation = (int)value;
     else if (!strcmp(name, "levels")) p->levels = (int)value;
+    else if (!strcmp(name, "pin_caller_buffers")) ((ClassPriv*)m_priv)->pin = (value != 0);
     else return false;
     return true;
 }
@@ -43,6 +75,9 @@ void bao_flow_patchmatch_multiscale_cuda::_destroy()
 {
     if (m_ctx) eppm_destroy(m_ctx);
     m_ctx = NULL;
+    ClassPriv* pr = (ClassPriv*)m_priv;
+    for (int i = 0; i < pr->n; i++) release_block(pr->blk[i]);
+    pr->n = pr->next = 0;
     free(m_stage); free(m_u); free(m_v);
     m_stage = NULL; m_u = NULL; m_v = NULL;
 }
@@ -64,35 +99,47 @@ void bao_flow_patchmatch_multiscale_cuda::init(int h, int w)
         m_ctx = NULL;
         return;
     }
-    m_stage = (unsigned char*)malloc((size_t)h * w * 3 * 2);
-    m_u = (float*)malloc(sizeof(float) * h * w);
-    m_v = (float*)malloc(sizeof(float) * h * w);
+}
+
+// The image as one contiguous h*w*3 block, or NULL when the row-pointer tables describe any other layout.  img[i][j] points at
+// pixel (i,j)'s three bytes (bao_alloc<unsigned char>(h,w,3), bao_basic.h:146-162); every pointer is checked the first time a
+// table is seen, afterwards both ends of every row.
+static const unsigned char* contiguous_rgb(void* priv, unsigned char*** img, int h, int w)
+{
+    ClassPriv* pr = (ClassPriv*)priv;
+    const unsigned char* base = img[0][0];
+    const size_t row = (size_t)w * 3;
+    for (int i = 0; i < h; i++)
+        if (img[i][0] != base + (size_t)i * row || img[i][w - 1] != base + (size_t)i * row + (size_t)3 * (w - 1)) return NULL;
+    if (seen(pr, img, base, row * h, false)) return base;
+    for (int i = 0; i < h; i++) {
+        unsigned char** r = img[i];
+        const unsigned char* b = base + (size_t)i * row;
+        for (int j = 1; j < w - 1; j++)
+            if (r[j] != b + (size_t)3 * j) return NULL;
+    }
+    seen(pr, img, base, row * h, true);
+    return base;
 }
 
 // driver .cpp:159-168 (bao_rgb2rgba indexes through the row tables, bao_basic_cuda.h:258-267)
 bool bao_flow_patchmatch_multiscale_cuda::set_data(unsigned char*** img1, unsigned char*** img2)
 {
     if (!m_ctx || !img1 || !img2) return false;
-    unsigned char* a = m_stage;
-    unsigned char* b = m_stage + (size_t)m_h * m_w * 3;
-    // img[i][j] points at pixel (i,j)'s three bytes; bao_alloc lays a row out contiguously (bao_basic.h:146-162), which is
-    // checked per row -- then the row is one memcpy; any other layout goes through the pointers as bao_rgb2rgba does
-    auto gather = [&](unsigned char* dst, unsigned char*** img) {
-        for (int i = 0; i < m_h; i++) {
-            unsigned char** row = img[i];
-            const unsigned char* base = row[0];
-            bool contiguous = true;
-            for (int j = 1; j < m_w; j++)
-                if (row[j] != base + (size_t)3 * j) { contiguous = false; break; }
-            unsigned char* d = dst + (size_t)i * m_w * 3;
-            if (contiguous) memcpy(d, base, (size_t)m_w * 3);
-            else
+    const unsigned char* a = contiguous_rgb(m_priv, img1, m_h, m_w);
+    const unsigned char* b = contiguous_rgb(m_priv, img2, m_h, m_w);
+    if (!a || !b) {
+        // any other layout goes through the pointers, as bao_rgb2rgba does, into a contiguous staging image
+        if (!m_stage) m_stage = (unsigned char*)malloc((size_t)m_h * m_w * 3 * 2);
+        if (!m_stage) return false;
+        auto gather = [&](unsigned char* dst, unsigned char*** img) {
+            for (int i = 0; i < m_h; i++)
                 for (int j = 0; j < m_w; j++)
-                    for (int c = 0; c < 3; c++) d[(size_t)j * 3 + c] = row[j][c];
-        }
-    };
-    gather(a, img1);
-    gather(b, img2);
+                    for (int c = 0; c < 3; c++) dst[((size_t)i * m_w + j) * 3 + c] = img[i][j][c];
+        };
+        if (!a) { gather(m_stage, img1); a = m_stage; }
+        if (!b) { gather(m_stage + (size_t)m_h * m_w * 3, img2); b = m_stage + (size_t)m_h * m_w * 3; }
+    }
     if (eppm_set_images(m_ctx, a, b, (size_t)m_w * 3) != EPPM_OK) {
         fprintf(stderr, "bao_flow_patchmatch_multiscale_cuda::set_data: %s\n", eppm_last_error());
         return false;
@@ -100,20 +147,41 @@ bool bao_flow_patchmatch_multiscale_cuda::set_data(unsigned char*** img1, unsign
     return true;
 }
 
+// disp[i] is a row of w floats; bao_alloc<float>(h,w) makes the rows one contiguous block (bao_basic.h:124-133)
+static float* contiguous_plane(void* priv, float** disp, int h, int w)
+{
+    for (int i = 1; i < h; i++)
+        if (disp[i] != disp[0] + (size_t)i * w) return NULL;
+    seen((ClassPriv*)priv, disp, disp[0], sizeof(float) * h * w, true);
+    return disp[0];
+}
+
 // driver .cpp:217-315
 void bao_flow_patchmatch_multiscale_cuda::compute_flow(float** disp1_x, float** disp1_y, unsigned char*** color_flow)
 {
     if (!m_ctx || !disp1_x || !disp1_y) return;
-    if (eppm_compute(m_ctx, m_u, m_v) != EPPM_OK) {
+    float* u = contiguous_plane(m_priv, disp1_x, m_h, m_w);
+    float* v = contiguous_plane(m_priv, disp1_y, m_h, m_w);
+    const bool direct = (u && v);
+    if (!direct) {
+        if (!m_u) m_u = (float*)malloc(sizeof(float) * m_h * m_w);
+        if (!m_v) m_v = (float*)malloc(sizeof(float) * m_h * m_w);
+        if (!m_u || !m_v) return;
+        u = m_u; v = m_v;
+    }
+    if (eppm_compute(m_ctx, u, v) != EPPM_OK) {
         fprintf(stderr, "bao_flow_patchmatch_multiscale_cuda::compute_flow: %s\n", eppm_last_error());
         return;
     }
-    for (int i = 0; i < m_h; i++) {                          // disp[i] is a row of w floats (bao_alloc<float>(h,w), bao_basic.h:124-133)
-        memcpy(disp1_x[i], m_u + (size_t)i * m_w, sizeof(float) * m_w);
-        memcpy(disp1_y[i], m_v + (size_t)i * m_w, sizeof(float) * m_w);
-    }
+    if (!direct)
+        for (int i = 0; i < m_h; i++) {
+            memcpy(disp1_x[i], m_u + (size_t)i * m_w, sizeof(float) * m_w);
+            memcpy(disp1_y[i], m_v + (size_t)i * m_w, sizeof(float) * m_w);
+        }
     if (color_flow != NULL) {
         // bao_cuda_convert_flow_to_colorshow(d_colorflow, flow, h, w, 20, 20) on the device flow, D2H, bao_rgba2rgb: driver .cpp:308-314
+        if (!m_stage) m_stage = (unsigned char*)malloc((size_t)m_h * m_w * 3 * 2);
+        if (!m_stage) return;
         unsigned char* rgb = m_stage;          // h*w*3 of the RGB staging buffer
         if (eppm_compute_color(m_ctx, rgb, (size_t)m_w * 3, 20, 20) != EPPM_OK) {
             fprintf(stderr, "bao_flow_patchmatch_multiscale_cuda::compute_flow (color): %s\n", eppm_last_error());

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -105,6 +106,68 @@ static int pyr_init_dim(int* arrH, int* arrW, int h, int w, int maxDepth, double
         arrW[i] = int(double(w) * pow(ratio, i));
     }
     return n;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// caller memory pinned for DMA (eppm_host_register / eppm_host_alloc): set_images reads registered images and compute
+// writes registered flow planes directly over PCIe -- no staging copy on either side (set_data / compute_flow's cudaMemcpy
+// legs, driver :159-168, :299-306, read and write the caller's memory too)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct HostBlock { size_t bytes; bool owned; };
+std::mutex g_reg_mu;
+std::map<uintptr_t, HostBlock> g_reg;
+bool host_registered(const void* p, size_t bytes)
+{
+    if (!p) return false;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_reg.upper_bound((uintptr_t)p);
+    if (it == g_reg.begin()) return false;
+    --it;
+    return (uintptr_t)p + bytes <= it->first + it->second.bytes;
+}
+}  // namespace
+
+extern "C" int eppm_host_register(void* p, size_t bytes)
+{
+    if (!p || !bytes) return set_err(EPPM_ERR_ARG, "eppm_host_register: NULL or empty block");
+    if (host_registered(p, bytes)) return EPPM_OK;
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterPortable));
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_reg[(uintptr_t)p] = HostBlock{bytes, false};
+    return EPPM_OK;
+}
+extern "C" int eppm_host_unregister(void* p)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_reg.find((uintptr_t)p);
+        if (it == g_reg.end() || it->second.owned) return set_err(EPPM_ERR_ARG, "eppm_host_unregister: not a block registered with eppm_host_register");
+        g_reg.erase(it);
+    }
+    HIPCHK(hipHostUnregister(p));
+    return EPPM_OK;
+}
+extern "C" int eppm_host_is_registered(const void* p, size_t bytes) { return host_registered(p, bytes) ? 1 : 0; }
+extern "C" int eppm_host_alloc(void** p, size_t bytes)
+{
+    if (!p || !bytes) return set_err(EPPM_ERR_ARG, "eppm_host_alloc: NULL or empty block");
+    HIPCHK(hipHostMalloc(p, bytes, hipHostMallocPortable));
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_reg[(uintptr_t)*p] = HostBlock{bytes, true};
+    return EPPM_OK;
+}
+extern "C" int eppm_host_free(void* p)
+{
+    if (!p) return EPPM_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_reg.find((uintptr_t)p);
+        if (it == g_reg.end() || !it->second.owned) return set_err(EPPM_ERR_ARG, "eppm_host_free: not a block from eppm_host_alloc");
+        g_reg.erase(it);
+    }
+    HIPCHK(hipHostFree(p));
+    return EPPM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -214,6 +277,7 @@ struct eppm_ctx {
     void *pk1[kMaxLevels] = {}, *pk2[kMaxLevels] = {};       // float4 texel planes {r,g,b,census}, linear (pitch = w)
     int16_t *nnf1 = nullptr, *nnf2 = nullptr, *nnf_tmp = nullptr, *nnf_tmp2 = nullptr;
     float *cost1 = nullptr, *cost2 = nullptr;
+    float *spec1 = nullptr, *spec2 = nullptr;   // speculative sweeps: cost of every pixel's rejection-path candidate (phase A)
     uint32_t* wmf_ws = nullptr;        // work lists + counters of the weighted median
     bool flow_pending = false;         // eppm_compute_begin issued, eppm_compute_end not yet
     float *flow[kMaxLevels] = {}, *flow_tmp[kMaxLevels] = {};
@@ -224,8 +288,15 @@ struct eppm_ctx {
     uint32_t* d_color = nullptr;        // colour-coded flow (optional output), in the slab
     uint32_t* h_color = nullptr;        // pinned, allocated on first use
     uint8_t* d_rgb = nullptr;           // staging for host RGB input (both frames), in the slab
-    uint8_t* h_rgb = nullptr;           // pinned, npairs x both frames
-    float* h_flow = nullptr;            // pinned, npairs x (u plane | v plane)
+    // pinned staging for images / flows in memory the caller did NOT register (eppm_host_register), allocated on the first such
+    // call; the image staging is double-buffered (an event per buffer marks its H2D done), so staging pair i+1 never waits for
+    // the stream to drain
+    uint8_t* h_rgb[2] = {nullptr, nullptr};   // each npairs x both frames
+    hipEvent_t ev_rgb[2] = {nullptr, nullptr};
+    hipEvent_t ev_h2d = nullptr;        // marks the DMA reads of registered caller images
+    int rgb_cur = 0;
+    float* h_flow = nullptr;            // npairs x (u plane | v plane)
+    std::vector<float*> out_u, out_v;   // per active pair: where eppm_compute_begin_into sent the planes directly (NULL: staging)
     bool have_images = false, have_flow = false;
     int timing = 0;                     // 0 off, 1 every stage, 2 only the dominant kernel (the candidate refine)
     std::vector<StageEv> ev;
@@ -285,7 +356,11 @@ extern "C" int eppm_destroy(eppm_ctx* c)
     (void)hipFree(c->slab);
     (void)hipFree(c->lut_pm); (void)hipFree(c->lut_wmf); (void)hipFree(c->lut_blf);
     if (c->h_color) (void)hipHostFree(c->h_color);
-    if (c->h_rgb) (void)hipHostFree(c->h_rgb);
+    for (int q = 0; q < 2; q++) {
+        if (c->h_rgb[q]) (void)hipHostFree(c->h_rgb[q]);
+        if (c->ev_rgb[q]) (void)hipEventDestroy(c->ev_rgb[q]);
+    }
+    if (c->ev_h2d) (void)hipEventDestroy(c->ev_h2d);
     if (c->h_flow) (void)hipHostFree(c->h_flow);
     rng_free(c->rng);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -337,6 +412,8 @@ static int ctx_alloc(eppm_ctx* c)
     plane((void**)&c->nnf_tmp2, n2 * 4);
     plane((void**)&c->cost1, n2 * 4);
     plane((void**)&c->cost2, n2 * 4);
+    plane((void**)&c->spec1, n2 * 4);
+    plane((void**)&c->spec2, n2 * 4);
     plane((void**)&c->wmf_ws, wmf_workspace_words(c->W[L], c->H[L], c->prm.wmf_iters) * 4);
     plane((void**)&c->d_rgb, (size_t)h * w * 3 * 2);
     plane((void**)&c->d_color, (size_t)h * w * 4);
@@ -353,8 +430,8 @@ static int ctx_alloc(eppm_ctx* c)
     host_pm_lut(c->prm.patch_r, v);  CHK(upload_lut(&c->lut_pm, v));
     host_wmf_lut(v);                 CHK(upload_lut(&c->lut_wmf, v));
     host_blf_lut(v);                 CHK(upload_lut(&c->lut_blf, v));
-    HIPCHK(hipHostMalloc((void**)&c->h_rgb, (size_t)h * w * 3 * 2 * c->npairs, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&c->h_flow, (size_t)h * w * 8 * c->npairs, hipHostMallocDefault));
+    c->out_u.assign(c->npairs, nullptr);
+    c->out_v.assign(c->npairs, nullptr);
     return EPPM_OK;
 }
 
@@ -469,28 +546,62 @@ static int prepare(eppm_ctx* c)
     return EPPM_OK;
 }
 
-// host RGB of pairs 0..n-1 -> pinned staging -> ONE H2D -> RGBA planes (bao_rgb2rgba, alpha = 0) -> prepare
+// host RGB of pairs 0..n-1 -> H2D -> RGBA planes (bao_rgb2rgba, alpha = 0) -> prepare.  An image inside memory registered with
+// eppm_host_register / eppm_host_alloc is read by the copy engine where it lies; any other image goes through the context's pinned
+// staging (one host copy), which is double-buffered.
 static int set_images_host(eppm_ctx* c, int n, const uint8_t* const* rgb1, const uint8_t* const* rgb2, size_t row_stride)
 {
     if (row_stride < (size_t)c->w * 3) return set_err(EPPM_ERR_ARG, "eppm_set_images: row_stride %zu < 3*w", row_stride);
     HIPCHK(hipSetDevice(c->device));
-    const size_t row = (size_t)c->w * 3, img = row * c->h;
-    HIPCHK(hipStreamSynchronize(c->stream));       // the pinned staging buffer may still be in flight
-    for (int k = 0; k < n; k++) {
+    const size_t row = (size_t)c->w * 3, img = row * c->h, span = row_stride * (c->h - 1) + row;
+    for (int k = 0; k < n; k++)
         if (!rgb1[k] || !rgb2[k]) return set_err(EPPM_ERR_ARG, "eppm_set_images: NULL image");
-        uint8_t* dst = c->h_rgb + (size_t)k * img * 2;
-        for (int y = 0; y < c->h; y++) {
-            memcpy(dst + (size_t)y * row, rgb1[k] + (size_t)y * row_stride, row);
-            memcpy(dst + img + (size_t)y * row, rgb2[k] + (size_t)y * row_stride, row);
+    uint8_t* stage = nullptr;
+    bool staged = false, direct = false;
+    for (int k = 0; k < n; k++)
+        for (int f = 0; f < 2; f++) {
+            const uint8_t* src = f ? rgb2[k] : rgb1[k];
+            uint8_t* dst = c->of_pair(c->d_rgb, k) + (size_t)f * img;
+            if (host_registered(src, span)) {
+                if (row_stride == row) HIPCHK(hipMemcpyAsync(dst, src, img, hipMemcpyHostToDevice, c->stream));
+                else HIPCHK(hipMemcpy2DAsync(dst, row, src, row_stride, row, c->h, hipMemcpyHostToDevice, c->stream));
+                direct = true;
+                continue;
+            }
+            if (!stage) {
+                const int q = c->rgb_cur;
+                if (!c->h_rgb[q]) {
+                    HIPCHK(hipHostMalloc((void**)&c->h_rgb[q], img * 2 * c->npairs, hipHostMallocDefault));
+                    HIPCHK(hipEventCreateWithFlags(&c->ev_rgb[q], hipEventDisableTiming));
+                } else {
+                    HIPCHK(hipEventSynchronize(c->ev_rgb[q]));      // the H2D that last read this buffer (two set_images ago)
+                }
+                stage = c->h_rgb[q];
+            }
+            uint8_t* h = stage + ((size_t)k * 2 + f) * img;
+            if (row_stride == row) memcpy(h, src, img);
+            else
+                for (int y = 0; y < c->h; y++) memcpy(h + (size_t)y * row, src + (size_t)y * row_stride, row);
+            HIPCHK(hipMemcpyAsync(dst, h, img, hipMemcpyHostToDevice, c->stream));
+            staged = true;
         }
+    if (staged) {
+        HIPCHK(hipEventRecord(c->ev_rgb[c->rgb_cur], c->stream));
+        c->rgb_cur ^= 1;
+    }
+    if (direct) {
+        if (!c->ev_h2d) HIPCHK(hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->ev_h2d, c->stream));
     }
     c->n_active = n;
-    for (int k = 0; k < n; k++)       // one copy per pair (the slab stride may exceed what a 2-D copy accepts as a pitch)
-        HIPCHK(hipMemcpyAsync(c->of_pair(c->d_rgb, k), c->h_rgb + (size_t)k * img * 2, img * 2, hipMemcpyHostToDevice, c->stream));
     const int p0 = (int)(c->raw_pitch / 4);
     launch_rgb_to_rgba(c->raw1, p0, c->d_rgb, c->h, c->w, c->stream, c->bt());
     launch_rgb_to_rgba(c->raw2, p0, c->d_rgb + img, c->h, c->w, c->stream, c->bt());
-    return prepare(c);
+    const int r = prepare(c);
+    // set_data's contract (a synchronous cudaMemcpy in the reference, driver :165-166): when the call returns the caller may reuse
+    // its images.  Staged images were copied above; for images read in place, wait for their DMA (the kernels are queued already).
+    if (direct) HIPCHK(hipEventSynchronize(c->ev_h2d));
+    return r;
 }
 
 extern "C" int eppm_set_images(eppm_ctx* c, const uint8_t* rgb1, const uint8_t* rgb2, size_t row_stride)
@@ -535,10 +646,10 @@ extern "C" int eppm_batch_set_images_device(eppm_ctx* c, int n, const void* cons
 }
 
 // ---- baoCudaPatchMatch (kernel.cu:1760-1826) for one problem or for the forward+backward pair at once ----
-static PmProblem mk_problem(const PlanesH& P, float* cost, int16_t* nnf, int16_t* nnf_alt, eppm_pm_rng* rng, int k)
+static PmProblem mk_problem(const PlanesH& P, float* cost, int16_t* nnf, int16_t* nnf_alt, eppm_pm_rng* rng, int k, float* spec = nullptr)
 {
     PmProblem p;
-    p.P = P; p.cost = cost; p.nnf = nnf; p.nnf_alt = nnf_alt;
+    p.P = P; p.cost = cost; p.nnf = nnf; p.nnf_alt = nnf_alt; p.spec = spec;
     p.rng_work = rng ? rng->work[k][rng->cur[k]] : nullptr;
     p.rng_work_next = rng ? rng->work[k][rng->cur[k] ^ 1] : nullptr;
     return p;
@@ -552,10 +663,22 @@ static void search(PmBatch& b, eppm_pm_rng* rng, const float* lut, const eppm_pa
         rng->cur[k] ^= 1;
     }
 }
-// one directional sweep on the batch; keeps the result in p[k].nnf (swaps the ping-pong pair when needed)
-static void sweep(PmBatch& b, const float* lut, const eppm_params& prm, int dir, hipStream_t s)
+// The sweeps of an iteration run in the speculative two-launch form (k_patchmatch.hip: k_pm_sweep_spec + phase B) once few
+// candidates are still accepted: from the third iteration on fewer than one step in ten follows an accepted candidate
+// (tools/sweep_stats.py), and a step that follows a rejection needs no dependent evaluation.  Same results either way.
+#ifndef EPPM_SPEC_FROM_ITER
+#define EPPM_SPEC_FROM_ITER 3
+#endif
+static std::atomic<int> g_sweep_spec{-1};      // test support ("sweep_spec"): -1 by iteration, 0 never, 1 always
+static bool sweep_speculative(int iteration)
 {
-    if (launch_pm_sweep(b, lut, prm.patch_r, prm.seg_len, dir, s))
+    const int m = g_sweep_spec.load();
+    return m < 0 ? iteration >= EPPM_SPEC_FROM_ITER : m != 0;
+}
+// one directional sweep on the batch; keeps the result in p[k].nnf (swaps the ping-pong pair when needed)
+static void sweep(PmBatch& b, const float* lut, const eppm_params& prm, int dir, hipStream_t s, bool speculative = false)
+{
+    if (launch_pm_sweep(b, lut, prm.patch_r, prm.seg_len, dir, s, speculative))
         for (int k = 0; k < b.n; k++) std::swap(b.p[k].nnf, b.p[k].nnf_alt);
 }
 // baoJumpPropagate: six Jacobi launches (kernel.cu:849-854); an even number of swaps
@@ -583,7 +706,7 @@ static void run_patchmatch(PmBatch& b, eppm_pm_rng* rng, const float* lut, const
     for (int it = 0; it < prm.num_iter; it++) {
         if (prm.propagation == 1) jump(b, lut, prm, s);
         else if (prm.propagation == 2) neighbor(b, lut, prm, 10, s);
-        else for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s);
+        else for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s, sweep_speculative(it));
         search(b, rng, lut, prm, s);
     }
 }
@@ -602,8 +725,8 @@ static int compute_all(eppm_ctx* c)
     {
         PmBatch b;
         b.n = 2; b.cpitch = lw; b.npitch = lw; b.npairs = bt.n; b.stride = bt.stride;
-        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0);     // driver :223
-        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1);     // driver :224
+        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0, c->spec1);     // driver :223
+        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1, c->spec2);     // driver :224
         run_patchmatch(b, c->rng, c->lut_pm, c->prm, s);
     }
     stage_end(c, c->ev);
@@ -663,18 +786,49 @@ extern "C" int eppm_batch_compute_device(eppm_ctx* c, void* const* d_flows)
     return EPPM_OK;
 }
 
-// compute_flow split in two so that a host thread can keep several contexts in flight: begin enqueues the whole
-// path and the device-to-host copy into the context's pinned buffer and returns; end waits and de-interleaves.
+// compute_flow split in two so that a host thread can keep several contexts in flight: begin enqueues the whole path, the
+// de-interleave (on the device) and the device-to-host copies and returns; end waits.  When begin knows the destination planes
+// and they lie in registered memory, the copy engine writes them directly; otherwise the planes land in the context's pinned
+// staging and end copies them out.
+static int compute_begin(eppm_ctx* c, int n_out, float* const* u, float* const* v)
+{
+    CHK(compute_all(c));
+    const size_t n = (size_t)c->h * c->w;
+    launch_split_flow(c->d_uv, c->flow[0], (int)n, c->stream, c->bt());                                                           // driver :302-306, on the device
+    for (int k = 0; k < c->n_active; k++) {                                                                                       // driver :299
+        float* du = (u && k < n_out) ? u[k] : nullptr;
+        float* dv = (v && k < n_out) ? v[k] : nullptr;
+        const float* src = c->of_pair(c->d_uv, k);
+        if (du && dv && host_registered(du, n * 4) && host_registered(dv, n * 4)) {
+            HIPCHK(hipMemcpyAsync(du, src, n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(dv, src + n, n * 4, hipMemcpyDeviceToHost, c->stream));
+            c->out_u[k] = du; c->out_v[k] = dv;
+            continue;
+        }
+        if (!c->h_flow) HIPCHK(hipHostMalloc((void**)&c->h_flow, n * 8 * c->npairs, hipHostMallocDefault));
+        HIPCHK(hipMemcpyAsync(c->h_flow + (size_t)k * n * 2, src, n * 8, hipMemcpyDeviceToHost, c->stream));
+        c->out_u[k] = c->out_v[k] = nullptr;
+    }
+    c->flow_pending = true;
+    return EPPM_OK;
+}
+
 extern "C" int eppm_compute_begin(eppm_ctx* c)
 {
     if (!c) return set_err(EPPM_ERR_ARG, "eppm_compute_begin: NULL ctx");
-    CHK(compute_all(c));
-    const size_t n = (size_t)c->h * c->w;
-    launch_split_flow(c->d_uv, c->flow[0], (int)n, c->stream, c->bt());                                                          // driver :302-306, on the device
-    for (int k = 0; k < c->n_active; k++)                                                                                         // driver :299
-        HIPCHK(hipMemcpyAsync(c->h_flow + (size_t)k * n * 2, c->of_pair(c->d_uv, k), n * 8, hipMemcpyDeviceToHost, c->stream));
-    c->flow_pending = true;
-    return EPPM_OK;
+    return compute_begin(c, 0, nullptr, nullptr);
+}
+
+extern "C" int eppm_compute_begin_into(eppm_ctx* c, float* u, float* v)
+{
+    if (!c || !u || !v) return set_err(EPPM_ERR_ARG, "eppm_compute_begin_into: NULL argument");
+    return compute_begin(c, 1, &u, &v);
+}
+
+extern "C" int eppm_batch_compute_begin_into(eppm_ctx* c, float* const* u, float* const* v)
+{
+    if (!c || !u || !v) return set_err(EPPM_ERR_ARG, "eppm_batch_compute_begin_into: NULL argument");
+    return compute_begin(c, c->n_active, u, v);
 }
 
 static int compute_end(eppm_ctx* c, int n_out, float* const* u, float* const* v)
@@ -684,11 +838,13 @@ static int compute_end(eppm_ctx* c, int n_out, float* const* u, float* const* v)
     HIPCHK(hipStreamSynchronize(c->stream));
     c->flow_pending = false;
     const size_t n = (size_t)c->h * c->w;
-    for (int k = 0; k < n_out; k++) {
+    for (int k = 0; k < n_out && k < c->n_active; k++) {
         if (!u[k] || !v[k]) continue;
-        const float* f = c->h_flow + (size_t)k * n * 2;          // u plane, then v plane (k_split_flow)
-        memcpy(u[k], f, n * sizeof(float));
-        memcpy(v[k], f + n, n * sizeof(float));
+        // the planes are in the caller's memory already (begin_into, registered), or in the staging buffer: u plane, then v plane
+        const float* fu = c->out_u[k] ? c->out_u[k] : c->h_flow + (size_t)k * n * 2;
+        const float* fv = c->out_v[k] ? c->out_v[k] : c->h_flow + (size_t)k * n * 2 + n;
+        if (u[k] != fu) memcpy(u[k], fu, n * sizeof(float));
+        if (v[k] != fv) memcpy(v[k], fv, n * sizeof(float));
     }
     return EPPM_OK;
 }
@@ -708,15 +864,15 @@ extern "C" int eppm_batch_compute_end(eppm_ctx* c, float* const* u, float* const
 extern "C" int eppm_compute(eppm_ctx* c, float* u, float* v)
 {
     if (!c || !u || !v) return set_err(EPPM_ERR_ARG, "eppm_compute: NULL argument");
-    CHK(eppm_compute_begin(c));
-    return eppm_compute_end(c, u, v);
+    CHK(compute_begin(c, 1, &u, &v));
+    return compute_end(c, 1, &u, &v);
 }
 
 extern "C" int eppm_batch_compute(eppm_ctx* c, float* const* u, float* const* v)
 {
     if (!c || !u || !v) return set_err(EPPM_ERR_ARG, "eppm_batch_compute: NULL argument");
-    CHK(eppm_compute_begin(c));
-    return eppm_batch_compute_end(c, u, v);
+    CHK(compute_begin(c, c->n_active, u, v));
+    return compute_end(c, c->n_active, u, v);
 }
 
 extern "C" int eppm_synchronize(eppm_ctx* c)
@@ -808,8 +964,8 @@ namespace {
 struct DevState {
     float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
     int lut_R = -1;
-    void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    void* scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[5] = {0, 0, 0, 0, 0};
     std::map<std::tuple<int, int, int, unsigned long long>, eppm_pm_rng*> rngs;
 };
 std::mutex g_mu;
@@ -957,9 +1113,12 @@ extern "C" int eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const ep
     b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
     PlanesH P;
     CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
-    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0);
+    void* spec = nullptr;
+    const bool speculative = g_sweep_spec.load() == 1;         // the stand-alone entry point has no iteration count: classic unless forced
+    if (speculative) CHK(get_scratch(ds, cost_pitch * h, &spec, 4));
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0, (float*)spec);
     for (int d = 0; d < 4; d++)
-        if (dir < 0 || dir == d) sweep(b, ds->lut_pm, g_prm, d, g_stream);
+        if (dir < 0 || dir == d) sweep(b, ds->lut_pm, g_prm, d, g_stream, speculative);
     if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
     return finish();
 }
@@ -1041,6 +1200,20 @@ static int probe(const float* x, float* y, int n, int which)
     (void)hipFree(dx); (void)hipFree(dy);
     return finish();
 }
+// ---- test support ----
+extern "C" int eppm_test_set_option(const char* name, int value)
+{
+    if (!name) return set_err(EPPM_ERR_ARG, "eppm_test_set_option: NULL name");
+    if (!strcmp(name, "c2f_no_split")) { c2f_set_no_split(value); return EPPM_OK; }
+    if (!strcmp(name, "sweep_spec")) { g_sweep_spec.store(value); return EPPM_OK; }
+    return set_err(EPPM_ERR_ARG, "eppm_test_set_option: unknown option '%s'", name);
+}
+extern "C" int eppm_probe_c2f_window(int patch_r, int* span_x, int* span_y)
+{
+    if (!span_x || !span_y) return set_err(EPPM_ERR_ARG, "eppm_probe_c2f_window: NULL argument");
+    if (!c2f_window_span(patch_r, span_x, span_y)) return set_err(EPPM_ERR_ARG, "no LDS-window refine kernel for patch_r %d", patch_r);
+    return EPPM_OK;
+}
 extern "C" int eppm_probe_fast_exp(const float* x, float* y, int n) { return probe(x, y, n, 0); }
 extern "C" int eppm_probe_div_const(const float* x, float* y, int n, int which) { return probe(x, y, n, 1 + which); }
 
@@ -1109,7 +1282,10 @@ extern "C" void baoCudaPatchMatch(eppm_short2* d_disp_vec, float* d_cost, eppm_u
     PlanesH P;
     g_launch_status = mk_planes(ds, &P, d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch);
     if (g_launch_status != EPPM_OK) return;
-    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0);
+    void* spec = nullptr;
+    g_launch_status = get_scratch(ds, cost_pitch * h, &spec, 4);
+    if (g_launch_status != EPPM_OK) return;
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0, (float*)spec);
     run_patchmatch(b, r, ds->lut_pm, g_prm, g_stream);
     if (b.p[0].nnf != (int16_t*)d_disp_vec && (g_launch_status = copy_d2d(d_disp_vec, b.p[0].nnf, disp_pitch * h)) != EPPM_OK) return;
     g_launch_status = finish();
@@ -1214,7 +1390,8 @@ extern "C" void baoCudaFlowSmoothing(eppm_float2* d_flow, eppm_uchar4* d_img, in
 extern "C" int eppm_flow_to_color(eppm_uchar4* d_rgba, const eppm_float2* d_flow, int h, int w, float max_disp_x, float max_disp_y)
 {
     if (!d_rgba || !d_flow || h < 1 || w < 1) return set_err(EPPM_ERR_ARG, "eppm_flow_to_color: bad argument");
-    std::lock_guard<std::mutex> lk(g_mu);
+    LAUNCHER_BEGIN_INT;
+    (void)ds;
     launch_flow_to_color((uint32_t*)d_rgba, (const float*)d_flow, h, w, max_disp_x, max_disp_y, g_stream);
     return finish();
 }

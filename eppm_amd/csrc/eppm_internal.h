@@ -61,6 +61,7 @@ struct PmProblem {
     float* cost;
     int16_t* nnf;        // short2, current
     int16_t* nnf_alt;    // short2, ping-pong partner for the sweeps
+    float* spec = nullptr;   // speculative sweeps: phase A's cost of every pixel's rejection-path candidate (cost pitch), or NULL
     uint32_t* rng_work;       // [nblocks][64][6] XORWOW lane states read by the random search
     uint32_t* rng_work_next;  // ... written by it (ping-pong: four workgroups read each block's state, one advances it)
 };
@@ -84,7 +85,8 @@ struct PmRngDev {
 void launch_pm_init_field(const PmBatch& b, const PmRngDev& rng, hipStream_t s);
 void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t s);
 // one directional sweep; returns true when the result is in nnf_alt (caller swaps nnf/nnf_alt)
-bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s);
+// speculative: the two-launch form for iterations in which few candidates are accepted (k_patchmatch.hip, k_pm_sweep_spec); same results
+bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s, bool speculative = false);
 // one jump-flood launch (step = neighbour distance); reads nnf, writes nnf_alt (caller swaps)
 void launch_pm_jump(const PmBatch& b, const float* lut, int R, int step, hipStream_t s);
 // one 4-neighbour propagation launch (d_neighbor_propagate); reads nnf, writes nnf_alt (caller swaps)
@@ -107,6 +109,8 @@ void launch_nnf2flow(float* flow, int flow_pitch, const int16_t* nnf, int nnf_pi
 void launch_resize_flow(float* out, int outH, int outW, const float* in, int h, int w, float ratio, float post_scale, hipStream_t s, Batch bt = kOnePair);
 void launch_mul_scalar(float* flow, float scale, int h, int w, hipStream_t s);
 bool c2f_refine_wants_split(int w, int h, int R, int npairs = 1);
+void c2f_set_no_split(int on);                                  // test support
+bool c2f_window_span(int R, int* span_x, int* span_y);          // test support: admissible centre spread of the LDS-window kernels
 // cost9: scratch of 36 floats per pixel for launches that c2f_refine_wants_split(), or NULL
 void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, float* cost9, hipStream_t s, Batch bt = kOnePair);
 void launch_flow_blf(float* out, const float* in, const uint32_t* img, int ipitch, int w, int h, int flow_pitch,

@@ -3,6 +3,7 @@
 // bao_pmflow_refine_kernel.cu:756-799 joint-bilateral flow smoothing).
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "eppm_device.cuh"
@@ -459,8 +460,10 @@ void k_c2f_refine_win(PlanesH Ph, float* __restrict__ flow_, const float* __rest
     constexpr int TW = (TWU + 15) / 16 * 16;
     constexpr int WW = 64, WH = EPPM_C2F_WIN_H;                      // window: row stride 64 texels = 1 KiB (conflict-free ds_read_b128)
     constexpr int XLO = C2fWinGeom<R>::xlo(), XHI = C2fWinGeom<R>::xhi(), YLO = C2fWinGeom<R>::ylo(), YHI = C2fWinGeom<R>::yhi();
-    constexpr int SPAN_X = WW - 2 - (XHI - XLO), SPAN_Y = WH - 2 - (YHI - YLO);   // admissible spread of the candidate centres (max - min)
-    static_assert(SPAN_X >= kBlock && SPAN_Y >= kBlock, "window too small for a constant-flow tile");
+    // admissible spread of the candidate centres (max - min): a read lands at window column (cx + dx) - wx0 with cx in [mnx-1, mxx+1],
+    // dx in [XLO, XHI] and wx0 = mnx - 1 + XLO, i.e. at most (mxx - mnx) + 2 + (XHI - XLO), which must stay <= WW - 1 (rows likewise)
+    constexpr int SPAN_X = WW - 3 - (XHI - XLO), SPAN_Y = WH - 3 - (YHI - YLO);
+    static_assert(SPAN_X >= kBlock - 1 && SPAN_Y >= kBlock - 1, "window too small for a constant-flow tile (spread kBlock - 1)");
     static_assert(TWU * TW * 16 >= 9 * 256 * 4, "the exchange buffer aliases the source tile");
     __shared__ PatchLutT<R + 1> L;
     __shared__ float4 s_src[TWU * TW];
@@ -602,8 +605,8 @@ void k_c2f_refine_win4(PlanesH Ph, float* __restrict__ flow_, const float* __res
     constexpr int XLO = C2fWinGeom<R>::xlo(), XHI = C2fWinGeom<R>::xhi(), YLO = C2fWinGeom<R>::ylo(), YHI = C2fWinGeom<R>::yhi();
     constexpr int WW = (kBlock + 2 + (XHI - XLO) + 8 + 15) / 16 * 16;            // >= 8 px of admissible flow spread, row stride a multiple of 256 B
     constexpr int WH = kBlock + 2 + (YHI - YLO) + 7;
-    constexpr int SPAN_X = WW - 2 - (XHI - XLO), SPAN_Y = WH - 2 - (YHI - YLO);
-    static_assert(SPAN_X >= kBlock && SPAN_Y >= kBlock, "window too small for a constant-flow tile");
+    constexpr int SPAN_X = WW - 3 - (XHI - XLO), SPAN_Y = WH - 3 - (YHI - YLO);          // see k_c2f_refine_win
+    static_assert(SPAN_X >= kBlock - 1 && SPAN_Y >= kBlock - 1, "window too small for a constant-flow tile (spread kBlock - 1)");
     static_assert(TWU * TW * 16 >= 27 * 256 * 4, "the exchange buffer aliases the source tile");
     static_assert(sizeof(PatchLutT<R + 1>) + (TWU * TW + WH * WW) * 16 + 16 <= 160 * 1024, "LDS budget of one CU");
     __shared__ PatchLutT<R + 1> L;
@@ -756,11 +759,32 @@ __global__ __launch_bounds__(256) void k_c2f_select(float* __restrict__ flow_, c
     flow[(y * w + x) * 2 + 1] = (float)(by - y);
 }
 
+// test support (eppm_test_set_option "c2f_no_split"): never split, so that small images go through the LDS-window kernels too
+static std::atomic<int> g_c2f_no_split{0};
+void c2f_set_no_split(int on) { g_c2f_no_split.store(on); }
+
+// admissible spread (max - min) of a tile's candidate centres in the LDS-window kernels, for the tests that probe the boundary
+bool c2f_window_span(int R, int* span_x, int* span_y)
+{
+    if (R == 9) {
+        using G = C2fWinGeom<9>;
+        *span_x = 64 - 3 - (G::xhi() - G::xlo());
+        *span_y = EPPM_C2F_WIN_H - 3 - (G::yhi() - G::ylo());
+        return true;
+    }
+    if (R == 17) {
+        using G = C2fWinGeom<17>;
+        constexpr int WW = (kBlock + 2 + (G::xhi() - G::xlo()) + 8 + 15) / 16 * 16, WH = kBlock + 2 + (G::yhi() - G::ylo()) + 7;
+        *span_x = WW - 3 - (G::xhi() - G::xlo());
+        *span_y = WH - 3 - (G::yhi() - G::ylo());
+        return true;
+    }
+    return false;
+}
+
 bool c2f_refine_wants_split(int w, int h, int R, int npairs)
 {
-    // EPPM_C2F_NO_SPLIT=1 (tests): never split, so that small images go through the LDS-window kernels too
-    static const bool no_split = getenv("EPPM_C2F_NO_SPLIT") != nullptr;
-    if (no_split) return false;
+    if (g_c2f_no_split.load()) return false;
     const int tiles = ((w + kBlock - 1) / kBlock) * ((h + kBlock - 1) / kBlock) * npairs;
 #ifndef EPPM_C2F_SPLIT_BELOW_WAVES
 #define EPPM_C2F_SPLIT_BELOW_WAVES (3 * 1024)        // fewer than 3 waves per SIMD on 256 CUs

@@ -42,6 +42,7 @@ __device__ __forceinline__ PmProblem pm_problem(const PmBatch& B, unsigned q)
     p.cost = pair_ptr_opt(p.cost, B.stride, pair);
     p.nnf = pair_ptr_opt(p.nnf, B.stride, pair);
     p.nnf_alt = pair_ptr_opt(p.nnf_alt, B.stride, pair);
+    p.spec = pair_ptr_opt(p.spec, B.stride, pair);
     p.rng_work = pair_ptr_opt(p.rng_work, B.stride, pair);
     p.rng_work_next = pair_ptr_opt(p.rng_work_next, B.stride, pair);
     return p;
@@ -117,6 +118,45 @@ void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t
     hipLaunchKernelGGL(k_pm_cost_field, grid, block, 0, s, b, lut, R);
 }
 
+// RT = 9 / 17: the source samples of the workgroup's 16x4 pixels come from an LDS tile (16+2R)x(4+2R), loaded once,
+// clamped at load -- one LDS read per sample instead of a clamped address and a gather; RT = 0: any radius, source
+// samples gathered from the plane.
+template <int RT>
+__device__ __forceinline__ float search_patch_dist(const Planes& P, const PatchLut& L, int R, const float4* __restrict__ s_src, int TW,
+                                                   int tx, int ty, int x1, int y1, int x2, int y2)
+{
+    if (RT == 0) return patch_dist(P, L, R, x1, y1, x2, y2);
+    constexpr int S = RT + 1;
+    const int pitch16 = P.pitch << 4;
+    const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
+    const rgbf c2 = texel_rgb(texel_at(P.pk2, texel_off(pitch16, P.w, P.h, x2, y2)));
+    float cost_sum = 0.0f, weight_sum = 0.0f;
+    for (int ii = 0; ii < S; ii++) {
+        const int i = 2 * ii - RT;
+        const unsigned r2 = __umul24((unsigned)iclamp(y2 + i, 0, P.h - 1), (unsigned)pitch16);
+        const float4* __restrict__ srow = s_src + (ty + 2 * ii) * TW + tx;
+        for (int j0 = 0; j0 < S; j0 += 5) {
+            float4 q1[5], q2[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int jj = min(j0 + k, S - 1);
+                q1[k] = srow[2 * jj];
+                q2[k] = texel_at(P.pk2, r2 + ((unsigned)iclamp(x2 + 2 * jj - RT, 0, P.w - 1) << 4));
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                if (j0 + k < S) {
+                    float ct, wt;
+                    patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.cnx, ct, wt);
+                    cost_sum += ct;
+                    weight_sum += wt;
+                }
+            }
+        }
+    }
+    return cost_sum / weight_sum;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Segmented scan-line propagation (kernel.cu:1049-1181), cooperative form.
 //
@@ -156,13 +196,20 @@ __device__ __forceinline__ float dpp_prev_lane(float v)
 // 16-byte lane-fetch per clock, tools/ubench/gather_rate.hip).  TW = tile row length (odd: spreads a chain's ds_read_b128 over the banks).
 template <int LPC> struct SweepTile { static constexpr int CPB = 256 / LPC, SEGS = (CPB >= 16) ? 4 : 2, LINES = CPB / SEGS; };
 
-template <int R, int LPC, bool IS_ROW, bool REVERSE, bool TILE>
+// SPEC: phase B of the speculative form (see k_pm_sweep_spec below): a step that follows a rejection takes its cost from
+// pr.spec; the stored match, cost and speculative cost of a chain's pixels are fetched once, before the first step, and
+// handed to the steps through LDS (they are the only memory a cheap step needs).  Requires L_ <= LPC.
+template <int R, int LPC, bool IS_ROW, bool REVERSE, bool TILE, bool SPEC = false>
 __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, const float* __restrict__ lut, int L_, int nseg, int nseg_pad, int TW)
 {
     constexpr int S = R + 1, NS = S * S, CH = (NS + LPC - 1) / LPC, CPB = 256 / LPC;
     constexpr int SEGS = SweepTile<LPC>::SEGS, LINES = SweepTile<LPC>::LINES, TROWS = S + LINES - 1;
+    static_assert(!(SPEC && TILE), "phase B evaluates rarely: it gathers its source samples");
     extern __shared__ float4 s_tile[];          // TILE: TROWS sample rows + LINES centre rows of TW texels
     __shared__ PatchLut L;
+    __shared__ int s_own[SPEC ? 256 : 1];       // SPEC: per chain and step, the pixel's stored match (x | y << 16),
+    __shared__ float s_cst[SPEC ? 256 : 1];     //       its stored cost
+    __shared__ float s_spc[SPEC ? 256 : 1];     //       and phase A's cost of the rejection-path candidate
     load_patch_lut(L, lut, R, threadIdx.x, 256);
     // 1-D grid, problem = id mod nprob: workgroups are dealt to the 8 XCDs by id mod 8, so with 8 problems (4 pairs x 2 directions)
     // each problem's planes stay in ONE XCD's L2 instead of all problems' planes competing for every L2
@@ -227,6 +274,20 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             nout[uidx * 2 + 1] = nin[uidx * 2 + 1];
         }
     }
+    if (SPEC) {
+        // lane r of a chain fetches what step r needs
+        int own = 0;
+        float cst = 0.0f, spc = 0.0f;
+        if (active && r < count) {
+            const int ir = i + r * step;
+            const int xr = IS_ROW ? ir : line, yr = IS_ROW ? line : ir;
+            own = (int)(uint16_t)nin[(yr * B.npitch + xr) * 2] | ((int)nin[(yr * B.npitch + xr) * 2 + 1] << 16);
+            cst = cost[yr * B.cpitch + xr];
+            spc = pr.spec[yr * B.cpitch + xr];
+        }
+        s_own[threadIdx.x] = own; s_cst[threadIdx.x] = cst; s_spc[threadIdx.x] = spc;
+    }
+    bool from_nin = true;                  // SPEC: the chain carries a stored match (seed, or the own match of a pixel that rejected)
     __syncthreads();   // LUT ready
     const int t0 = r * CH;
     const int pitch16 = P.pitch << 4, wmax16 = (P.w - 1) << 4;
@@ -244,8 +305,17 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
         if (active && s < count) {
             const int x = IS_ROW ? i : line, y = IS_ROW ? line : i;
             const int nidx = y * B.npitch + x, cidx = y * B.cpitch + x;
-            const float cur_best = cost[cidx];
-            const int ox = nin[nidx * 2], oy = nin[nidx * 2 + 1];     // the pixel's own match, needed on rejection: fetched with the rest
+            const bool second_visit = (!REVERSE) && (seg == 0) && (s == L_ - 1) && (nseg > 1);   // pixel L, after segment 1
+            float cur_best;
+            int ox, oy;
+            if (SPEC) {
+                const int sl = grp * LPC + s, e = s_own[sl];
+                ox = (int)(int16_t)(e & 0xffff); oy = e >> 16;
+                cur_best = second_visit ? cost[cidx] : s_cst[sl];     // segment 1 may have lowered pixel L's cost at its first step
+            } else {
+                cur_best = cost[cidx];
+                ox = nin[nidx * 2]; oy = nin[nidx * 2 + 1];           // the pixel's own match, needed on rejection: fetched with the rest
+            }
             if (IS_ROW) px = REVERSE ? max(px - 1, 0) : min(px + 1, P.w - 1);
             else        py = REVERSE ? max(py - 1, 0) : min(py + 1, P.h - 1);
             // A candidate equal to the pixel's current match would reproduce the stored cost bit for bit
@@ -253,7 +323,9 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             // reference evaluates and rejects it, here the evaluation is skipped.  Converged regions --
             // neighbours sharing one offset -- make this the common case after the first iterations.
             float cv = cur_best;
-            if (!(px == ox && py == oy)) {
+            const bool differs = !(px == ox && py == oy);
+            if (SPEC && differs && from_nin) cv = s_spc[grp * LPC + s];           // phase A evaluated exactly this candidate
+            else if (differs) {
             const rgbf c1 = texel_rgb(TILE ? s_tile[lc + i] : tex_px(P.pk1, P.pitch, P.w, P.h, x, y));
             const rgbf c2 = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, px, py));
             float tc[CH], tw[CH];
@@ -292,24 +364,95 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             const float cs = __shfl(ac, src, 64), ws = __shfl(aw, src, 64);
             cv = cs / ws;
             }
-            const bool second_visit = (!REVERSE) && (seg == 0) && (s == L_ - 1) && (nseg > 1);   // pixel L, after segment 1
             if (cv < cur_best) {
                 if (r == 0) {
                     nout[nidx * 2] = (int16_t)px;
                     nout[nidx * 2 + 1] = (int16_t)py;
                     cost[cidx] = cv;
                 }
+                from_nin = false;
             } else {
                 if (r == 0 && !second_visit) {
                     nout[nidx * 2] = (int16_t)ox;
                     nout[nidx * 2 + 1] = (int16_t)oy;
                 }
                 px = ox; py = oy;
+                from_nin = true;
             }
             i += step;
         }
         if (!REVERSE && s == 0) __syncthreads();   // (b)
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Speculative form of a sweep, for the iterations in which few candidates are accepted (from the third iteration on fewer
+// than one step in ten, tools/sweep_stats.py): phase A + phase B, same results bit for bit.
+//
+// The candidate a chain tries at pixel i is shift(p) where p is what the chain carries out of pixel i-1: the match it accepted
+// there, or -- when pixel i-1 REJECTED its candidate (and at a segment's first step, whose seed is pixel i-1) -- pixel i-1's own
+// match nin[i-1].  So for every visited pixel the candidate on the rejection path, shift(nin[i-1]), is known before the sweep
+// starts and its cost does not depend on the chain's history (the patch cost is a pure function of (pixel, candidate)):
+//  phase A (k_pm_sweep_spec): evaluates E(i, shift(nin[i-1])) for every visited pixel in parallel -- no dependent steps, one
+//      evaluation per lane with the source samples from an LDS tile; pixels whose candidate equals their own match are skipped
+//      (the skip rule), the rest are compacted inside the workgroup so that whole waves work or exit;
+//  phase B (k_pm_sweep<.., SPEC>): the chains walk their pixels in the reference's order as before, but a step that follows a
+//      rejection takes its cost from phase A's plane; only a step that follows an ACCEPTED candidate evaluates (cooperatively,
+//      as in the classic form).  In the converged iterations phase B is ten compare-and-select steps.
+// ---------------------------------------------------------------------------------------------------
+template <int RT, bool IS_ROW, bool REVERSE>
+__global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* __restrict__ lut, int R, int gx)
+{
+    constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT;
+    __shared__ float4 s_src[TW * TW];
+    __shared__ PatchLut L;
+    __shared__ uint32_t s_list[256];       // compacted work: pixel index inside the block
+    __shared__ int s_cand[256];            // its candidate, x | y << 16
+    __shared__ int s_wcount[4];
+    const unsigned nprob = B.n * B.npairs, bq = blockIdx.x % nprob, brest = blockIdx.x / nprob;
+    const int bxx = brest % gx, byy = brest / gx;
+    const PmProblem pr = pm_problem(B, bq);
+    const Planes P = to_dev(pr.P);
+    const int tid = threadIdx.x;
+    load_patch_lut(L, lut, R, tid, 256);
+    if (RT != 0) {
+        const int x0 = bxx * kBlock - RT, y0 = byy * kBlock - RT;
+        for (int t = tid; t < TW * TW; t += 256) {
+            const int sy = iclamp(y0 + t / TW, 0, P.h - 1), sx = iclamp(x0 + t % TW, 0, P.w - 1);
+            s_src[t] = P.pk1[(unsigned)(sy * P.pitch + sx)];
+        }
+    }
+    const int x = bxx * kBlock + (tid & 15), y = byy * kBlock + (tid >> 4);
+    // the pixel the chain comes from: one step against the sweep direction; the first pixel of a line is never visited
+    const int qx = IS_ROW ? (REVERSE ? x + 1 : x - 1) : x, qy = IS_ROW ? y : (REVERSE ? y + 1 : y - 1);
+    bool need = false;
+    int cx = 0, cy = 0;
+    if (x < P.w && y < P.h && qx >= 0 && qy >= 0 && qx < P.w && qy < P.h) {
+        const int qi = (qy * B.npitch + qx) * 2, ni = (y * B.npitch + x) * 2;
+        cx = pr.nnf[qi]; cy = pr.nnf[qi + 1];
+        if (IS_ROW) cx = REVERSE ? max(cx - 1, 0) : min(cx + 1, P.w - 1);
+        else        cy = REVERSE ? max(cy - 1, 0) : min(cy + 1, P.h - 1);
+        need = !(cx == pr.nnf[ni] && cy == pr.nnf[ni + 1]);          // equal to the pixel's own match: rejected unevaluated
+    }
+    // compaction: wave-level ballot + prefix, then the four wave counts
+    const unsigned long long bal = __ballot(need);
+    const int lane = tid & 63, wv = tid >> 6;
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wcount[wv] = __popcll(bal);
+    __syncthreads();                          // LUT, tile, wave counts
+    int base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int c = s_wcount[k]; if (k < wv) base += c; total += c; }
+    if (need) {
+        s_list[base + before] = (uint32_t)tid;
+        s_cand[base + before] = (cx & 0xffff) | (cy << 16);
+    }
+    __syncthreads();
+    if (tid >= total) return;
+    const int pix = (int)s_list[tid], e = s_cand[tid];
+    const int tx = pix & 15, ty = pix >> 4;
+    const int px = bxx * kBlock + tx, py = byy * kBlock + ty;
+    pr.spec[py * B.cpitch + px] = search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16);
 }
 
 // Fallback for patch radii without a cooperative instantiation: the reference's one-thread-per-chain form,
@@ -372,6 +515,35 @@ __global__ __launch_bounds__(1024) void k_pm_seg_propagate(PmBatch B, const floa
     }
 }
 
+// phase A of the speculative form for one direction
+template <int RT>
+static void launch_sweep_spec(const PmBatch& b, const float* lut, int R, int dir, hipStream_t s)
+{
+    const int w = b.p[0].P.w, h = b.p[0].P.h, gx = (w + kBlock - 1) / kBlock, gy = (h + kBlock - 1) / kBlock;
+    dim3 grid(gx * gy * (b.n * b.npairs)), block(256);
+    switch (dir) {
+        case 0: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, false>), grid, block, 0, s, b, lut, R, gx); break;
+        case 1: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, false>), grid, block, 0, s, b, lut, R, gx); break;
+        case 2: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, true>), grid, block, 0, s, b, lut, R, gx); break;
+        default: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, true>), grid, block, 0, s, b, lut, R, gx); break;
+    }
+}
+// phase B
+template <int R, int LPC>
+static void launch_sweep_b(const PmBatch& b, const float* lut, int seg_len, int dir, int nseg, int lines, hipStream_t s)
+{
+    constexpr int CPB = 256 / LPC;
+    const int nseg_pad = (nseg + 1) & ~1;
+    const int wgs = (lines * nseg_pad + CPB - 1) / CPB;
+    dim3 grid(wgs * (b.n * b.npairs)), block(256);
+    switch (dir) {
+        case 0: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, false, false, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad, 0); break;
+        case 1: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, false, false, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad, 0); break;
+        case 2: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, true, false, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad, 0); break;
+        default: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, true, false, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad, 0); break;
+    }
+}
+
 template <int R, int LPC, bool TILE>
 static void launch_sweep_t(const PmBatch& b, const float* lut, int seg_len, int dir, int nseg, int lines, hipStream_t s)
 {
@@ -400,12 +572,17 @@ static void launch_sweep_r(const PmBatch& b, const float* lut, int seg_len, int 
     else launch_sweep_t<R, LPC, false>(b, lut, seg_len, dir, nseg, lines, s);
 }
 
-bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s)
+bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s, bool speculative)
 {
     const PlanesH& P = b.p[0].P;
     const bool is_row = (dir == 0 || dir == 2);
     const int len = is_row ? P.w : P.h, lines = is_row ? P.h : P.w;
     const int nseg = (len + seg_len - 1) / seg_len;
+    if (speculative && b.p[0].spec && (R == 9 || R == 17) && seg_len <= ((R == 9) ? EPPM_LPC9 : EPPM_LPC17)) {
+        if (R == 9) { launch_sweep_spec<9>(b, lut, R, dir, s); launch_sweep_b<9, EPPM_LPC9>(b, lut, seg_len, dir, nseg, lines, s); }
+        else { launch_sweep_spec<17>(b, lut, R, dir, s); launch_sweep_b<17, EPPM_LPC17>(b, lut, seg_len, dir, nseg, lines, s); }
+        return true;
+    }
     if (R == 9) {
         // 16 lanes per chain are the most instruction-efficient; when that leaves fewer than two waves per SIMD (the
         // quarter-resolution level of a 1024x436 pair: 1.4) the chip is latency bound and 32 lanes per chain shorten
@@ -531,45 +708,6 @@ void launch_pm_neighbor(const PmBatch& b, const float* lut, int R, hipStream_t s
 // pixels, the costs meet in LDS and wave 0 replays the reference's in-order strict-< selection.  The four
 // quarter-workgroups of a block draw the same numbers (cheap); only quarter 0 advances the stored state.
 // ---------------------------------------------------------------------------------------------------
-// RT = 9 / 17: the source samples of the workgroup's 16x4 pixels come from an LDS tile (16+2R)x(4+2R), loaded once,
-// clamped at load -- one LDS read per sample instead of a clamped address and a gather; RT = 0: any radius, source
-// samples gathered from the plane.
-template <int RT>
-__device__ __forceinline__ float search_patch_dist(const Planes& P, const PatchLut& L, int R, const float4* __restrict__ s_src, int TW,
-                                                   int tx, int ty, int x1, int y1, int x2, int y2)
-{
-    if (RT == 0) return patch_dist(P, L, R, x1, y1, x2, y2);
-    constexpr int S = RT + 1;
-    const int pitch16 = P.pitch << 4;
-    const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
-    const rgbf c2 = texel_rgb(texel_at(P.pk2, texel_off(pitch16, P.w, P.h, x2, y2)));
-    float cost_sum = 0.0f, weight_sum = 0.0f;
-    for (int ii = 0; ii < S; ii++) {
-        const int i = 2 * ii - RT;
-        const unsigned r2 = __umul24((unsigned)iclamp(y2 + i, 0, P.h - 1), (unsigned)pitch16);
-        const float4* __restrict__ srow = s_src + (ty + 2 * ii) * TW + tx;
-        for (int j0 = 0; j0 < S; j0 += 5) {
-            float4 q1[5], q2[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const int jj = min(j0 + k, S - 1);
-                q1[k] = srow[2 * jj];
-                q2[k] = texel_at(P.pk2, r2 + ((unsigned)iclamp(x2 + 2 * jj - RT, 0, P.w - 1) << 4));
-            }
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                if (j0 + k < S) {
-                    float ct, wt;
-                    patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.cnx, ct, wt);
-                    cost_sum += ct;
-                    weight_sum += wt;
-                }
-            }
-        }
-    }
-    return cost_sum / weight_sum;
-}
-
 template <int RT>
 __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
                                                           int search_range, int G)

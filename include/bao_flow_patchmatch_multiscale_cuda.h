@@ -36,7 +36,10 @@ public:
     // before init(); access to the C handle
     void set_device(int device) { m_device = device; }
     // name = a field of eppm_params (include/eppm.h): "patch_r", "num_iter", "search_range", "num_guess",
-    // "seg_len", "wmf_iters", "seed", "propagation", "levels".  false: unknown name.
+    // "seg_len", "wmf_iters", "seed", "propagation", "levels"; or "pin_caller_buffers" (0/1, default 0): register the contiguous
+    // image and flow blocks passed to set_data / compute_flow for DMA (eppm_host_register) the first time they are seen, so that no
+    // host copy remains between the caller's memory and the GPU -- the caller then keeps those blocks allocated until the object
+    // is destroyed or init() is called again.  false: unknown name.
     bool set_option(const char* name, long long value);
     eppm_ctx* handle() const { return m_ctx; }
 
@@ -49,9 +52,10 @@ private:
     int m_device;
     eppm_ctx* m_ctx;
     void* m_params;           // eppm_params*
-    unsigned char* m_stage;   // contiguous RGB staging for the row-pointer inputs
-    float* m_u;
+    unsigned char* m_stage;   // contiguous RGB staging for row-pointer inputs that are not one block (allocated when needed)
+    float* m_u;               // ... and for flow planes whose rows are not contiguous
     float* m_v;
+    void* m_priv;             // caller blocks seen so far (verified layouts, DMA registrations)
 };
 
 #endif

@@ -76,6 +76,19 @@ int  eppm_set_stream(eppm_ctx* ctx, void* hip_stream);
 /* Host images: h rows of w RGB triplets, row_stride bytes apart (>= 3*w).  RGB->RGBA, H2D,
  * prefilter, pyramid, census (set_data + _prepare_data, driver .cpp:159-168,212-215). */
 int  eppm_set_images(eppm_ctx* ctx, const uint8_t* rgb1, const uint8_t* rgb2, size_t row_stride);
+/* Caller memory pinned for DMA.  eppm_set_images / eppm_batch_set_images read an image that lies inside a registered block where
+ * it is (no staging copy), and eppm_compute / eppm_compute_begin_into / the batch forms write flow planes that lie inside
+ * registered blocks directly; anything else goes through the context's pinned staging buffers (one host copy each way), with
+ * identical results.  Register the buffers a program reuses from pair to pair once (hipHostRegister underneath: the cost of a
+ * registration is that of pinning the pages, paid once); eppm_host_alloc returns pinned memory that counts as registered.
+ * eppm_set_images returns when the images have been read (set_data is a synchronous cudaMemcpy in the reference,
+ * driver .cpp:165-166); a block must stay registered until the calls using it have returned. */
+int  eppm_host_register(void* p, size_t bytes);
+int  eppm_host_unregister(void* p);
+int  eppm_host_is_registered(const void* p, size_t bytes);   /* 1 / 0 */
+int  eppm_host_alloc(void** p, size_t bytes);
+int  eppm_host_free(void* p);
+
 /* Device-resident RGBA (uchar4, alpha ignored/0) images, pitch in bytes: copies them into the context (device to device,
  * in the order of the context's stream) and runs prepare.  The planes must be complete before the call (or produced on
  * that stream) and stay valid until that copy has run (eppm_synchronize, or any later synchronous call on this
@@ -99,8 +112,10 @@ int  eppm_batch_set_images_device(eppm_ctx* ctx, int n, const void* const* d_rgb
 int  eppm_batch_compute(eppm_ctx* ctx, float* const* u, float* const* v);
 /* asynchronous; d_flows: NULL, or n device pointers (NULL entries allowed) receiving the interleaved float2 flows */
 int  eppm_batch_compute_device(eppm_ctx* ctx, void* const* d_flows);
-/* second half of eppm_compute_begin for every active pair */
+/* second half of eppm_compute_begin / eppm_batch_compute_begin_into for every active pair */
 int  eppm_batch_compute_end(eppm_ctx* ctx, float* const* u, float* const* v);
+/* eppm_compute_begin_into for every active pair */
+int  eppm_batch_compute_begin_into(eppm_ctx* ctx, float* const* u, float* const* v);
 /* eppm_get_plane of pair `pair` */
 int  eppm_batch_get_plane(eppm_ctx* ctx, int pair, const char* name, int level, void* dst, size_t dst_bytes);
 
@@ -111,6 +126,9 @@ int  eppm_compute(eppm_ctx* ctx, float* u, float* v);
  * this context's stream and writes u, v.  eppm_set_images on a context waits for that context's previous work. */
 int  eppm_compute_begin(eppm_ctx* ctx);
 int  eppm_compute_end(eppm_ctx* ctx, float* u, float* v);
+/* eppm_compute_begin with the destination named up front: planes in registered memory (eppm_host_register) are written by the
+ * copy engine directly and eppm_compute_end(ctx, u, v) with the same pointers only waits.  eppm_compute = this + eppm_compute_end. */
+int  eppm_compute_begin_into(eppm_ctx* ctx, float* u, float* v);
 /* Optional colour-coded flow of the last eppm_compute* (compute_flow's color_flow argument, driver .cpp:308-314):
  * Middlebury colour wheel on the device flow (basic/bao_basic_cuda.cuh:776-845), h rows of w R,G,B triplets,
  * row_stride bytes apart.  The reference calls it with max_disp (20,20).  On a batch context: pair 0. */
@@ -215,10 +233,11 @@ int  eppm_flow_to_color(eppm_uchar4* d_rgba, const eppm_float2* d_flow, int h, i
  * baoRandomSearch (bao_pmflow_kernel.cu:153-165, 689-696, 1167-1181, 1588-1594), with the
  * texture bindings and the global RNG state made explicit arguments.
  * rng: opaque device buffer from eppm_pm_rng_create (one XORWOW stream per 16x16 block).
- * PRECONDITION of the three propagate entry points: d_cost[p] is the patch cost of d_nnf[p] (as eppm_pm_cost_field,
+ * PRECONDITION of the three propagate entry points AND of eppm_pm_random_search: d_cost[p] is the patch cost of d_nnf[p] (as eppm_pm_cost_field,
  * a propagate or a search leaves it).  A candidate equal to the pixel's stored match is rejected without being
  * evaluated -- it would reproduce the stored cost bit for bit, and the reference's strict `<` rejects it too; with a
- * cost plane that is NOT consistent with the NNF the reference would re-evaluate and could lower the cost, these would not.
+ * cost plane that is NOT consistent with the NNF the reference would re-evaluate and could lower the cost, these would not
+ * (a random guess equal to the stored match likewise sits its evaluation out).
  * -------------------------------------------------------------------------------------- */
 typedef struct eppm_pm_rng eppm_pm_rng;
 int  eppm_pm_rng_create(eppm_pm_rng** out, int w, int h, const eppm_params* p);
@@ -250,6 +269,14 @@ int  eppm_gauss_filter_rgba(eppm_uchar4* d_out, const eppm_uchar4* d_in, size_t 
 int  eppm_resize_rgba(eppm_uchar4* d_out, size_t out_pitch, int outH, int outW, const eppm_uchar4* d_in, size_t in_pitch,
         int h, int w, float ratio);
 int  eppm_resize_flow(eppm_float2* d_out, int outH, int outW, const eppm_float2* d_in, int h, int w, float ratio);
+/* test support: process-wide switches with which the parity tests steer launches onto a specific kernel variant (a host program
+ * never needs them).  "c2f_no_split" = 1: the candidate refine is never split over several workgroups per tile, so that small
+ * images run the LDS-window kernels too.  "sweep_spec": -1 (default) the sweeps of PatchMatch iteration >= 3 run in the
+ * speculative two-launch form, 0 never, 1 always (also in eppm_pm_seg_propagate, which otherwise runs the classic form). */
+int  eppm_test_set_option(const char* name, int value);
+/* admissible spread (max - min, pixels) of a 16x16 tile's candidate centres for which the LDS-window refine kernels stage the
+ * target window; wider tiles take the per-access path inside the same launch (patch_r 9 or 17) */
+int  eppm_probe_c2f_window(int patch_r, int* span_x, int* span_y);
 /* device-side arithmetic probes (parity of the shared float formulas): y[i] = f(x[i]) for n host floats */
 int  eppm_probe_fast_exp(const float* x, float* y, int n);
 int  eppm_probe_div_const(const float* x, float* y, int n, int which); /* 0: /(.1f*.1f) 1: /(.02f*.02f) 2: unorm8 (x = 0..255) */

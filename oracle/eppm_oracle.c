@@ -79,6 +79,27 @@ void orc_set_num_threads(int n)
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Variants: OTHER legal readings of the racy / unspecified parts of the reference (tools/parity_envelope.py measures how far
+ * each moves the flow away from the default reading; they never serve as the parity oracle).  All zero = the lockstep oracle.
+ *   sweep_order   0 lockstep (seeds read before any walk, pixel L visited by segment 1 first);
+ *                 1 serial: the segments of a line run one after the other in sweep direction and read their seed when they
+ *                   start, i.e. propagation along the whole line (a grid whose earlier blocks finish first,
+ *                   bao_pmflow_kernel.cu:1059-1076 read nnf[start] live);
+ *                 2 lockstep seeds, but pixel L is visited by segment 0 first (the other order of the two racing writes).
+ *   post_inplace  1: outlier removal, weighted median, hole filling and the flow smoothing run in place in raster order (a
+ *                   thread sees the results of threads that ran before it: refine :149-193, :206-259, :297-371, :764-799
+ *                   read and write one buffer) instead of Jacobi.
+ *   exp_mode      1: libm expf (correctly rounded-ish) wherever the reference calls __expf, instead of the shared 2-ulp formula.
+ *   seed_variant  1: another seed scrambling (seed ^ golden ratio before cuRAND's constants): a different but equally
+ *                   plausible random stream.
+ * ---------------------------------------------------------------------------------------- */
+static struct { int sweep_order, post_inplace, exp_mode, seed_variant; } g_var = {0, 0, 0, 0};
+void orc_set_variant(int sweep_order, int post_inplace, int exp_mode, int seed_variant)
+{
+    g_var.sweep_order = sweep_order; g_var.post_inplace = post_inplace; g_var.exp_mode = exp_mode; g_var.seed_variant = seed_variant;
+}
+
+/* ------------------------------------------------------------------------------------------
  * __expf restated.  CUDA's __expf(x) is ex2.approx(x * log2(e)) (libdevice __nv_fast_expf; the
  * reference is built without -use_fast_math / -ftz, CMakeLists.txt:12-27, so subnormal results
  * are NOT flushed).  The SFU's ex2.approx is not specified bit for bit, so both the oracle and
@@ -91,6 +112,7 @@ void orc_set_num_threads(int n)
  * ---------------------------------------------------------------------------------------- */
 float orc_fast_exp(float x)
 {
+    if (g_var.exp_mode == 1) return expf(x);     /* variant only, see orc_set_variant */
     float y = x * 0x1.715476p+0f;
     if (y > 127.0f) y = 127.0f;      /* never reached on this path (all arguments are <= 0) */
     if (y < -1000.0f) y = -1000.0f;  /* keeps (int)n defined; the result is 0 from y < -150.5 on */
@@ -229,6 +251,7 @@ void orc_xorwow_skip(orc_xorwow* s, unsigned long long n)
 void orc_xorwow_init(orc_xorwow* s, unsigned long long seed, unsigned long long subsequence)
 {
     init_jump();
+    if (g_var.seed_variant == 1) seed ^= 0x9E3779B97F4A7C15ULL;     /* variant only, see orc_set_variant */
     /* seed scrambling (curand_kernel.h, _curand_init_scratch) */
     uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
     uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
@@ -585,6 +608,17 @@ void orc_seg_propagate_dir(float* cost, orc_short2* nnf, const orc_uchar4* img1,
             else { start = (s + 1) * L; if (start >= len) start = len - 1; }
             seeds[s] = nnf[pix_index(&c, is_row, line, start)];
         }
+        if (g_var.sweep_order == 1) {          /* variant: serial along the line, live seeds */
+            for (int k = 0; k < nseg; k++) {
+                const int s = reverse ? nseg - 1 - k : k;
+                int start;
+                if (!reverse) start = (s == 0) ? 0 : s * L - 1;
+                else { start = (s + 1) * L; if (start >= len) start = len - 1; }
+                seg_walk(&c, is_row, reverse, line, s, L, nnf[pix_index(&c, is_row, line, start)]);
+            }
+        } else if (g_var.sweep_order == 2 && !reverse) {   /* variant: segment 0 reaches pixel L before segment 1 */
+            for (int s = 0; s < nseg; s++) seg_walk(&c, is_row, 0, line, s, L, seeds[s]);
+        } else
         if (!reverse) for (int s = nseg - 1; s >= 0; s--) seg_walk(&c, is_row, 0, line, s, L, seeds[s]);
         else          for (int s = 0; s < nseg; s++)      seg_walk(&c, is_row, 1, line, s, L, seeds[s]);
         free(seeds);
@@ -758,9 +792,11 @@ void orc_left_right_check(orc_short2* nnf1, float* cost1, orc_short2* nnf2, floa
 /* refine :149-193 (Jacobi) */
 void orc_outlier_removal(orc_short2* nnf, float* cost, int w, int h)
 {
-    orc_short2* in = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
-    memcpy(in, nnf, sizeof(orc_short2) * w * h);
-#pragma omp parallel for schedule(static)
+    orc_short2* in_copy = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
+    memcpy(in_copy, nnf, sizeof(orc_short2) * w * h);
+    const int inplace = g_var.post_inplace;                    /* variant: read the buffer being written, raster order */
+    const orc_short2* in = inplace ? nnf : in_copy;
+#pragma omp parallel for schedule(static) if (!inplace)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             orc_short2 cur = in[(size_t)y * w + x];
@@ -780,7 +816,7 @@ void orc_outlier_removal(orc_short2* nnf, float* cost, int w, int h)
                 cost[(size_t)y * w + x] = FLT_MAX;
             }
         }
-    free(in);
+    free(in_copy);
 }
 
 /* refine :198-204 */
@@ -797,10 +833,12 @@ void orc_weighted_median(orc_short2* nnf, const orc_uchar4* img, int w, int h, i
     float g[WMF_RADIUS + 1];
     orc_wmf_lut(g);
     init_unorm();
-    orc_short2* in = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
+    orc_short2* in_copy = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
+    const int inplace = g_var.post_inplace;                    /* variant: read the buffer being written, raster order */
+    const orc_short2* in = inplace ? nnf : in_copy;
     for (int it = 0; it < num_iter; it++) {
-        memcpy(in, nnf, sizeof(orc_short2) * w * h);
-#pragma omp parallel for schedule(dynamic, 2)
+        memcpy(in_copy, nnf, sizeof(orc_short2) * w * h);
+#pragma omp parallel for schedule(dynamic, 2) if (!inplace)
         for (int y = 0; y < h; y++)
             for (int x = 0; x < w; x++) {
                 orc_short2 out = in[(size_t)y * w + x];
@@ -837,16 +875,18 @@ void orc_weighted_median(orc_short2* nnf, const orc_uchar4* img, int w, int h, i
                 nnf[(size_t)y * w + x] = out;
             }
     }
-    free(in);
+    free(in_copy);
 }
 
 /* refine :297-371 (Jacobi) */
 void orc_fill_holes(orc_short2* nnf, const orc_uchar4* img, int w, int h)
 {
     init_unorm();
-    orc_short2* in = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
-    memcpy(in, nnf, sizeof(orc_short2) * w * h);
-#pragma omp parallel for schedule(static)
+    orc_short2* in_copy = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
+    memcpy(in_copy, nnf, sizeof(orc_short2) * w * h);
+    const int inplace = g_var.post_inplace;                    /* variant: read the buffer being written, raster order */
+    const orc_short2* in = inplace ? nnf : in_copy;
+#pragma omp parallel for schedule(static) if (!inplace)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             orc_short2 cur = in[(size_t)y * w + x];
@@ -872,7 +912,7 @@ void orc_fill_holes(orc_short2* nnf, const orc_uchar4* img, int w, int h)
             cur.y = (int16_t)(cur.y + y);
             nnf[(size_t)y * w + x] = cur;
         }
-    free(in);
+    free(in_copy);
 }
 
 /* refine :636-655 */
@@ -970,9 +1010,11 @@ void orc_flow_smoothing(orc_float2* flow, const orc_uchar4* img, int w, int h)
     float g[POSTPROC_BLF_RADIUS + 1];
     orc_blf_lut(g);
     init_unorm();
-    orc_float2* in = (orc_float2*)malloc(sizeof(orc_float2) * w * h);
-    memcpy(in, flow, sizeof(orc_float2) * w * h);
-#pragma omp parallel for schedule(static)
+    orc_float2* in_copy = (orc_float2*)malloc(sizeof(orc_float2) * w * h);
+    memcpy(in_copy, flow, sizeof(orc_float2) * w * h);
+    const int inplace = g_var.post_inplace;                    /* variant: read the buffer being written, raster order */
+    const orc_float2* in = inplace ? flow : in_copy;
+#pragma omp parallel for schedule(static) if (!inplace)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             rgbf center = tex_rgb(img, w, h, x, y);
@@ -995,7 +1037,7 @@ void orc_flow_smoothing(orc_float2* flow, const orc_uchar4* img, int w, int h)
                 flow[(size_t)y * w + x].y = ny / wsum;
             }
         }
-    free(in);
+    free(in_copy);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -54,6 +54,9 @@ typedef struct {
 } orc_params;
 
 void  orc_default_params(orc_params* p);
+/* OTHER legal readings of the racy / unspecified parts of the reference, for measuring how far they move the flow
+ * (tools/parity_envelope.py); all zero = the lockstep oracle, the only reading used for parity.  See eppm_oracle.c. */
+void  orc_set_variant(int sweep_order, int post_inplace, int exp_mode, int seed_variant);
 
 /* ---- arithmetic building blocks ---- */
 float orc_fast_exp(float x);                       /* restates __expf (see .c) */

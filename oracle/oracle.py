@@ -357,6 +357,12 @@ def compute_flow(rgb1, rgb2, params=None, dump=False):
     return u, v, st
 
 
+def set_variant(sweep_order=0, post_inplace=0, exp_mode=0, seed_variant=0):
+    """Select another legal reading of the reference's racy / unspecified parts (eppm_oracle.c: orc_set_variant); call with no
+    arguments to return to the lockstep oracle.  Used only by tools/parity_envelope.py and its test."""
+    lib().orc_set_variant(int(sweep_order), int(post_inplace), int(exp_mode), int(seed_variant))
+
+
 def num_threads():
     return lib().orc_num_threads()
 

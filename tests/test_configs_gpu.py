@@ -173,6 +173,111 @@ def test_batch_device_entry_points_and_begin_end(crop, crop_stages):
     B.close()
 
 
+def test_host_boundary_registered_buffers_and_begin_into(crop, crop_stages):
+    """a2 / a19 without staging copies: images in memory registered with eppm_host_register (or from eppm_host_alloc) are read
+    by DMA where they lie, flow planes in registered memory are written directly (eppm_compute, eppm_compute_begin_into,
+    eppm_batch_compute_begin_into); mixed registered / unregistered arguments, strided rows and a destination that changes
+    between begin and end all give the flows of the plain staged calls, bit for bit."""
+    import eppm_amd
+    from oracle import oracle as O
+    a, b = crop
+    st = crop_stages
+    h, w = 120, 160
+    want = (st["u"], st["v"])
+    rev = O.compute_flow(b, a)
+
+    def same(got, ref):
+        return np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32))
+    L = eppm_amd.lib()
+    pa, pb = eppm_amd.pinned_empty((h, w, 3)), eppm_amd.pinned_empty((h, w, 3))          # eppm_host_alloc
+    pa[:], pb[:] = a, b
+    ra = eppm_amd.host_register(a.copy())                                                 # eppm_host_register on malloc'ed memory
+    u, v = eppm_amd.host_register(np.full((h, w), -7, np.float32)), eppm_amd.host_register(np.full((h, w), -7, np.float32))
+    import ctypes as C
+
+    def is_reg(x):
+        return L.eppm_host_is_registered(C.c_void_p(x.ctypes.data), C.c_size_t(x.nbytes))
+    assert is_reg(pa) == 1 and is_reg(ra) == 1 and is_reg(u) == 1 and is_reg(b) == 0
+    e = eppm_amd.EPPM()
+    e.init(h, w)
+    e.set_data(pa, pb)
+    assert same(e.compute_flow(out=(u, v)), want), "registered in, registered out"
+    e.set_data(ra, b)                                   # one registered, one staged
+    assert same(e.compute_flow(), want), "mixed in, staged out"
+    pa[:] = 0                                            # set_data has consumed the images when it returns
+    e.set_data(pb, ra)
+    ra[:] = 0
+    uu = np.empty((h, w), np.float32)
+    assert same(e.compute_flow(out=(uu, v)), rev), "registered in (reused right after the call), one registered plane out"
+    pa[:], ra[:] = a, a
+    # strided rows inside a registered block
+    wide = eppm_amd.pinned_empty((h, w + 13, 3))
+    wide2 = eppm_amd.pinned_empty((h, w + 13, 3))
+    wide[:, :w], wide2[:, :w] = a, b
+    from eppm_amd._lib import check
+    check(L.eppm_set_images(e._ctx, C.c_void_p(wide.ctypes.data), C.c_void_p(wide2.ctypes.data), C.c_size_t((w + 13) * 3)), "strided")
+    assert same(e.compute_flow(), want), "strided registered rows"
+    # begin_into + end: same pointers (only waits), other pointers (copied from the direct destination), begin without destination
+    e.set_data(pa, pb)
+    e.compute_flow_begin(out=(u, v))
+    got = e.compute_flow_end(out=(u, v))
+    assert got[0] is u and same(got, want)
+    e.set_data(pb, pa)
+    e.compute_flow_begin(out=(u, v))
+    other = e.compute_flow_end()                          # fresh unregistered planes
+    assert same(other, rev) and same((u, v), rev)
+    e.set_data(pa, pb)
+    e.compute_flow_begin()
+    assert same(e.compute_flow_end(out=(u, v)), want)
+    e.close()
+    # batch context: registered and unregistered destinations in one call
+    B = eppm_amd.EPPMBatch(h, w, 3)
+    B.set_data([(pa, pb), (b, a), (ra, pb)])
+    outs = [(u, v), (np.empty((h, w), np.float32), np.empty((h, w), np.float32)),
+            (eppm_amd.pinned_empty((h, w), np.float32), eppm_amd.pinned_empty((h, w), np.float32))]
+    B.compute_flow_begin(out=outs)
+    got = B.compute_flow_end(out=outs)
+    for k, ref in enumerate((want, rev, want)):
+        assert same(got[k], ref), k
+    got = B.compute_flow(out=outs[::-1])
+    for k, ref in enumerate((want, rev, want)):
+        assert same(got[k], ref), k
+    B.close()
+    for x in (ra, u, v):
+        eppm_amd.host_unregister(x)
+    with pytest.raises(eppm_amd.EppmError):
+        eppm_amd.host_unregister(u)                       # twice
+
+
+def test_class_pinned_caller_buffers_cli(tmp_path):
+    """The drop-in class with set_option("pin_caller_buffers", 1) (runeppm --pin): bao_alloc-shaped blocks registered for DMA,
+    no host copies; the .flo equals the default class's byte for byte, and the steady-state loop reproduces it (the CLI
+    compares every repetition with the first flow)."""
+    exe = os.path.join(ROOT, "eppm_amd", "lib", "runeppm")
+    outs = []
+    for extra in ([], ["--pin"]):
+        o = str(tmp_path / ("flow%d.flo" % len(outs)))
+        r = subprocess.run([exe, "--size", "320x200", "--pairs", "5", "--out", o] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(open(o, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) == 12 + 320 * 200 * 8
+
+
+def test_config1_single_scale_full_size(frames):
+    """BASELINE configs[0] reads "single scale": levels = 1 (PYR_MAX_DEPTH 1: PatchMatch, post-processing and the final
+    smoothing all at full resolution, no coarse-to-fine step) on the whole 640x480 bundled pair with default parameters,
+    against the live oracle (about 40 s on 16 threads)."""
+    import eppm_amd
+    from oracle import oracle as O
+    a, b = frames
+    e = eppm_amd.EPPM(params=eppm_amd.Params(levels=1))
+    e.init(a, b, 480, 640)
+    u, v = e.compute_flow()
+    e.close()
+    ou, ov = O.compute_flow(a, b, O.default_params(levels=1))
+    assert np.array_equal(u.view(np.uint32), ou.view(np.uint32)) and np.array_equal(v.view(np.uint32), ov.view(np.uint32))
+
+
 def test_config4_hd_pair_bit_exact():
     """BASELINE configs[3]: 1920x1080, full pyramid + bilateral refine (the non-split tiled refine with many tiles, XCD tile
     order, two-pixel-per-lane smoothing)."""
@@ -211,7 +316,10 @@ def _fuzz_case(seed, t):
     return a, b, params
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
+FUZZ_SEEDS = [11, 12, 13, 14, 15, 16, 17, 18]
+
+
+@pytest.mark.parametrize("seed", FUZZ_SEEDS)
 def test_fuzz_parity_fixed_seeds(seed):
     import eppm_amd
     from oracle import oracle as O
@@ -227,14 +335,17 @@ def test_fuzz_parity_fixed_seeds(seed):
         assert same, f"fuzz seed {seed} case {t}: {w}x{h} {params}"
 
 
-def test_fuzz_parity_window_kernels_at_small_sizes():
-    """The fuzz sweep again in a child process with EPPM_C2F_NO_SPLIT=1: the candidate refine of small images then runs the
-    LDS-window kernels (k_c2f_refine_win / _win4) instead of the split gather kernel they normally get, at ragged sizes,
-    radii 9 and 17, every propagation mode and pyramid depth."""
-    env = dict(os.environ, EPPM_C2F_NO_SPLIT="1")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "test_fuzz_parity_fixed_seeds"],
-                         env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
-    assert out.returncode == 0 and "8 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+@pytest.mark.parametrize("seed", FUZZ_SEEDS)
+def test_fuzz_parity_window_kernels_at_small_sizes(seed):
+    """The fuzz sweep again with the test switch "c2f_no_split" (eppm_test_set_option): the candidate refine of small images then
+    runs the LDS-window kernels (k_c2f_refine_win / _win4) instead of the split gather kernel they normally get, at ragged
+    sizes, radii 9 and 17, every propagation mode and pyramid depth."""
+    import eppm_amd
+    assert eppm_amd.lib().eppm_test_set_option(b"c2f_no_split", 1) == 0
+    try:
+        test_fuzz_parity_fixed_seeds(seed)
+    finally:
+        eppm_amd.lib().eppm_test_set_option(b"c2f_no_split", 0)
 
 
 # ---------------------------------------------------------------------------------------------------

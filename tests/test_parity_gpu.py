@@ -91,12 +91,23 @@ def test_patchmatch_substages(S, O, L1):
     cost = S.pm_cost_field(nnf, P)
     ocost = O.cost_field(onnf, i1, i2, c1, c2)
     eq(cost, ocost, "initial cost field")
-    for it in range(2):
+    import eppm_amd
+    L = eppm_amd.lib()
+    for it in range(3):
         for d in range(4):
+            # both forms of the sweep on the same state: classic, and speculative (phase A + phase B; the context path uses it
+            # from the fourth iteration on, here it also meets the first iterations' many accepted candidates)
+            try:
+                assert L.eppm_test_set_option(b"sweep_spec", 1) == 0
+                scost, snnf = S.pm_seg_propagate(cost, nnf, P, d)
+            finally:
+                L.eppm_test_set_option(b"sweep_spec", -1)
             cost, nnf = S.pm_seg_propagate(cost, nnf, P, d)
             ocost, onnf = O.seg_propagate_dir(ocost, onnf, i1, i2, c1, c2, d)
             eq(nnf, onnf, f"NNF after propagate dir {d} iter {it}")
             eq(cost, ocost, f"cost after propagate dir {d} iter {it}")
+            eq(snnf, onnf, f"NNF after speculative propagate dir {d} iter {it}")
+            eq(scost, ocost, f"cost after speculative propagate dir {d} iter {it}")
         cost, nnf = S.pm_random_search(rng, cost, nnf, P)
         ostates, ocost, onnf = O.random_search(ostates, ocost, onnf, i1, i2, c1, c2)
         eq(nnf, onnf, f"NNF after random search iter {it}")
@@ -191,13 +202,22 @@ def test_c2f_refine_window_and_fallback_paths(S, O, crop_stages):
 
     z = np.zeros((h, w))
     run(z + 3.7, z - 2.2, "constant flow (coherent everywhere)")
-    fx, fy = z.copy(), z.copy()
-    fx[:, 8::16] = 17.0            # one column per tile shifted: centre spread = 15 + 17 = 32 <= 33 (coherent) ...
-    fy[8::16, :] = 9.0             # ... rows: 15 + 9 = 24 <= 25
-    run(fx, fy, "spread just inside the window")
-    fx[:, 8::16] = 19.0            # 15 + 19 = 34 > 33: those tiles take the fallback
-    fy[8::16, :] = 11.0
-    run(fx, fy, "spread just outside the window")
+    # The admissible spread of a tile's candidate centres (eppm_probe_c2f_window).  Shifting the LAST column (row) of every
+    # 16x16 tile by d makes the spread exactly 15 + d: one below the limit, at the limit (the window's last column / row is
+    # read), and one past it (fallback).  An off-by-one here reads a texel of the next window row: caught bit for bit.
+    import ctypes as C
+    from eppm_amd import lib
+    sx, sy = C.c_int(), C.c_int()
+    assert lib().eppm_probe_c2f_window(9, C.byref(sx), C.byref(sy)) == 0
+    for dxs, dys in ((-1, -1), (0, 0), (1, 1), (0, -40), (-40, 0), (1, -40), (-40, 1)):
+        fx, fy = z.copy(), z.copy()
+        fx[:, 15::16] = sx.value - 15 + dxs
+        fy[15::16, :] = sy.value - 15 + dys
+        run(fx, fy, "centre spread = limit %+d (x), limit %+d (y)" % (dxs, dys))
+        fx, fy = z.copy(), z.copy()                   # the same with the first column / row pulled the other way
+        fx[:, 0::16] = -(sx.value - 15 + dxs)
+        fy[0::16, :] = -(sy.value - 15 + dys)
+        run(fx, fy, "centre spread = limit %+d (x), limit %+d (y), negative side" % (dxs, dys))
     run(rng.integers(-40, 41, (h, w)), rng.integers(-40, 41, (h, w)), "random jumps (incoherent)")
     run(z - 300.0, z + 250.0, "targets far outside the image")
     fx, fy = rng.normal(0, 1.5, (h, w)) + 5, rng.normal(0, 1.5, (h, w)) - 4
@@ -241,6 +261,14 @@ def test_c2f_refine_window_and_fallback_paths(S, O, crop_stages):
     p17 = eppm_amd.Params(patch_r=17)
     S.set_params(p17)
     try:
+        assert lib().eppm_probe_c2f_window(17, C.byref(sx), C.byref(sy)) == 0
+        for dxs, dys in ((-1, -1), (0, 0), (1, 1), (0, -40), (-40, 0)):
+            fx, fy = z.copy(), z.copy()
+            fx[:, 15::16] = sx.value - 15 + dxs
+            fy[15::16, :] = sy.value - 15 + dys
+            f = np.zeros((h, w), O.float2)
+            f["x"], f["y"] = fx.astype(np.float32), fy.astype(np.float32)
+            eq(S.c2f_refine(f, P0), O.c2f_refine(f, i1, i2, c1, c2, O.default_params(patch_r=17)), "R=17 centre spread = limit %+d (x), %+d (y)" % (dxs, dys))
         for fx, fy, what in ((z + 2.0, z - 1.0, "R=17 constant flow"), (rng.integers(-30, 31, (h, w)), rng.integers(-30, 31, (h, w)), "R=17 random jumps"),
                              (rng.normal(0, 2.5, (h, w)) + 6, rng.normal(0, 2.5, (h, w)) - 3, "R=17 noisy flow")):
             f = np.zeros((h, w), O.float2)
@@ -352,6 +380,31 @@ def test_sweep_and_search_parameter_extremes(frames, params):
     a, b = frames
     u, v, ou, ov = _run_both(a[40:231, 100:421].copy(), b[40:231, 100:421].copy(), **params)
     eq(u, ou, f"u {params}"); eq(v, ov, f"v {params}")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("params,region", [
+    (dict(), (slice(40, 231), slice(100, 421))),
+    (dict(seg_len=16, num_iter=5), (slice(40, 231), slice(100, 421))),        # the longest segments phase B takes (16 lanes per chain)
+    (dict(seg_len=17, num_iter=4), (slice(40, 231), slice(100, 421))),        # one more: classic form whatever the switch says
+    (dict(seg_len=2, num_iter=4), (slice(100, 223), slice(200, 357))),        # two steps per chain, odd size
+    (dict(patch_r=17, num_iter=4), (slice(0, 192), slice(0, 256))),           # radius 17: 64 lanes per chain
+    (dict(patch_r=5, num_iter=3), (slice(0, 128), slice(0, 192))),            # no instantiation for this radius: classic fallback
+    (dict(levels=1, num_iter=4), (slice(180, 300), slice(240, 400))),         # single scale
+])
+def test_speculative_sweeps_forced_on_and_off(frames, params, region, mode):
+    """The speculative two-launch sweeps (phase A evaluates every pixel's rejection-path candidate in parallel, phase B walks
+    the chains) against the classic dependent-step kernel: forced for EVERY iteration (mode 1: also the first ones, where most
+    steps follow an accepted candidate and phase B evaluates) and forced off (mode 0), both == the oracle bit for bit."""
+    import eppm_amd
+    a, b = frames
+    L = eppm_amd.lib()
+    try:
+        assert L.eppm_test_set_option(b"sweep_spec", mode) == 0
+        u, v, ou, ov = _run_both(a[region].copy(), b[region].copy(), **params)
+    finally:
+        L.eppm_test_set_option(b"sweep_spec", -1)
+    eq(u, ou, f"u {params} sweep_spec={mode}"); eq(v, ov, f"v {params} sweep_spec={mode}")
 
 
 def test_bundled_pair_full_size(frames):

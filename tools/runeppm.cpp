@@ -14,6 +14,7 @@
 //   --gpus G          G worker threads, one context per GPU; the P pairs are dealt round-robin (pair i -> GPU i mod G)
 //   --batch B         each worker runs its pairs B at a time through a batch context (eppm_create_batch: every kernel launch
 //                     covers the B pairs); default 1 = the drop-in class, one pair per launch
+//   --pin             set_option("pin_caller_buffers", 1): the class registers the image and flow blocks for DMA, no host copies
 //   --out file.flo    output name (same as the third positional argument)
 //   --gt file.flo     print EPE / AAE of the result against a ground-truth .flo (bao_flow_tools.cpp:64-111)
 #include <atomic>
@@ -85,6 +86,7 @@ static bool apply_opt(eppm_params& p, const std::string& name, long long v)
     else if (name == "seed") p.seed = (unsigned long long)v;
     else if (name == "propagation") p.propagation = (int)v;
     else if (name == "levels") p.levels = (int)v;
+    else if (name == "pin_caller_buffers") return true;      // an option of the class, not of eppm_params
     else return false;
     return true;
 }
@@ -92,7 +94,7 @@ static bool apply_opt(eppm_params& p, const std::string& name, long long v)
 static int usage()
 {
     fprintf(stderr, "usage: runeppm [--size WxH] [--seed N] [--levels N] [--patch-r N] [--iters N] [--propagation M]\n"
-                    "               [--pairs P] [--gpus G] [--batch B] [--gt file.flo] [--out file.flo] [img1.ppm img2.ppm [out.flo]]\n");
+                    "               [--pin] [--pairs P] [--gpus G] [--batch B] [--gt file.flo] [--out file.flo] [img1.ppm img2.ppm [out.flo]]\n");
     return 2;
 }
 
@@ -114,6 +116,7 @@ int main(int argc, char** argv)
         else if (!strcmp(a, "--pairs")) { if (!val(&v) || v < 1) return usage(); o.pairs = (int)v; }
         else if (!strcmp(a, "--gpus")) { if (!val(&v) || v < 1) return usage(); o.gpus = (int)v; }
         else if (!strcmp(a, "--batch")) { if (!val(&v) || v < 1) return usage(); o.batch = (int)v; }
+        else if (!strcmp(a, "--pin")) o.opts.push_back({"pin_caller_buffers", 1});
         else if (!strcmp(a, "--gt")) { if (i + 1 >= argc) return usage(); o.gt = argv[++i]; }
         else if (!strcmp(a, "--out")) { if (i + 1 >= argc) return usage(); o.fo = argv[++i]; }
         else if (a[0] == '-' && a[1] == '-') return usage();

@@ -121,11 +121,17 @@ void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t
 // RT = 9 / 17: the source samples of the workgroup's 16x4 pixels come from an LDS tile (16+2R)x(4+2R), loaded once,
 // clamped at load -- one LDS read per sample instead of a clamped address and a gather; RT = 0: any radius, source
 // samples gathered from the plane.
-template <int RT>
-__device__ __forceinline__ float search_patch_dist(const Planes& P, const PatchLut& L, int R, const float4* __restrict__ s_src, int TW,
+template <int RT> struct SearchLut { using type = PatchLutT<RT + 1>; };
+template <> struct SearchLut<0> { using type = PatchLut; };          // any radius the ABI accepts
+
+__device__ __forceinline__ float patch_dist_any(const Planes& P, const PatchLut& L, int R, int x1, int y1, int x2, int y2) { return patch_dist(P, L, R, x1, y1, x2, y2); }
+template <int M> __device__ __forceinline__ float patch_dist_any(const Planes&, const PatchLutT<M>&, int, int, int, int, int) { return 0.0f; }   // never called (RT != 0)
+
+template <int RT, class LUT>
+__device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L, int R, const float4* __restrict__ s_src, int TW,
                                                    int tx, int ty, int x1, int y1, int x2, int y2)
 {
-    if (RT == 0) return patch_dist(P, L, R, x1, y1, x2, y2);
+    if (RT == 0) return patch_dist_any(P, L, R, x1, y1, x2, y2);
     constexpr int S = RT + 1;
     const int pitch16 = P.pitch << 4;
     const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
@@ -400,21 +406,59 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
 //      rejection takes its cost from phase A's plane; only a step that follows an ACCEPTED candidate evaluates (cooperatively,
 //      as in the classic form).  In the converged iterations phase B is ten compare-and-select steps.
 // ---------------------------------------------------------------------------------------------------
-template <int RT, bool IS_ROW, bool REVERSE>
+// WIN (R = 9): the TARGET samples come from LDS too.  The candidates of a block are its neighbours' matches shifted by one
+// pixel, and in the iterations this form runs in the matches of a 16x16 block differ by a pixel or two except at motion
+// boundaries and at the outliers the left-right check will remove: the block votes (a histogram of candidate - pixel offsets per
+// axis, the densest run of SP+1 values wins), loads the (16 + 2R + SP)^2 window of the target image those offsets reach -- cells
+// clamped to the image at load, like the source tile -- and every lane whose offset lies in the winning run reads its 100 target
+// texels with one ds_read_b128 each, no clamps, no gathers.  The other lanes are listed last and gather as before.  The L1
+// serves one 16-byte lane-fetch per clock and CU (tools/ubench/gather_rate.hip), which bounded this kernel; LDS serves eight.
+template <int RT> struct SpecGeom { static constexpr int SP = 9, WW = kBlock + 2 * RT + SP; };
+
+template <int RT, int WW, class LUT>
+__device__ __forceinline__ float window_patch_dist(const LUT& L, const float4* __restrict__ s_src, int TW, int tx, int ty,
+                                                   const float4* __restrict__ s_win, int wx, int wy)
+{
+    // (wx, wy): window cell of the candidate itself; the sample (i, j) lies RT-relative at (wy + i, wx + j)
+    constexpr int S = RT + 1;
+    const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
+    const rgbf c2 = texel_rgb(s_win[wy * WW + wx]);
+    float cost_sum = 0.0f, weight_sum = 0.0f;
+    for (int ii = 0; ii < S; ii++) {
+        const float4* __restrict__ srow = s_src + (ty + 2 * ii) * TW + tx;
+        const float4* __restrict__ wrow = s_win + (wy + 2 * ii - RT) * WW + wx - RT;
+#pragma unroll
+        for (int jj = 0; jj < S; jj++) {
+            float ct, wt;
+            patch_terms(srow[2 * jj], wrow[2 * jj], c1, c2, L.gsp[ii * S + jj], L.cnx, ct, wt);
+            cost_sum += ct;
+            weight_sum += wt;
+        }
+    }
+    return cost_sum / weight_sum;
+}
+
+template <int RT, bool IS_ROW, bool REVERSE, bool WIN>
 __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* __restrict__ lut, int R, int gx)
 {
+    using LUT = typename SearchLut<RT>::type;
     constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT;
+    constexpr int SP = SpecGeom<RT>::SP, WW = WIN ? SpecGeom<RT>::WW : 1, HB = 128, HO = 64;      // histogram: offsets -64 .. 63
     __shared__ float4 s_src[TW * TW];
-    __shared__ PatchLut L;
-    __shared__ uint32_t s_list[256];       // compacted work: pixel index inside the block
+    __shared__ float4 s_win[WW * WW];
+    __shared__ LUT L;
+    __shared__ uint32_t s_list[256];       // compacted work: pixel index inside the block (window lanes first, gather lanes from the end)
     __shared__ int s_cand[256];            // its candidate, x | y << 16
-    __shared__ int s_wcount[4];
+    __shared__ int s_wcount[8];
+    __shared__ int s_hist[WIN ? 2 * HB : 1];
+    __shared__ int s_org[2];
     const unsigned nprob = B.n * B.npairs, bq = blockIdx.x % nprob, brest = blockIdx.x / nprob;
     const int bxx = brest % gx, byy = brest / gx;
     const PmProblem pr = pm_problem(B, bq);
     const Planes P = to_dev(pr.P);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     load_patch_lut(L, lut, R, tid, 256);
+    if (WIN) s_hist[tid] = 0;              // 2 * HB == 256
     if (RT != 0) {
         const int x0 = bxx * kBlock - RT, y0 = byy * kBlock - RT;
         for (int t = tid; t < TW * TW; t += 256) {
@@ -434,25 +478,74 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
         else        cy = REVERSE ? max(cy - 1, 0) : min(cy + 1, P.h - 1);
         need = !(cx == pr.nnf[ni] && cy == pr.nnf[ni + 1]);          // equal to the pixel's own match: rejected unevaluated
     }
-    // compaction: wave-level ballot + prefix, then the four wave counts
-    const unsigned long long bal = __ballot(need);
-    const int lane = tid & 63, wv = tid >> 6;
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wcount[wv] = __popcll(bal);
-    __syncthreads();                          // LUT, tile, wave counts
-    int base = 0, total = 0;
+    const int dx = cx - x, dy = cy - y;
+    bool inwin = false;
+    if (WIN) {
+        __syncthreads();                      // histogram zeroed
+        const bool votes = need && dx >= -HO && dx < HB - HO && dy >= -HO && dy < HB - HO;
+        if (votes) { atomicAdd(&s_hist[dx + HO], 1); atomicAdd(&s_hist[HB + dy + HO], 1); }
+        __syncthreads();
+        if (wv < 2) {                         // wave 0: x axis, wave 1: y axis; lane l scores the runs starting at bins l and l + 64
+            const int* hh = s_hist + wv * HB;
+            int best = -1, arg = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int c = s_wcount[k]; if (k < wv) base += c; total += c; }
+            for (int half = 0; half < 2; half++) {
+                const int b0 = lane + 64 * half;
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k <= SP; k++) sum += (b0 + k < HB) ? hh[b0 + k] : 0;
+                if (sum > best) { best = sum; arg = b0; }
+            }
+            int key = (best << 8) | (255 - arg);      // most votes, then the lowest start
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) key = max(key, __shfl_xor(key, o, 64));
+            if (lane == 0) s_org[wv] = (255 - (key & 255)) - HO;
+        }
+        __syncthreads();
+        const int ox = s_org[0], oy = s_org[1];           // offsets ox .. ox + SP (oy likewise) are served by the window
+        inwin = need && dx >= ox && dx <= ox + SP && dy >= oy && dy <= oy + SP;
+        // window cell (0,0) = image (bxx*16 + ox - RT, byy*16 + oy - RT), clamped at load
+        const int wx0 = bxx * kBlock + ox - RT, wy0 = byy * kBlock + oy - RT;
+        if (__syncthreads_or(inwin)) {
+            for (int t = tid; t < WW * WW; t += 256) {
+                const int sy = iclamp(wy0 + t / WW, 0, P.h - 1), sx = iclamp(wx0 + t % WW, 0, P.w - 1);
+                s_win[t] = P.pk2[(unsigned)(sy * P.pitch + sx)];
+            }
+        }
+    }
+    // compaction: wave-level ballots + prefixes, then the wave counts; window lanes fill the list from the front, gather lanes
+    // from the back, so that a wave holds lanes of one kind (except the one that straddles)
+    const unsigned long long balw = __ballot(need && inwin), balg = __ballot(need && !inwin);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) { s_wcount[wv] = __popcll(balw); s_wcount[4 + wv] = __popcll(balg); }
+    __syncthreads();                          // LUT, tile, window, wave counts
+    int basew = 0, totalw = 0, baseg = 0, totalg = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int a = s_wcount[k], g = s_wcount[4 + k];
+        if (k < wv) { basew += a; baseg += g; }
+        totalw += a; totalg += g;
+    }
+    const int total = totalw + totalg;
     if (need) {
-        s_list[base + before] = (uint32_t)tid;
-        s_cand[base + before] = (cx & 0xffff) | (cy << 16);
+        const int slot = inwin ? basew + __popcll(balw & below) : total - 1 - (baseg + __popcll(balg & below));
+        s_list[slot] = (uint32_t)tid;
+        s_cand[slot] = (cx & 0xffff) | (cy << 16);
     }
     __syncthreads();
     if (tid >= total) return;
     const int pix = (int)s_list[tid], e = s_cand[tid];
     const int tx = pix & 15, ty = pix >> 4;
     const int px = bxx * kBlock + tx, py = byy * kBlock + ty;
-    pr.spec[py * B.cpitch + px] = search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16);
+    const int ecx = (int)(int16_t)(e & 0xffff), ecy = e >> 16;
+    float cv;
+    if (WIN && tid < totalw) {
+        const int ox = s_org[0], oy = s_org[1];
+        cv = window_patch_dist<RT, WW>(L, s_src, TW, tx, ty, s_win, ecx - (bxx * kBlock + ox - RT), ecy - (byy * kBlock + oy - RT));
+    } else {
+        cv = search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, px, py, ecx, ecy);
+    }
+    pr.spec[py * B.cpitch + px] = cv;
 }
 
 // Fallback for patch radii without a cooperative instantiation: the reference's one-thread-per-chain form,
@@ -521,11 +614,15 @@ static void launch_sweep_spec(const PmBatch& b, const float* lut, int R, int dir
 {
     const int w = b.p[0].P.w, h = b.p[0].P.h, gx = (w + kBlock - 1) / kBlock, gy = (h + kBlock - 1) / kBlock;
     dim3 grid(gx * gy * (b.n * b.npairs)), block(256);
+#ifndef EPPM_SPEC_WINDOW
+#define EPPM_SPEC_WINDOW 1
+#endif
+    constexpr bool WIN = EPPM_SPEC_WINDOW && (RT == 9);      // radius 17: tile + window would leave one workgroup per CU
     switch (dir) {
-        case 0: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, false>), grid, block, 0, s, b, lut, R, gx); break;
-        case 1: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, false>), grid, block, 0, s, b, lut, R, gx); break;
-        case 2: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, true>), grid, block, 0, s, b, lut, R, gx); break;
-        default: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, true>), grid, block, 0, s, b, lut, R, gx); break;
+        case 0: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, false, WIN>), grid, block, 0, s, b, lut, R, gx); break;
+        case 1: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, false, WIN>), grid, block, 0, s, b, lut, R, gx); break;
+        case 2: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, true, WIN>), grid, block, 0, s, b, lut, R, gx); break;
+        default: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, true, WIN>), grid, block, 0, s, b, lut, R, gx); break;
     }
 }
 // phase B
@@ -708,17 +805,53 @@ void launch_pm_neighbor(const PmBatch& b, const float* lut, int R, hipStream_t s
 // pixels, the costs meet in LDS and wave 0 replays the reference's in-order strict-< selection.  The four
 // quarter-workgroups of a block draw the same numbers (cheap); only quarter 0 advances the stored state.
 // ---------------------------------------------------------------------------------------------------
-template <int RT>
+// WIN (R = 9): the guesses at radius <= WM (7, 3, 1, 1 of the default six) land within a few pixels of the pixel's current match, and the
+// current matches of the 64 pixels of a quarter-block agree to a pixel or two wherever the field has converged: the workgroup
+// votes on the offsets (match - pixel) as k_pm_sweep_spec does, loads the target window those offsets +- WM reach into LDS and the
+// guesses inside it read their 100 target texels from LDS.  The two wide guesses (radius 30, 15) and the lanes outside the window
+// gather as before: a third of the lane-fetches the L1 had to serve at one per clock.
+template <int RT> struct SearchGeom { static constexpr int WM = 7, SP = 6, WWX = kBlock + 2 * RT + 2 * WM + SP, WWY = 4 + 2 * RT + 2 * WM + SP; };
+
+template <int RT, int WWX, class LUT>
+__device__ __forceinline__ float search_window_patch_dist(const LUT& L, const float4* __restrict__ s_src, int TW, int tx, int ty,
+                                                          const float4* __restrict__ s_win, int wx, int wy)
+{
+    constexpr int S = RT + 1;
+    const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
+    const rgbf c2 = texel_rgb(s_win[wy * WWX + wx]);
+    float cost_sum = 0.0f, weight_sum = 0.0f;
+#pragma unroll 1
+    for (int ii = 0; ii < S; ii++) {
+        const float4* __restrict__ srow = s_src + (ty + 2 * ii) * TW + tx;
+        const float4* __restrict__ wrow = s_win + (wy + 2 * ii - RT) * WWX + wx - RT;
+#pragma unroll 5
+        for (int jj = 0; jj < S; jj++) {
+            float ct, wt;
+            patch_terms(srow[2 * jj], wrow[2 * jj], c1, c2, L.gsp[ii * S + jj], L.cnx, ct, wt);
+            cost_sum += ct;
+            weight_sum += wt;
+        }
+    }
+    return cost_sum / weight_sum;
+}
+
+template <int RT, bool WIN>
 __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
                                                           int search_range, int G)
 {
+    using LUT = typename SearchLut<RT>::type;
     constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT, TH = (RT == 0) ? 1 : 4 + 2 * RT;
+    constexpr int WM = SearchGeom<RT>::WM, SP = SearchGeom<RT>::SP, WWX = WIN ? SearchGeom<RT>::WWX : 1, WWY = WIN ? SearchGeom<RT>::WWY : 1;
+    constexpr int HB = 128, HO = 64;                  // vote histogram: offsets -64 .. 63 per axis
     __shared__ float4 s_src[TW * TH];
-    __shared__ PatchLut L;
+    __shared__ float4 s_win[WWX * WWY];
+    __shared__ LUT L;
     __shared__ int16_t s_rand[8 * 512];
     __shared__ float s_cost[8][64];
     __shared__ int s_guess[8][64];
     __shared__ uint32_t s_state[64 * 6];
+    __shared__ int s_hist[WIN ? 2 * HB : 1];
+    __shared__ int s_org[2];
     // problem = id mod nprob (one problem per XCD L2, see k_pm_sweep); the rest of the id walks the quarter-blocks row by row
     const unsigned nprob = B.n * B.npairs, bq = blockIdx.x % nprob, brest = blockIdx.x / nprob;
     const int bxx = brest % rng.gx, byy = brest / rng.gx;
@@ -727,6 +860,8 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     const int tile_y = byy >> 2, quarter = byy & 3;
     const int block_id = tile_y * rng.gx + bxx;
     load_patch_lut(L, lut, R, tid, blockDim.x);
+    if (WIN)
+        for (int t = tid; t < 2 * HB; t += blockDim.x) s_hist[t] = 0;
     if (tid < 64) {
         const size_t so = ((size_t)block_id * 64 + tid) * 6;
         Xorwow st = load_state(pr.rng_work + so);
@@ -772,26 +907,80 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     const bool inimg = (k < G) && (x < P.w && y < P.h);
     const int nidx = y * B.npitch + x, cidx = y * B.cpitch + x;
     int bx = 0, by = 0;
+    // sampling window of guess k: mag = search_range halved k times while >= 1 (:1564)
+    int mag = search_range;
+    for (int q = 0; q < k; q++) if (mag / 2 >= 1) mag /= 2;
+    if (inimg) { bx = pr.nnf[nidx * 2]; by = pr.nnf[nidx * 2 + 1]; }
+    int wx0 = 0, wy0 = 0;
+    bool win_loaded = false;
+    if (WIN) {
+        // vote of the 64 pixels' current offsets (wave 0 holds one pixel per lane, as every wave does)
+        const int odx = bx - x, ody = by - y;
+        if (k == 0 && inimg && odx >= -HO && odx < HB - HO && ody >= -HO && ody < HB - HO) {
+            atomicAdd(&s_hist[odx + HO], 1); atomicAdd(&s_hist[HB + ody + HO], 1);
+        }
+        __syncthreads();
+        if (k < 2) {                          // wave 0: x axis, wave 1: y axis; lane l scores the runs starting at bins l and l + 64
+            const int* hh = s_hist + k * HB;
+            int best = -1, arg = 0;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int b0 = lane + 64 * half;
+                int sum = 0;
+#pragma unroll
+                for (int q = 0; q <= SP; q++) sum += (b0 + q < HB) ? hh[b0 + q] : 0;
+                if (sum > best) { best = sum; arg = b0; }
+            }
+            int key = (best << 8) | (255 - arg);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) key = max(key, __shfl_xor(key, o, 64));
+            if (lane == 0) s_org[k] = (255 - (key & 255)) - HO;
+        }
+        __syncthreads();
+        // window cell (0,0) = image (block x0 + ox - WM - RT, quarter y0 + oy - WM - RT), clamped at load; it serves every guess whose
+        // offset from its pixel lies in [ox - WM, ox + SP + WM] x [oy - WM, oy + SP + WM]
+        wx0 = bxx * kBlock + s_org[0] - WM - RT;
+        wy0 = tile_y * kBlock + quarter * 4 + s_org[1] - WM - RT;
+    }
+    int gx = 0, gy = 0;
+    bool evaluate = false, use_win = false;
     if (inimg) {
-        bx = pr.nnf[nidx * 2]; by = pr.nnf[nidx * 2 + 1];
-        // sampling window of guess k: mag = search_range halved k times while >= 1 (:1564)
-        int mag = search_range;
-        for (int q = 0; q < k; q++) if (mag / 2 >= 1) mag /= 2;
         const uint32_t rdn1 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix];       // short -> unsigned int, :1558-1559
         const uint32_t rdn2 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix + 1];
         const int xmin = max(bx - mag, 0), xmax = min(bx + mag + 1, P.w + 1);
         const int ymin = max(by - mag, 0), ymax = min(by + mag + 1, P.h + 1);
-        const int gx = (int)(int16_t)((uint32_t)xmin + rdn1 % (uint32_t)(xmax - xmin));
-        const int gy = (int)(int16_t)((uint32_t)ymin + rdn2 % (uint32_t)(ymax - ymin));
+        gx = (int)(int16_t)((uint32_t)xmin + rdn1 % (uint32_t)(xmax - xmin));
+        gy = (int)(int16_t)((uint32_t)ymin + rdn2 % (uint32_t)(ymax - ymin));
 #ifndef EPPM_SEARCH_SKIP_SAME
 #define EPPM_SEARCH_SKIP_SAME 1
 #endif
         // A guess equal to the pixel's current match would reproduce the stored cost bit for bit (the skip rule of the sweeps): the
-        // reference evaluates and rejects it ("<"), here the lane sits the evaluation out -- a ninth of the radius-1 guesses, and
-        // in a kernel that runs at one L1 lane-fetch per clock an idle lane is time saved.
-        if (EPPM_SEARCH_SKIP_SAME && gx == bx && gy == by) s_cost[k][lane] = INFINITY;
-        else s_cost[k][lane] = search_patch_dist<RT>(P, L, R, s_src, TW, lane & 15, lane >> 4, x, y, gx, gy);
+        // reference evaluates and rejects it ("<"), here the lane sits the evaluation out -- a ninth of the radius-1 guesses.
+        evaluate = !(EPPM_SEARCH_SKIP_SAME && gx == bx && gy == by);
+        if (WIN) {
+            const int ux = gx - wx0 - (x - bxx * kBlock), uy = gy - wy0 - (y - (tile_y * kBlock + quarter * 4));   // = offset - org + WM + RT
+            use_win = evaluate && mag <= WM && ux >= RT && ux <= RT + SP + 2 * WM && uy >= RT && uy <= RT + SP + 2 * WM;
+        }
         s_guess[k][lane] = (gx & 0xffff) | (gy << 16);
+    }
+    if (WIN) {
+        // worth loading when the LDS reads it saves outnumber the loads it costs (100 target samples per guess)
+        win_loaded = __syncthreads_count(use_win) * 100 > 2 * WWX * WWY;
+        if (win_loaded) {
+            for (int t = tid; t < WWX * WWY; t += blockDim.x) {
+                const int sy = iclamp(wy0 + t / WWX, 0, P.h - 1), sx = iclamp(wx0 + t % WWX, 0, P.w - 1);
+                s_win[t] = P.pk2[(unsigned)(sy * P.pitch + sx)];
+            }
+        }
+        __syncthreads();
+    }
+    if (inimg) {
+        float cv = INFINITY;
+        if (evaluate) {
+            if (WIN && win_loaded && use_win) cv = search_window_patch_dist<RT, WWX>(L, s_src, TW, lane & 15, lane >> 4, s_win, gx - wx0, gy - wy0);
+            else cv = search_patch_dist<RT>(P, L, R, s_src, TW, lane & 15, lane >> 4, x, y, gx, gy);
+        }
+        s_cost[k][lane] = cv;
     }
     __syncthreads();
     if (k == 0 && inimg) {
@@ -813,9 +1002,13 @@ void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float*
                              hipStream_t s)
 {
     dim3 grid(rng.gx * rng.gy * 4 * b.n * b.npairs), block(64 * (num_guess + 1));      // + the wave that advances the RNG states
-    if (R == 9) hipLaunchKernelGGL(k_pm_random_search<9>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
-    else if (R == 17) hipLaunchKernelGGL(k_pm_random_search<17>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
-    else hipLaunchKernelGGL(k_pm_random_search<0>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+#ifndef EPPM_SEARCH_WINDOW
+#define EPPM_SEARCH_WINDOW 1
+#endif
+    if (R == 9 && EPPM_SEARCH_WINDOW) hipLaunchKernelGGL((k_pm_random_search<9, true>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+    else if (R == 9) hipLaunchKernelGGL((k_pm_random_search<9, false>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+    else if (R == 17) hipLaunchKernelGGL((k_pm_random_search<17, false>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+    else hipLaunchKernelGGL((k_pm_random_search<0, false>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
 }
 
 }  // namespace eppm

@@ -1,6 +1,7 @@
 """Copies the outputs of tools/gpu_round_end.sh (gpurun_out/<tag>/) into profiles/<tag>_* as per-kernel summaries and writes
-profiles/pmc_constants.json: the PMC-derived per-pair constants of the dominant kernel, keyed by the sha256 of the kernel
-sources they were measured on (bench.py emits null when the sources have changed since).  Usage: store_profiles.py r02_d"""
+profiles/pmc_constants.json: PMC-derived constants per shape -- the dominant kernel (the candidate refine) per launch size and the
+whole path per kernel group -- each valid only for the device sources it was measured on (sha256 inside; bench.py emits null
+when they have changed since).  Usage: store_profiles.py r03_x"""
 import csv, glob, hashlib, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
@@ -11,7 +12,7 @@ for f in glob.glob(f"{dst}/{tag}_*"):
 for name in ("bench_default.json", "bench_streams3.json", "bench_hd.json", "bench_4k_r17.json", "bench_under_rocprof.json", "bench_torchrun_2ranks_1gpu.json", "gpu_tests.txt"):
     if os.path.exists(f"{src}/{name}") and os.path.getsize(f"{src}/{name}") > 0:
         shutil.copy(f"{src}/{name}", f"{dst}/{tag}_{name}")
-for d in ("stats_default", "stats_single"):
+for d in ("stats_default", "stats_single", "stats_batch4"):
     f = glob.glob(f"{src}/{d}/*/*kernel_stats.csv")
     if f:
         shutil.copy(f[0], f"{dst}/{tag}_{d}_kernel_stats.csv")
@@ -22,40 +23,56 @@ for d in sorted(os.listdir(src)):
         open(f"{dst}/{tag}_{d}.csv", "w").write(out)
         summ[d] = list(csv.DictReader(out.splitlines()))
 
-
-def val(d, kernel, grid, counter):
-    rows = [r for r in summ[d] if r["kernel"].startswith(kernel) and (grid is None or int(r["grid"]) == grid)]
-    assert len(rows) == 1, (d, kernel, grid, [(r["kernel"], r["grid"]) for r in rows])
-    return float(rows[0][counter])
+VALU_PEAK = 256 * 4 * 2.4e9 / 2
+GROUPS = (("refine", ("k_c2f_refine", "k_c2f_select")), ("sweeps", ("k_pm_sweep", "k_pm_seg_propagate")), ("search", ("k_pm_random_search",)),
+          ("smoothing", ("k_flow_blf",)), ("weighted_median", ("k_wmf",)))
 
 
-W, H = 1024, 436
-n0, n1 = W * H, (W // 2) * (H // 2)
-tiles = lambda w, h: ((w + 15) // 16 + 0) * ((h + 15) // 16)
-g_win = lambda w, h, n: ((tiles(w, h) + 7) // 8) * 8 * 512 * n            # threads of a k_c2f_refine_win launch
-g_split4 = lambda w, h: ((tiles(w, h) + 7) // 8) * 8 * 4 * 256
-per_pair = {}
-for key, d_sfx, kern, grid, div in (("refine_win_L0", "single", "k_c2f_refine_win<9>", g_win(W, H, 1), 1),
-                                    ("refine_split4_L1", "single", "k_c2f_refine_tiled<9, 4>", g_split4(W // 2, H // 2), 1),
-                                    ("refine_win_L0_batch4", "batch4", "k_c2f_refine_win<9>", g_win(W, H, 4), 4),
-                                    ("refine_win_L1_batch4", "batch4", "k_c2f_refine_win<9>", g_win(W // 2, H // 2, 4), 4)):
-    per_pair[key] = {"valu_insts": val(f"pmc_sq_{d_sfx}", kern, grid, "SQ_INSTS_VALU") / div,
-                     "fetch_size_kb": val(f"pmc_fetch_{d_sfx}", kern, grid, "FETCH_SIZE") / div,
-                     "write_size_kb": val(f"pmc_write_{d_sfx}", kern, grid, "WRITE_SIZE") / div,
-                     "avg_us_under_pmc": val(f"pmc_sq_{d_sfx}", kern, grid, "avg_us") / div}
-srcs = ["eppm_amd/csrc/k_c2f.hip", "eppm_amd/csrc/eppm_device.cuh"]
-sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, f), "rb").read() for f in srcs)).hexdigest()
-# the whole path: wave64 VALU instructions of EVERY kernel per pair, from the 4-pairs-per-launch SQ pass (k_pm_init_field runs
-# once per batch: its call count gives the number of batches the profiled command processed); keyed by ALL device sources
+def group_of(kernel):
+    for g, pref in GROUPS:
+        if kernel.startswith(pref):
+            return g
+    return "other"
+
+
+def pairs_of(rows, nb):
+    """pairs the profiled command processed: k_pm_init_field runs once per launch sequence of nb pairs"""
+    return sum(float(r["calls"]) for r in rows if "k_pm_init_field" in r["kernel"]) * nb
+
+
+def per_pair(label, nb, kernels, counter, d_prefix):
+    rows = summ[f"{d_prefix}_{label}"]
+    return sum(float(r[counter]) * float(r["calls"]) for r in rows if r["kernel"].startswith(kernels)) / pairs_of(rows, nb)
+
+
 all_srcs = sorted(os.path.relpath(f, ROOT) for f in glob.glob(f"{ROOT}/eppm_amd/csrc/*.hip") + glob.glob(f"{ROOT}/eppm_amd/csrc/*.cuh"))
 sha_all = hashlib.sha256(b"".join(open(os.path.join(ROOT, f), "rb").read() for f in all_srcs)).hexdigest()
-rows4 = summ["pmc_sq_batch4"]
-batches = sum(float(r["calls"]) for r in rows4 if "k_pm_init_field" in r["kernel"])
-path = {"sources_sha256": sha_all, "kernel_sources": all_srcs, "pairs_per_launch": 4,
-        "valu_insts_per_pair": sum(float(r["SQ_INSTS_VALU"]) * float(r["calls"]) for r in rows4) / (batches * 4),
-        "kernel_us_per_pair_one_context": sum(float(r["avg_us"]) * float(r["calls"]) for r in rows4) / (batches * 4)}
-entry = {"width": W, "height": H, "patch_r": 9, "source": f"profiles/{tag}_pmc_*.csv (tools/gpu_round_end.sh, tools/store_profiles.py)",
-         "kernel_sources": srcs, "per_pair": per_pair, "path": path,
-         "note": "FETCH_SIZE counts the 128-B requests of 16-B-per-lane loads at 64 B on gfx950 (MI355X_MICROARCH.md, HBM): traffic = 2*FETCH + WRITE"}
-json.dump({sha: entry}, open(f"{dst}/pmc_constants.json", "w"), indent=1)
-print(json.dumps(per_pair, indent=1))
+REF = ("k_c2f_refine", "k_c2f_select")
+shapes = {}
+for key, labels in (("1024x436_r9", (("single", 1), ("batch4", 4))), ("1920x1080_r9", (("hd", 1),)), ("3840x2160_r17", (("uhd17", 1),))):
+    if not all(f"pmc_sq_{lb}" in summ and f"pmc_fetch_{lb}" in summ and f"pmc_write_{lb}" in summ for lb, _ in labels):
+        continue
+    dominant = {}
+    for lb, nb in labels:
+        # per PAIR, summed over the kernel's level-1 and level-0 launches
+        dominant[str(nb)] = {"valu_insts": per_pair(lb, nb, REF, "SQ_INSTS_VALU", "pmc_sq"), "fetch_size_kb": per_pair(lb, nb, REF, "FETCH_SIZE", "pmc_fetch"),
+                             "write_size_kb": per_pair(lb, nb, REF, "WRITE_SIZE", "pmc_write"), "us_under_pmc": per_pair(lb, nb, REF, "avg_us", "pmc_sq")}
+    lb, nb = labels[-1]
+    rows = summ[f"pmc_sq_{lb}"]
+    np_ = pairs_of(rows, nb)
+    by = {}
+    for r in rows:
+        g = by.setdefault(group_of(r["kernel"]), {"valu_insts_per_pair": 0.0, "kernel_us_per_pair": 0.0})
+        g["valu_insts_per_pair"] += float(r["SQ_INSTS_VALU"]) * float(r["calls"]) / np_
+        g["kernel_us_per_pair"] += float(r["avg_us"]) * float(r["calls"]) / np_
+    for g in by.values():
+        g["valu_issue_frac_under_pmc"] = g["valu_insts_per_pair"] / (g["kernel_us_per_pair"] * 1e-6) / VALU_PEAK if g["kernel_us_per_pair"] else None
+    shapes[key] = {"source": f"profiles/{tag}_pmc_*.csv (tools/gpu_round_end.sh, tools/store_profiles.py)", "kernel_sources": all_srcs, "sources_sha256": sha_all,
+                   "dominant": dominant,
+                   "path": {"pairs_per_launch": nb, "valu_insts_per_pair": sum(g["valu_insts_per_pair"] for g in by.values()),
+                            "kernel_us_per_pair_one_context": sum(g["kernel_us_per_pair"] for g in by.values()), "by_kernel_group": by}}
+json.dump({"note": "FETCH_SIZE counts the 128-B requests of 16-B-per-lane loads at 64 B on gfx950 (MI355X_MICROARCH.md, HBM): traffic = 2*FETCH + WRITE; "
+                   "dominant: the candidate refine per PAIR (level 1 + level 0) by pairs per launch; path: every kernel, one context",
+           "shapes": shapes}, open(f"{dst}/pmc_constants.json", "w"), indent=1)
+print(json.dumps({k: {"dominant": v["dominant"], "path_insts": v["path"]["valu_insts_per_pair"],
+                      "groups": {g: round(x["valu_issue_frac_under_pmc"] or 0, 3) for g, x in v["path"]["by_kernel_group"].items()}} for k, v in shapes.items()}, indent=1))

@@ -43,6 +43,7 @@ __device__ __forceinline__ PmProblem pm_problem(const PmBatch& B, unsigned q)
     p.nnf = pair_ptr_opt(p.nnf, B.stride, pair);
     p.nnf_alt = pair_ptr_opt(p.nnf_alt, B.stride, pair);
     p.spec = pair_ptr_opt(p.spec, B.stride, pair);
+    p.tq = pair_ptr_opt(p.tq, B.stride, pair);
     p.rng_work = pair_ptr_opt(p.rng_work, B.stride, pair);
     p.rng_work_next = pair_ptr_opt(p.rng_work_next, B.stride, pair);
     return p;
@@ -161,6 +162,64 @@ __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L
         }
     }
     return cost_sum / weight_sum;
+}
+
+// The same evaluation with the target samples from the packed parity planes (eppm_internal.h: PackedGeom): the S samples of a
+// patch row are S consecutive 4-byte words of one plane -- 16-, 16- and 8-byte fetches for S = 10 where the float4 plane needs ten
+// 16-byte ones -- and no coordinate is clamped (the planes carry replicated borders).  Requires 0 <= x2 <= w, 0 <= y2 <= h.
+struct __attribute__((packed, aligned(4))) Words4 { uint32_t a, b, c, d; };
+struct __attribute__((packed, aligned(4))) Words2 { uint32_t a, b; };
+
+template <int RT, class LUT>
+__device__ __forceinline__ float search_patch_dist_packed(const LUT& L, const float4* __restrict__ s_src, int TW, int tx, int ty,
+                                                          const uint32_t* __restrict__ tq, const PackedGeom& g, int x2, int y2)
+{
+    constexpr int S = RT + 1;
+    static_assert(S % 4 == 2, "row = whole 16-byte fetches + one 8-byte fetch");
+    const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
+    const int xc = x2 + g.padx;
+    const rgbf c2 = texel_rgb(unpack_texel(tq[(unsigned)((xc & 1) * (int)g.plane_words + (y2 + g.pady) * g.nk + (xc >> 1))]));
+    const int xs0 = x2 - RT + g.padx;
+    // byte offset of sample (row 0, column 0); rows 2 apart
+    unsigned off = (unsigned)((xs0 & 1) * (int)g.plane_words + (y2 - RT + g.pady) * g.nk + (xs0 >> 1)) * 4u;
+    const unsigned rstep = (unsigned)g.nk * 8u;
+    const char* __restrict__ base = reinterpret_cast<const char*>(tq);
+    float cost_sum = 0.0f, weight_sum = 0.0f;
+#pragma unroll 2
+    for (int ii = 0; ii < S; ii++, off += rstep) {
+        uint32_t wd[S];
+#pragma unroll
+        for (int j0 = 0; j0 + 4 <= S; j0 += 4) {
+            const Words4 q = *reinterpret_cast<const Words4*>(base + off + j0 * 4);
+            wd[j0] = q.a; wd[j0 + 1] = q.b; wd[j0 + 2] = q.c; wd[j0 + 3] = q.d;
+        }
+        {
+            const Words2 q = *reinterpret_cast<const Words2*>(base + off + (S - 2) * 4);
+            wd[S - 2] = q.a; wd[S - 1] = q.b;
+        }
+        const float4* __restrict__ srow = s_src + (ty + 2 * ii) * TW + tx;
+#pragma unroll
+        for (int jj = 0; jj < S; jj++) {
+            float ct, wt;
+            patch_terms(srow[2 * jj], unpack_texel(wd[jj]), c1, c2, L.gsp[ii * S + jj], L.cnx, ct, wt);
+            cost_sum += ct;
+            weight_sum += wt;
+        }
+    }
+    return cost_sum / weight_sum;
+}
+
+// target samples from the packed planes when the problem has them and the candidate lies where they reach, else gathered
+template <int RT, class LUT>
+__device__ __forceinline__ float eval_patch(const Planes& P, const LUT& L, int R, const float4* __restrict__ s_src, int TW, int tx, int ty,
+                                            int x1, int y1, int x2, int y2, const uint32_t* __restrict__ tq, const PackedGeom& g)
+{
+#ifndef EPPM_PACKED_TARGET
+#define EPPM_PACKED_TARGET 1
+#endif
+    if (EPPM_PACKED_TARGET && RT != 0 && tq != nullptr && (unsigned)x2 <= (unsigned)P.w && (unsigned)y2 <= (unsigned)P.h)
+        return search_patch_dist_packed<(RT == 0 ? 9 : RT)>(L, s_src, TW, tx, ty, tq, g, x2, y2);
+    return search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, x1, y1, x2, y2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -335,7 +394,12 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             const rgbf c1 = texel_rgb(TILE ? s_tile[lc + i] : tex_px(P.pk1, P.pitch, P.w, P.h, x, y));
             const rgbf c2 = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, px, py));
             float tc[CH], tw[CH];
-            constexpr int GB = (CH < EPPM_SWEEP_GB) ? CH : EPPM_SWEEP_GB;           // gathers in flight per lane
+#ifndef EPPM_SWEEP_GB_SPEC
+#define EPPM_SWEEP_GB_SPEC 3
+#endif
+            // gathers in flight per lane; phase B evaluates rarely and gains more from waves (one round of workgroups) than from depth
+            constexpr int GBW = SPEC ? EPPM_SWEEP_GB_SPEC : EPPM_SWEEP_GB;
+            constexpr int GB = (CH < GBW) ? CH : GBW;
 #pragma unroll
             for (int q0 = 0; q0 < CH; q0 += GB) {
                 float4 q1[GB], q2[GB];
@@ -406,59 +470,22 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
 //      rejection takes its cost from phase A's plane; only a step that follows an ACCEPTED candidate evaluates (cooperatively,
 //      as in the classic form).  In the converged iterations phase B is ten compare-and-select steps.
 // ---------------------------------------------------------------------------------------------------
-// WIN (R = 9): the TARGET samples come from LDS too.  The candidates of a block are its neighbours' matches shifted by one
-// pixel, and in the iterations this form runs in the matches of a 16x16 block differ by a pixel or two except at motion
-// boundaries and at the outliers the left-right check will remove: the block votes (a histogram of candidate - pixel offsets per
-// axis, the densest run of SP+1 values wins), loads the (16 + 2R + SP)^2 window of the target image those offsets reach -- cells
-// clamped to the image at load, like the source tile -- and every lane whose offset lies in the winning run reads its 100 target
-// texels with one ds_read_b128 each, no clamps, no gathers.  The other lanes are listed last and gather as before.  The L1
-// serves one 16-byte lane-fetch per clock and CU (tools/ubench/gather_rate.hip), which bounded this kernel; LDS serves eight.
-template <int RT> struct SpecGeom { static constexpr int SP = 9, WW = kBlock + 2 * RT + SP; };
-
-template <int RT, int WW, class LUT>
-__device__ __forceinline__ float window_patch_dist(const LUT& L, const float4* __restrict__ s_src, int TW, int tx, int ty,
-                                                   const float4* __restrict__ s_win, int wx, int wy)
-{
-    // (wx, wy): window cell of the candidate itself; the sample (i, j) lies RT-relative at (wy + i, wx + j)
-    constexpr int S = RT + 1;
-    const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
-    const rgbf c2 = texel_rgb(s_win[wy * WW + wx]);
-    float cost_sum = 0.0f, weight_sum = 0.0f;
-    for (int ii = 0; ii < S; ii++) {
-        const float4* __restrict__ srow = s_src + (ty + 2 * ii) * TW + tx;
-        const float4* __restrict__ wrow = s_win + (wy + 2 * ii - RT) * WW + wx - RT;
-#pragma unroll
-        for (int jj = 0; jj < S; jj++) {
-            float ct, wt;
-            patch_terms(srow[2 * jj], wrow[2 * jj], c1, c2, L.gsp[ii * S + jj], L.cnx, ct, wt);
-            cost_sum += ct;
-            weight_sum += wt;
-        }
-    }
-    return cost_sum / weight_sum;
-}
-
-template <int RT, bool IS_ROW, bool REVERSE, bool WIN>
+template <int RT, bool IS_ROW, bool REVERSE>
 __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* __restrict__ lut, int R, int gx)
 {
     using LUT = typename SearchLut<RT>::type;
     constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT;
-    constexpr int SP = SpecGeom<RT>::SP, WW = WIN ? SpecGeom<RT>::WW : 1, HB = 128, HO = 64;      // histogram: offsets -64 .. 63
     __shared__ float4 s_src[TW * TW];
-    __shared__ float4 s_win[WW * WW];
     __shared__ LUT L;
-    __shared__ uint32_t s_list[256];       // compacted work: pixel index inside the block (window lanes first, gather lanes from the end)
+    __shared__ uint32_t s_list[256];       // compacted work: pixel index inside the block
     __shared__ int s_cand[256];            // its candidate, x | y << 16
-    __shared__ int s_wcount[8];
-    __shared__ int s_hist[WIN ? 2 * HB : 1];
-    __shared__ int s_org[2];
+    __shared__ int s_wcount[4];
     const unsigned nprob = B.n * B.npairs, bq = blockIdx.x % nprob, brest = blockIdx.x / nprob;
     const int bxx = brest % gx, byy = brest / gx;
     const PmProblem pr = pm_problem(B, bq);
     const Planes P = to_dev(pr.P);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     load_patch_lut(L, lut, R, tid, 256);
-    if (WIN) s_hist[tid] = 0;              // 2 * HB == 256
     if (RT != 0) {
         const int x0 = bxx * kBlock - RT, y0 = byy * kBlock - RT;
         for (int t = tid; t < TW * TW; t += 256) {
@@ -478,57 +505,15 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
         else        cy = REVERSE ? max(cy - 1, 0) : min(cy + 1, P.h - 1);
         need = !(cx == pr.nnf[ni] && cy == pr.nnf[ni + 1]);          // equal to the pixel's own match: rejected unevaluated
     }
-    const int dx = cx - x, dy = cy - y;
-    bool inwin = false;
-    if (WIN) {
-        __syncthreads();                      // histogram zeroed
-        const bool votes = need && dx >= -HO && dx < HB - HO && dy >= -HO && dy < HB - HO;
-        if (votes) { atomicAdd(&s_hist[dx + HO], 1); atomicAdd(&s_hist[HB + dy + HO], 1); }
-        __syncthreads();
-        if (wv < 2) {                         // wave 0: x axis, wave 1: y axis; lane l scores the runs starting at bins l and l + 64
-            const int* hh = s_hist + wv * HB;
-            int best = -1, arg = 0;
+    // compaction: wave-level ballot + prefix, then the four wave counts: whole waves work or exit
+    const unsigned long long bal = __ballot(need);
+    if (lane == 0) s_wcount[wv] = __popcll(bal);
+    __syncthreads();                          // LUT, tile, wave counts
+    int base = 0, total = 0;
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int b0 = lane + 64 * half;
-                int sum = 0;
-#pragma unroll
-                for (int k = 0; k <= SP; k++) sum += (b0 + k < HB) ? hh[b0 + k] : 0;
-                if (sum > best) { best = sum; arg = b0; }
-            }
-            int key = (best << 8) | (255 - arg);      // most votes, then the lowest start
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) key = max(key, __shfl_xor(key, o, 64));
-            if (lane == 0) s_org[wv] = (255 - (key & 255)) - HO;
-        }
-        __syncthreads();
-        const int ox = s_org[0], oy = s_org[1];           // offsets ox .. ox + SP (oy likewise) are served by the window
-        inwin = need && dx >= ox && dx <= ox + SP && dy >= oy && dy <= oy + SP;
-        // window cell (0,0) = image (bxx*16 + ox - RT, byy*16 + oy - RT), clamped at load
-        const int wx0 = bxx * kBlock + ox - RT, wy0 = byy * kBlock + oy - RT;
-        if (__syncthreads_or(inwin)) {
-            for (int t = tid; t < WW * WW; t += 256) {
-                const int sy = iclamp(wy0 + t / WW, 0, P.h - 1), sx = iclamp(wx0 + t % WW, 0, P.w - 1);
-                s_win[t] = P.pk2[(unsigned)(sy * P.pitch + sx)];
-            }
-        }
-    }
-    // compaction: wave-level ballots + prefixes, then the wave counts; window lanes fill the list from the front, gather lanes
-    // from the back, so that a wave holds lanes of one kind (except the one that straddles)
-    const unsigned long long balw = __ballot(need && inwin), balg = __ballot(need && !inwin);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (lane == 0) { s_wcount[wv] = __popcll(balw); s_wcount[4 + wv] = __popcll(balg); }
-    __syncthreads();                          // LUT, tile, window, wave counts
-    int basew = 0, totalw = 0, baseg = 0, totalg = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int a = s_wcount[k], g = s_wcount[4 + k];
-        if (k < wv) { basew += a; baseg += g; }
-        totalw += a; totalg += g;
-    }
-    const int total = totalw + totalg;
+    for (int k = 0; k < 4; k++) { const int c = s_wcount[k]; if (k < wv) base += c; total += c; }
     if (need) {
-        const int slot = inwin ? basew + __popcll(balw & below) : total - 1 - (baseg + __popcll(balg & below));
+        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
         s_list[slot] = (uint32_t)tid;
         s_cand[slot] = (cx & 0xffff) | (cy << 16);
     }
@@ -537,15 +522,7 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
     const int pix = (int)s_list[tid], e = s_cand[tid];
     const int tx = pix & 15, ty = pix >> 4;
     const int px = bxx * kBlock + tx, py = byy * kBlock + ty;
-    const int ecx = (int)(int16_t)(e & 0xffff), ecy = e >> 16;
-    float cv;
-    if (WIN && tid < totalw) {
-        const int ox = s_org[0], oy = s_org[1];
-        cv = window_patch_dist<RT, WW>(L, s_src, TW, tx, ty, s_win, ecx - (bxx * kBlock + ox - RT), ecy - (byy * kBlock + oy - RT));
-    } else {
-        cv = search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, px, py, ecx, ecy);
-    }
-    pr.spec[py * B.cpitch + px] = cv;
+    pr.spec[py * B.cpitch + px] = eval_patch<RT>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16, pr.tq, B.tg);
 }
 
 // Fallback for patch radii without a cooperative instantiation: the reference's one-thread-per-chain form,
@@ -614,15 +591,11 @@ static void launch_sweep_spec(const PmBatch& b, const float* lut, int R, int dir
 {
     const int w = b.p[0].P.w, h = b.p[0].P.h, gx = (w + kBlock - 1) / kBlock, gy = (h + kBlock - 1) / kBlock;
     dim3 grid(gx * gy * (b.n * b.npairs)), block(256);
-#ifndef EPPM_SPEC_WINDOW
-#define EPPM_SPEC_WINDOW 1
-#endif
-    constexpr bool WIN = EPPM_SPEC_WINDOW && (RT == 9);      // radius 17: tile + window would leave one workgroup per CU
     switch (dir) {
-        case 0: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, false, WIN>), grid, block, 0, s, b, lut, R, gx); break;
-        case 1: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, false, WIN>), grid, block, 0, s, b, lut, R, gx); break;
-        case 2: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, true, WIN>), grid, block, 0, s, b, lut, R, gx); break;
-        default: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, true, WIN>), grid, block, 0, s, b, lut, R, gx); break;
+        case 0: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, false>), grid, block, 0, s, b, lut, R, gx); break;
+        case 1: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, false>), grid, block, 0, s, b, lut, R, gx); break;
+        case 2: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, true>), grid, block, 0, s, b, lut, R, gx); break;
+        default: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, true>), grid, block, 0, s, b, lut, R, gx); break;
     }
 }
 // phase B
@@ -805,53 +778,18 @@ void launch_pm_neighbor(const PmBatch& b, const float* lut, int R, hipStream_t s
 // pixels, the costs meet in LDS and wave 0 replays the reference's in-order strict-< selection.  The four
 // quarter-workgroups of a block draw the same numbers (cheap); only quarter 0 advances the stored state.
 // ---------------------------------------------------------------------------------------------------
-// WIN (R = 9): the guesses at radius <= WM (7, 3, 1, 1 of the default six) land within a few pixels of the pixel's current match, and the
-// current matches of the 64 pixels of a quarter-block agree to a pixel or two wherever the field has converged: the workgroup
-// votes on the offsets (match - pixel) as k_pm_sweep_spec does, loads the target window those offsets +- WM reach into LDS and the
-// guesses inside it read their 100 target texels from LDS.  The two wide guesses (radius 30, 15) and the lanes outside the window
-// gather as before: a third of the lane-fetches the L1 had to serve at one per clock.
-template <int RT> struct SearchGeom { static constexpr int WM = 7, SP = 6, WWX = kBlock + 2 * RT + 2 * WM + SP, WWY = 4 + 2 * RT + 2 * WM + SP; };
-
-template <int RT, int WWX, class LUT>
-__device__ __forceinline__ float search_window_patch_dist(const LUT& L, const float4* __restrict__ s_src, int TW, int tx, int ty,
-                                                          const float4* __restrict__ s_win, int wx, int wy)
-{
-    constexpr int S = RT + 1;
-    const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
-    const rgbf c2 = texel_rgb(s_win[wy * WWX + wx]);
-    float cost_sum = 0.0f, weight_sum = 0.0f;
-#pragma unroll 1
-    for (int ii = 0; ii < S; ii++) {
-        const float4* __restrict__ srow = s_src + (ty + 2 * ii) * TW + tx;
-        const float4* __restrict__ wrow = s_win + (wy + 2 * ii - RT) * WWX + wx - RT;
-#pragma unroll 5
-        for (int jj = 0; jj < S; jj++) {
-            float ct, wt;
-            patch_terms(srow[2 * jj], wrow[2 * jj], c1, c2, L.gsp[ii * S + jj], L.cnx, ct, wt);
-            cost_sum += ct;
-            weight_sum += wt;
-        }
-    }
-    return cost_sum / weight_sum;
-}
-
-template <int RT, bool WIN>
+template <int RT>
 __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
                                                           int search_range, int G)
 {
     using LUT = typename SearchLut<RT>::type;
     constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT, TH = (RT == 0) ? 1 : 4 + 2 * RT;
-    constexpr int WM = SearchGeom<RT>::WM, SP = SearchGeom<RT>::SP, WWX = WIN ? SearchGeom<RT>::WWX : 1, WWY = WIN ? SearchGeom<RT>::WWY : 1;
-    constexpr int HB = 128, HO = 64;                  // vote histogram: offsets -64 .. 63 per axis
     __shared__ float4 s_src[TW * TH];
-    __shared__ float4 s_win[WWX * WWY];
     __shared__ LUT L;
     __shared__ int16_t s_rand[8 * 512];
     __shared__ float s_cost[8][64];
     __shared__ int s_guess[8][64];
     __shared__ uint32_t s_state[64 * 6];
-    __shared__ int s_hist[WIN ? 2 * HB : 1];
-    __shared__ int s_org[2];
     // problem = id mod nprob (one problem per XCD L2, see k_pm_sweep); the rest of the id walks the quarter-blocks row by row
     const unsigned nprob = B.n * B.npairs, bq = blockIdx.x % nprob, brest = blockIdx.x / nprob;
     const int bxx = brest % rng.gx, byy = brest / rng.gx;
@@ -860,8 +798,6 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     const int tile_y = byy >> 2, quarter = byy & 3;
     const int block_id = tile_y * rng.gx + bxx;
     load_patch_lut(L, lut, R, tid, blockDim.x);
-    if (WIN)
-        for (int t = tid; t < 2 * HB; t += blockDim.x) s_hist[t] = 0;
     if (tid < 64) {
         const size_t so = ((size_t)block_id * 64 + tid) * 6;
         Xorwow st = load_state(pr.rng_work + so);
@@ -911,39 +847,8 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     int mag = search_range;
     for (int q = 0; q < k; q++) if (mag / 2 >= 1) mag /= 2;
     if (inimg) { bx = pr.nnf[nidx * 2]; by = pr.nnf[nidx * 2 + 1]; }
-    int wx0 = 0, wy0 = 0;
-    bool win_loaded = false;
-    if (WIN) {
-        // vote of the 64 pixels' current offsets (wave 0 holds one pixel per lane, as every wave does)
-        const int odx = bx - x, ody = by - y;
-        if (k == 0 && inimg && odx >= -HO && odx < HB - HO && ody >= -HO && ody < HB - HO) {
-            atomicAdd(&s_hist[odx + HO], 1); atomicAdd(&s_hist[HB + ody + HO], 1);
-        }
-        __syncthreads();
-        if (k < 2) {                          // wave 0: x axis, wave 1: y axis; lane l scores the runs starting at bins l and l + 64
-            const int* hh = s_hist + k * HB;
-            int best = -1, arg = 0;
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int b0 = lane + 64 * half;
-                int sum = 0;
-#pragma unroll
-                for (int q = 0; q <= SP; q++) sum += (b0 + q < HB) ? hh[b0 + q] : 0;
-                if (sum > best) { best = sum; arg = b0; }
-            }
-            int key = (best << 8) | (255 - arg);
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) key = max(key, __shfl_xor(key, o, 64));
-            if (lane == 0) s_org[k] = (255 - (key & 255)) - HO;
-        }
-        __syncthreads();
-        // window cell (0,0) = image (block x0 + ox - WM - RT, quarter y0 + oy - WM - RT), clamped at load; it serves every guess whose
-        // offset from its pixel lies in [ox - WM, ox + SP + WM] x [oy - WM, oy + SP + WM]
-        wx0 = bxx * kBlock + s_org[0] - WM - RT;
-        wy0 = tile_y * kBlock + quarter * 4 + s_org[1] - WM - RT;
-    }
     int gx = 0, gy = 0;
-    bool evaluate = false, use_win = false;
+    bool evaluate = false;
     if (inimg) {
         const uint32_t rdn1 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix];       // short -> unsigned int, :1558-1559
         const uint32_t rdn2 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix + 1];
@@ -957,28 +862,12 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
         // A guess equal to the pixel's current match would reproduce the stored cost bit for bit (the skip rule of the sweeps): the
         // reference evaluates and rejects it ("<"), here the lane sits the evaluation out -- a ninth of the radius-1 guesses.
         evaluate = !(EPPM_SEARCH_SKIP_SAME && gx == bx && gy == by);
-        if (WIN) {
-            const int ux = gx - wx0 - (x - bxx * kBlock), uy = gy - wy0 - (y - (tile_y * kBlock + quarter * 4));   // = offset - org + WM + RT
-            use_win = evaluate && mag <= WM && ux >= RT && ux <= RT + SP + 2 * WM && uy >= RT && uy <= RT + SP + 2 * WM;
-        }
         s_guess[k][lane] = (gx & 0xffff) | (gy << 16);
-    }
-    if (WIN) {
-        // worth loading when the LDS reads it saves outnumber the loads it costs (100 target samples per guess)
-        win_loaded = __syncthreads_count(use_win) * 100 > 2 * WWX * WWY;
-        if (win_loaded) {
-            for (int t = tid; t < WWX * WWY; t += blockDim.x) {
-                const int sy = iclamp(wy0 + t / WWX, 0, P.h - 1), sx = iclamp(wx0 + t % WWX, 0, P.w - 1);
-                s_win[t] = P.pk2[(unsigned)(sy * P.pitch + sx)];
-            }
-        }
-        __syncthreads();
     }
     if (inimg) {
         float cv = INFINITY;
         if (evaluate) {
-            if (WIN && win_loaded && use_win) cv = search_window_patch_dist<RT, WWX>(L, s_src, TW, lane & 15, lane >> 4, s_win, gx - wx0, gy - wy0);
-            else cv = search_patch_dist<RT>(P, L, R, s_src, TW, lane & 15, lane >> 4, x, y, gx, gy);
+            cv = eval_patch<RT>(P, L, R, s_src, TW, lane & 15, lane >> 4, x, y, gx, gy, pr.tq, B.tg);
         }
         s_cost[k][lane] = cv;
     }
@@ -1002,13 +891,9 @@ void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float*
                              hipStream_t s)
 {
     dim3 grid(rng.gx * rng.gy * 4 * b.n * b.npairs), block(64 * (num_guess + 1));      // + the wave that advances the RNG states
-#ifndef EPPM_SEARCH_WINDOW
-#define EPPM_SEARCH_WINDOW 1
-#endif
-    if (R == 9 && EPPM_SEARCH_WINDOW) hipLaunchKernelGGL((k_pm_random_search<9, true>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
-    else if (R == 9) hipLaunchKernelGGL((k_pm_random_search<9, false>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
-    else if (R == 17) hipLaunchKernelGGL((k_pm_random_search<17, false>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
-    else hipLaunchKernelGGL((k_pm_random_search<0, false>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+    if (R == 9) hipLaunchKernelGGL(k_pm_random_search<9>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+    else if (R == 17) hipLaunchKernelGGL(k_pm_random_search<17>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+    else hipLaunchKernelGGL(k_pm_random_search<0>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
 }
 
 }  // namespace eppm

@@ -279,7 +279,7 @@ int  eppm_test_set_option(const char* name, int value);
 int  eppm_probe_c2f_window(int patch_r, int* span_x, int* span_y);
 /* device-side arithmetic probes (parity of the shared float formulas): y[i] = f(x[i]) for n host floats */
 int  eppm_probe_fast_exp(const float* x, float* y, int n);
-int  eppm_probe_div_const(const float* x, float* y, int n, int which); /* 0: /(.1f*.1f) 1: /(.02f*.02f) 2: unorm8 (x = 0..255) */
+int  eppm_probe_div_const(const float* x, float* y, int n, int which); /* 0: /(.1f*.1f) 1: /(.02f*.02f) 2: unorm8 (x = 0..255) 3: unorm8, the two-operation form of the packed planes */
 
 /* ----------------------------------------------------------------------------------------
  * file formats used by the reference's CLI (main.cpp:56-69)

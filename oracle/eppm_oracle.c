@@ -86,9 +86,10 @@ void orc_set_num_threads(int n)
  *                   start, i.e. propagation along the whole line (a grid whose earlier blocks finish first,
  *                   bao_pmflow_kernel.cu:1059-1076 read nnf[start] live);
  *                 2 lockstep seeds, but pixel L is visited by segment 0 first (the other order of the two racing writes).
- *   post_inplace  1: outlier removal, weighted median, hole filling and the flow smoothing run in place in raster order (a
- *                   thread sees the results of threads that ran before it: refine :149-193, :206-259, :297-371, :764-799
- *                   read and write one buffer) instead of Jacobi.
+ *   post_inplace  bit mask: 1 outlier removal, 2 weighted median, 4 hole filling, 8 flow smoothing run in place in raster order
+ *                   (a thread sees the results of every thread before it: refine :149-193, :206-259, :297-371, :764-799 read and
+ *                   write one buffer) instead of Jacobi.  Raster order is the far end of what a grid can do; for the outlier
+ *                   vote it is degenerate (an invalidated pixel stops supporting its neighbours and the whole field cascades).
  *   exp_mode      1: libm expf (correctly rounded-ish) wherever the reference calls __expf, instead of the shared 2-ulp formula.
  *   seed_variant  1: another seed scrambling (seed ^ golden ratio before cuRAND's constants): a different but equally
  *                   plausible random stream.
@@ -794,7 +795,7 @@ void orc_outlier_removal(orc_short2* nnf, float* cost, int w, int h)
 {
     orc_short2* in_copy = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
     memcpy(in_copy, nnf, sizeof(orc_short2) * w * h);
-    const int inplace = g_var.post_inplace;                    /* variant: read the buffer being written, raster order */
+    const int inplace = (g_var.post_inplace & 1) != 0;                    /* variant: read the buffer being written, raster order */
     const orc_short2* in = inplace ? nnf : in_copy;
 #pragma omp parallel for schedule(static) if (!inplace)
     for (int y = 0; y < h; y++)
@@ -834,7 +835,7 @@ void orc_weighted_median(orc_short2* nnf, const orc_uchar4* img, int w, int h, i
     orc_wmf_lut(g);
     init_unorm();
     orc_short2* in_copy = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
-    const int inplace = g_var.post_inplace;                    /* variant: read the buffer being written, raster order */
+    const int inplace = (g_var.post_inplace & 2) != 0;                    /* variant: read the buffer being written, raster order */
     const orc_short2* in = inplace ? nnf : in_copy;
     for (int it = 0; it < num_iter; it++) {
         memcpy(in_copy, nnf, sizeof(orc_short2) * w * h);
@@ -884,7 +885,7 @@ void orc_fill_holes(orc_short2* nnf, const orc_uchar4* img, int w, int h)
     init_unorm();
     orc_short2* in_copy = (orc_short2*)malloc(sizeof(orc_short2) * w * h);
     memcpy(in_copy, nnf, sizeof(orc_short2) * w * h);
-    const int inplace = g_var.post_inplace;                    /* variant: read the buffer being written, raster order */
+    const int inplace = (g_var.post_inplace & 4) != 0;                    /* variant: read the buffer being written, raster order */
     const orc_short2* in = inplace ? nnf : in_copy;
 #pragma omp parallel for schedule(static) if (!inplace)
     for (int y = 0; y < h; y++)
@@ -1012,7 +1013,7 @@ void orc_flow_smoothing(orc_float2* flow, const orc_uchar4* img, int w, int h)
     init_unorm();
     orc_float2* in_copy = (orc_float2*)malloc(sizeof(orc_float2) * w * h);
     memcpy(in_copy, flow, sizeof(orc_float2) * w * h);
-    const int inplace = g_var.post_inplace;                    /* variant: read the buffer being written, raster order */
+    const int inplace = (g_var.post_inplace & 8) != 0;                    /* variant: read the buffer being written, raster order */
     const orc_float2* in = inplace ? flow : in_copy;
 #pragma omp parallel for schedule(static) if (!inplace)
     for (int y = 0; y < h; y++)

@@ -48,6 +48,7 @@ def test_div_const_bits(S):
     eq(S.probe_div_const(x, 1), (x / (np.float32(0.02) * np.float32(0.02))).astype(np.float32), "x/(.02f*.02f)")
     c = np.arange(256, dtype=np.float32)
     eq(S.probe_div_const(c, 2), (c / np.float32(255)).astype(np.float32), "unorm8")
+    eq(S.probe_div_const(c, 3), (c / np.float32(255)).astype(np.float32), "unorm8, two-operation form (texels of the packed parity planes)")
 
 
 def test_prepare_stages(S, O, crop):
@@ -113,6 +114,38 @@ def test_patchmatch_substages(S, O, L1):
         eq(nnf, onnf, f"NNF after random search iter {it}")
         eq(cost, ocost, f"cost after random search iter {it}")
         eq(rng.block_states(), ostates, f"RNG states after search iter {it}")
+
+
+def test_patchmatch_evaluation_kernels_with_arbitrary_nnf(S, O, L1):
+    """The one-evaluation-per-lane kernels (random search, phase A of the speculative sweeps) read their target samples from the
+    packed parity planes when the candidate lies in [0, w] x [0, h] and gather from the float4 plane otherwise.  An NNF as a
+    caller of the stage launchers may hand over -- targets on the last row / column, one past them (the reference's inclusive
+    random range), and far outside the image -- takes every lane through one path or the other inside the same waves."""
+    import eppm_amd
+    i1, i2, c1, c2 = L1
+    h, w = i1.shape
+    P = S.PlaneSet(i1, i2, c1, c2)
+    rng = np.random.default_rng(77)
+    nnf = np.zeros((h, w), O.short2)
+    nnf["x"] = rng.integers(0, w + 1, (h, w))
+    nnf["y"] = rng.integers(0, h + 1, (h, w))
+    m = rng.random((h, w))
+    nnf["x"][m < 0.05] = w; nnf["y"][(m > 0.05) & (m < 0.1)] = h               # one past the last column / row
+    nnf["x"][(m > 0.1) & (m < 0.13)] = -7; nnf["y"][(m > 0.13) & (m < 0.16)] = h + 40      # outside: gather path
+    nnf["x"][(m > 0.16) & (m < 0.18)] = w + 300
+    cost = O.cost_field(nnf, i1, i2, c1, c2)
+    eq(S.pm_cost_field(nnf, P), cost, "cost field of the arbitrary NNF")
+    L = eppm_amd.lib()
+    ocost, onnf = cost, nnf
+    try:
+        assert L.eppm_test_set_option(b"sweep_spec", 1) == 0
+        for d in range(4):
+            cost, nnf = S.pm_seg_propagate(cost, nnf, P, d)
+            ocost, onnf = O.seg_propagate_dir(ocost, onnf, i1, i2, c1, c2, d)
+            eq(nnf, onnf, f"NNF after speculative propagate dir {d}")
+            eq(cost, ocost, f"cost after speculative propagate dir {d}")
+    finally:
+        L.eppm_test_set_option(b"sweep_spec", -1)
 
 
 def test_patchmatch_launcher(S, O, crop_stages):

@@ -8,10 +8,12 @@ so a real CUDA run is ONE of many possible outputs.  This script runs the oracle
 
   sweep_serial     the segments of a line run one after the other in sweep direction with live seeds (propagation along the line)
   sweep_pixelL     lockstep seeds, but the doubly visited pixel L is reached by segment 0 before segment 1
-  post_inplace     outlier removal / weighted median / hole filling / flow smoothing read the buffer they write (raster order)
+  outlier_inplace, wmf_inplace, fill_inplace, smoothing_inplace
+                   that stage reads the buffer it writes, in raster order (the far end of what a grid can do; degenerate for the
+                   outlier vote, where every invalidated pixel stops supporting its neighbours)
   libm_expf        libm expf instead of the shared 2-ulp __expf formula
   other_stream     another seed scrambling (a different, equally plausible XORWOW stream)
-  all              all of the above together
+  all_but_outlier  all of the above together except the degenerate raster-order outlier vote
 
 on the bundled Middlebury pair (640x480) and on the 1024x436 synthetic pair of BASELINE configs[1].  Results go to
 profiles/parity_envelope.json (committed; DESIGN.md section 3.6 quotes them); tests/test_oracle_cpu.py pins the small case.
@@ -29,9 +31,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-VARIANTS = [("sweep_serial", dict(sweep_order=1)), ("sweep_pixelL", dict(sweep_order=2)), ("post_inplace", dict(post_inplace=1)),
-            ("libm_expf", dict(exp_mode=1)), ("other_stream", dict(seed_variant=1)),
-            ("all", dict(sweep_order=1, post_inplace=1, exp_mode=1, seed_variant=1))]
+VARIANTS = [("sweep_serial", dict(sweep_order=1)), ("sweep_pixelL", dict(sweep_order=2)),
+            ("outlier_inplace", dict(post_inplace=1)), ("wmf_inplace", dict(post_inplace=2)), ("fill_inplace", dict(post_inplace=4)),
+            ("smoothing_inplace", dict(post_inplace=8)), ("libm_expf", dict(exp_mode=1)), ("other_stream", dict(seed_variant=1)),
+            ("all_but_outlier", dict(sweep_order=1, post_inplace=14, exp_mode=1, seed_variant=1))]
 
 
 def epe_stats(u, v, u0, v0):

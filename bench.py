@@ -4,7 +4,7 @@
 A step = one pass of the hot path (set_data's device part: prefilter + pyramid + census, then
 compute_flow: PatchMatch fwd/bwd at 1/4 res, L-R check, outlier removal, weighted median, hole fill,
 two coarse-to-fine levels, final smoothing) over ONE synthetic 1024x436 pair whose RGBA planes are
-already resident in HBM.  Consecutive steps are issued in groups of --batch (default 4) to batch contexts
+already resident in HBM.  Consecutive steps are issued in groups of --batch (default 8) to batch contexts
 (eppm_create_batch: every kernel launch covers the group's pairs -- the quarter-resolution stages of ONE pair
 are too few pixels to fill 256 CUs), round robin over --inflight such contexts (default 3), each on its own HIP
 stream, so that the tail of one launch overlaps the next context's work; every step's work runs inside the timed
@@ -54,7 +54,7 @@ def parse_args(known_only=False):
     ap.add_argument("--patch-r", type=int, default=9)
     ap.add_argument("--inflight", type=int, default=3,
                     help="pairs in flight per GPU: steps are issued round robin over this many contexts, each on its own HIP stream")
-    ap.add_argument("--batch", type=int, default=4,
+    ap.add_argument("--batch", type=int, default=8,
                     help="pairs per launch sequence: > 1 groups consecutive steps into batch contexts (eppm_create_batch) whose every kernel launch "
                          "covers the whole group; --inflight such contexts are kept in flight")
     ap.add_argument("--pairs-per-gpu", type=int, default=8, help="size of the config-3 leg (distinct pairs per GPU)")
@@ -522,10 +522,14 @@ def approx_variant_leg(args):
         cmd = [sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", str(min(args.steps, 60)), "--warmup", str(args.warmup),
                "--batch", str(args.batch), "--inflight", str(args.inflight), "--width", str(args.width), "--height", str(args.height), "--patch-r", str(args.patch_r)]
         b = json.loads([ln for ln in subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600).stdout.splitlines() if ln.startswith("{")][-1])
-        e = json.loads([ln for ln in subprocess.run([sys.executable, os.path.join(ROOT, "tools", "approx_exp_epe.py")], env=env, capture_output=True,
-                                                    text=True, timeout=600).stdout.splitlines() if ln.startswith("{")][-1])
+        env2 = dict(env)
+        env2.pop("EPPM_HIP_VARIANT", None)
+        e = json.loads([ln for ln in subprocess.run([sys.executable, os.path.join(ROOT, "tools", "approx_exp_epe.py")], env=env2, capture_output=True,
+                                                    text=True, timeout=900).stdout.splitlines() if ln.startswith("{")][-1])
         return {"value": b["value"], "unit": b["unit"], "ms_per_step": b["ms_per_step"], "epe_vs_oracle_px": e["epe_mean_px"], "epe_pair": e["pair"],
-                "tolerance_px": 1e-3, "library": e["library"], "note": "opt-in build, not bit-identical to the oracle; the headline value is the exact library"}
+                "tolerance_px": 1e-3, "library": e["library"], "worst_case_mean_px": e["worst_case_mean_px"],
+                "epe_by_case": {k: {"mean": c["epe_mean_px"], "p99": c["epe_p99_px"], "max": c["epe_max_px"]} for k, c in e["cases"].items()},
+                "note": "opt-in build, not bit-identical to the oracle; EPE measured against the exact library (= the oracle bit for bit); the headline value is the exact library"}
     except Exception as ex:                      # a reported extra, never a reason to lose the line
         return {"error": str(ex)[:200]}
 

@@ -278,7 +278,6 @@ struct eppm_ctx {
     int16_t *nnf1 = nullptr, *nnf2 = nullptr, *nnf_tmp = nullptr, *nnf_tmp2 = nullptr;
     float *cost1 = nullptr, *cost2 = nullptr;
     float *spec1 = nullptr, *spec2 = nullptr;   // speculative sweeps: cost of every pixel's rejection-path candidate (phase A)
-    uint32_t *tq1 = nullptr, *tq2 = nullptr;    // packed parity planes of image 1 / 2 at the PatchMatch level (eppm_internal.h: PackedGeom), or NULL
     uint32_t* wmf_ws = nullptr;        // work lists + counters of the weighted median
     bool flow_pending = false;         // eppm_compute_begin issued, eppm_compute_end not yet
     float *flow[kMaxLevels] = {}, *flow_tmp[kMaxLevels] = {};
@@ -415,10 +414,6 @@ static int ctx_alloc(eppm_ctx* c)
     plane((void**)&c->cost2, n2 * 4);
     plane((void**)&c->spec1, n2 * 4);
     plane((void**)&c->spec2, n2 * 4);
-    if (c->prm.patch_r == 9 || c->prm.patch_r == 17) {          // the radii whose evaluation kernels read packed target planes
-        plane((void**)&c->tq1, packed_bytes(c->W[L], c->H[L], c->prm.patch_r));
-        plane((void**)&c->tq2, packed_bytes(c->W[L], c->H[L], c->prm.patch_r));
-    }
     plane((void**)&c->wmf_ws, wmf_workspace_words(c->W[L], c->H[L], c->prm.wmf_iters) * 4);
     plane((void**)&c->d_rgb, (size_t)h * w * 3 * 2);
     plane((void**)&c->d_color, (size_t)h * w * 4);
@@ -544,11 +539,6 @@ static int prepare(eppm_ctx* c)
             J.w = c->W[i]; J.h = c->H[i]; J.first_block = 0;
         }
     launch_census_batch(cb, s, bt);
-    if (c->tq1) {
-        const int L = c->nl - 1;
-        launch_pack_parity(c->tq1, c->img1[L], (int)(c->ipitch[L] / 4), c->cen1[L], (int)c->cpitch[L], c->W[L], c->H[L], c->prm.patch_r, s, bt);
-        launch_pack_parity(c->tq2, c->img2[L], (int)(c->ipitch[L] / 4), c->cen2[L], (int)c->cpitch[L], c->W[L], c->H[L], c->prm.patch_r, s, bt);
-    }
     stage_end(c, c->ev_prep);
     HIPCHK(hipGetLastError());
     c->have_images = true;
@@ -656,11 +646,10 @@ extern "C" int eppm_batch_set_images_device(eppm_ctx* c, int n, const void* cons
 }
 
 // ---- baoCudaPatchMatch (kernel.cu:1760-1826) for one problem or for the forward+backward pair at once ----
-static PmProblem mk_problem(const PlanesH& P, float* cost, int16_t* nnf, int16_t* nnf_alt, eppm_pm_rng* rng, int k, float* spec = nullptr,
-                            const uint32_t* tq = nullptr)
+static PmProblem mk_problem(const PlanesH& P, float* cost, int16_t* nnf, int16_t* nnf_alt, eppm_pm_rng* rng, int k, float* spec = nullptr)
 {
     PmProblem p;
-    p.P = P; p.cost = cost; p.nnf = nnf; p.nnf_alt = nnf_alt; p.spec = spec; p.tq = tq;
+    p.P = P; p.cost = cost; p.nnf = nnf; p.nnf_alt = nnf_alt; p.spec = spec;
     p.rng_work = rng ? rng->work[k][rng->cur[k]] : nullptr;
     p.rng_work_next = rng ? rng->work[k][rng->cur[k] ^ 1] : nullptr;
     return p;
@@ -674,17 +663,24 @@ static void search(PmBatch& b, eppm_pm_rng* rng, const float* lut, const eppm_pa
         rng->cur[k] ^= 1;
     }
 }
-// The sweeps of an iteration run in the speculative two-launch form (k_patchmatch.hip: k_pm_sweep_spec + phase B) once few
-// candidates are still accepted: from the third iteration on fewer than one step in ten follows an accepted candidate
-// (tools/sweep_stats.py), and a step that follows a rejection needs no dependent evaluation.  Same results either way.
+// The sweeps of an iteration run in the speculative two-launch form (k_patchmatch.hip: k_pm_sweep_spec + phase B) once most
+// candidates are rejected: in the third iteration (index 2) one step in eight to one in four still follows an accepted
+// candidate, from the fourth on fewer than one in ten (tools/sweep_stats.py), and a step that follows a rejection needs no
+// dependent evaluation.  Same results either way; from iteration 2 / 3 measured equal within 0.5 %, from 0 or 1 slower.
 #ifndef EPPM_SPEC_FROM_ITER
-#define EPPM_SPEC_FROM_ITER 3
+#define EPPM_SPEC_FROM_ITER 2
 #endif
 static std::atomic<int> g_sweep_spec{-1};      // test support ("sweep_spec"): -1 by iteration, 0 never, 1 always
-static bool sweep_speculative(int iteration)
+// A launch over one 1024x436 pair (two problems of 28 k pixels) is too small for the two-launch form to pay: phase A's evaluations
+// are one wave per SIMD, and the classic kernel at 32 lanes per chain finishes in 27 us where phase A + phase B take 19 + 16.  From
+// about a hundred thousand pixels per launch on (two such pairs; one 1920x1080 or 3840x2160 pair) the speculative form wins.
+#ifndef EPPM_SPEC_MIN_PIXELS
+#define EPPM_SPEC_MIN_PIXELS 100000
+#endif
+static bool sweep_speculative(int iteration, long long pixels)
 {
     const int m = g_sweep_spec.load();
-    return m < 0 ? iteration >= EPPM_SPEC_FROM_ITER : m != 0;
+    return m < 0 ? (iteration >= EPPM_SPEC_FROM_ITER && pixels >= EPPM_SPEC_MIN_PIXELS) : m != 0;
 }
 // one directional sweep on the batch; keeps the result in p[k].nnf (swaps the ping-pong pair when needed)
 static void sweep(PmBatch& b, const float* lut, const eppm_params& prm, int dir, hipStream_t s, bool speculative = false)
@@ -717,7 +713,7 @@ static void run_patchmatch(PmBatch& b, eppm_pm_rng* rng, const float* lut, const
     for (int it = 0; it < prm.num_iter; it++) {
         if (prm.propagation == 1) jump(b, lut, prm, s);
         else if (prm.propagation == 2) neighbor(b, lut, prm, 10, s);
-        else for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s, sweep_speculative(it));
+        else for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s, sweep_speculative(it, (long long)b.n * b.npairs * b.p[0].P.w * b.p[0].P.h));
         search(b, rng, lut, prm, s);
     }
 }
@@ -736,9 +732,8 @@ static int compute_all(eppm_ctx* c)
     {
         PmBatch b;
         b.n = 2; b.cpitch = lw; b.npitch = lw; b.npairs = bt.n; b.stride = bt.stride;
-        if (c->tq1) b.tg = packed_geom(lw, lh, c->prm.patch_r);
-        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0, c->spec1, c->tq2);     // driver :223 (target: image 2)
-        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1, c->spec2, c->tq1);     // driver :224 (target: image 1)
+        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0, c->spec1);     // driver :223
+        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1, c->spec2);     // driver :224
         run_patchmatch(b, c->rng, c->lut_pm, c->prm, s);
     }
     stage_end(c, c->ev);
@@ -976,8 +971,8 @@ namespace {
 struct DevState {
     float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
     int lut_R = -1;
-    void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+    void* scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[5] = {0, 0, 0, 0, 0};
     std::map<std::tuple<int, int, int, unsigned long long>, eppm_pm_rng*> rngs;
 };
 std::mutex g_mu;
@@ -1037,18 +1032,6 @@ int mk_planes(DevState* ds, PlanesH* out, const void* i1, const void* i2, const 
     launch_pack(a, w, (const uint32_t*)i1, (int)(ip / 4), (const uint8_t*)c1, (int)cp, w, h, g_stream);
     launch_pack(b, w, (const uint32_t*)i2, (int)(ip / 4), (const uint8_t*)c2, (int)cp, w, h, g_stream);
     out->pk1 = a; out->pk2 = b; out->w = w; out->h = h; out->pitch = w;
-    return EPPM_OK;
-}
-// packed parity planes of the target image (image 2) for the evaluation kernels of the context-less PatchMatch launchers (slot 5)
-int mk_packed_target(DevState* ds, PmBatch* b, const void* i2, const void* c2, int w, int h, size_t ip, size_t cp)
-{
-    const int R = g_prm.patch_r;
-    if (R != 9 && R != 17) return EPPM_OK;
-    void* q = nullptr;
-    CHK(get_scratch(ds, packed_bytes(w, h, R), &q, 5));
-    launch_pack_parity((uint32_t*)q, (const uint32_t*)i2, (int)(ip / 4), (const uint8_t*)c2, (int)cp, w, h, R, g_stream);
-    b->tg = packed_geom(w, h, R);
-    b->p[0].tq = (const uint32_t*)q;
     return EPPM_OK;
 }
 int finish() { HIPCHK(hipGetLastError()); return EPPM_OK; }
@@ -1141,7 +1124,6 @@ extern "C" int eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const ep
     const bool speculative = g_sweep_spec.load() == 1;         // the stand-alone entry point has no iteration count: classic unless forced
     if (speculative) CHK(get_scratch(ds, cost_pitch * h, &spec, 4));
     b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0, (float*)spec);
-    if (speculative) CHK(mk_packed_target(ds, &b, i2, c2, w, h, img_pitch, census_pitch));
     for (int d = 0; d < 4; d++)
         if (dir < 0 || dir == d) sweep(b, ds->lut_pm, g_prm, d, g_stream, speculative);
     if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
@@ -1191,7 +1173,6 @@ extern "C" int eppm_pm_random_search(eppm_pm_rng* r, float* d_cost, eppm_short2*
     PlanesH P;
     CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
     b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, nullptr, r, 0);
-    CHK(mk_packed_target(ds, &b, i2, c2, w, h, img_pitch, census_pitch));
     search(b, r, ds->lut_pm, g_prm, g_stream);
     return finish();
 }
@@ -1312,8 +1293,6 @@ extern "C" void baoCudaPatchMatch(eppm_short2* d_disp_vec, float* d_cost, eppm_u
     g_launch_status = get_scratch(ds, cost_pitch * h, &spec, 4);
     if (g_launch_status != EPPM_OK) return;
     b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0, (float*)spec);
-    g_launch_status = mk_packed_target(ds, &b, d_img2, d_census2, w, h, img_pitch, census_pitch);
-    if (g_launch_status != EPPM_OK) return;
     run_patchmatch(b, r, ds->lut_pm, g_prm, g_stream);
     if (b.p[0].nnf != (int16_t*)d_disp_vec && (g_launch_status = copy_d2d(d_disp_vec, b.p[0].nnf, disp_pitch * h)) != EPPM_OK) return;
     g_launch_status = finish();

@@ -86,10 +86,6 @@ __device__ __forceinline__ float div_wmf2(float x) { return div_const(x, kWmfSig
 // unorm8 -> float exactly as c/255.0f (cudaReadModeNormalizedFloat)
 __device__ __forceinline__ float unorm8(float c) { return div_const(c, 255.0f, 1.0f / 255.0f); }
 
-// The same value in two operations for the packed planes, whose texels are converted per fetch: 1/255 = khi + klo to 48 bits,
-// c * klo is exact enough to vanish in the one rounding of the fma.  Equal to c / 255.0f for all 256 bytes (tests: probe 3).
-__device__ __forceinline__ float unorm8_fast(float c) { return __builtin_fmaf(c, 0x1.010102p-8f, c * -0x1.fdfdfep-33f); }
-
 struct rgbf { float x, y, z; };
 
 __device__ __forceinline__ rgbf unpack_rgb(uint32_t p)
@@ -134,12 +130,6 @@ __device__ __forceinline__ float4 make_texel(uint32_t rgba, uint32_t census)
 {
     const rgbf c = unpack_rgb(rgba);
     return make_float4(c.x, c.y, c.z, __uint_as_float((census & 0xffu) << 2));
-}
-// a word of the packed parity planes -> the texel the float4 planes hold for that pixel, bit for bit
-__device__ __forceinline__ float4 unpack_texel(uint32_t w)
-{
-    return make_float4(unorm8_fast((float)(w & 0xffu)), unorm8_fast((float)((w >> 8) & 0xffu)), unorm8_fast((float)((w >> 16) & 0xffu)),
-                       __uint_as_float((w >> 22) & 0x3fcu));
 }
 __device__ __forceinline__ float census_cost(const float* __restrict__ cnx, uint32_t w1, uint32_t w2)
 {

@@ -53,29 +53,6 @@ void launch_census(uint8_t* census, int cpitch, void* texels, int tpitch, const 
 void launch_pack(void* texels, int tpitch, const uint32_t* img, int ipitch, const uint8_t* census, int cpitch, int w, int h, hipStream_t s);
 void launch_rgb_to_rgba(uint32_t* out, int pitch_px, const uint8_t* rgb, int h, int w, hipStream_t s, Batch bt = kOnePair);
 
-// ---- packed target planes of the PatchMatch level (k_prepare.hip: k_pack_parity; read by k_patchmatch.hip) ----
-// The one-evaluation-per-lane kernels (random search, phase A of the speculative sweeps) were bound by the L1, which serves one
-// 16-byte lane-fetch per clock and CU whatever the addresses (tools/ubench/gather_rate.hip): a float4 texel per fetch.  A patch
-// row is S samples two pixels apart, so the TARGET image is also kept as two planes of 4-byte texels {R, G, B, census} -- the
-// pixels of even and of odd x -- with replicated borders: the S samples of a row are S consecutive words of one plane (no
-// clamps: padx, pady cover every coordinate a candidate in [0, w] x [0, h] can reach) and arrive in S/4 fetches instead of S.
-// The u8 -> float conversion (c / 255.0f, exact, 3 operations per channel) moves back into the evaluation.
-struct PackedGeom {
-    int padx, pady;        // replicated columns (even) / rows on every side
-    int nk, rows;          // words per plane row, rows per plane
-    size_t plane_words;    // nk * rows; the odd plane follows the even one
-};
-inline PackedGeom packed_geom(int w, int h, int R)
-{
-    PackedGeom g;
-    g.padx = (R + 2) & ~1; g.pady = R + 1;
-    g.nk = (w + 2 * g.padx) / 2 + 2; g.rows = h + 2 * g.pady + 1;
-    g.plane_words = (size_t)g.nk * g.rows;
-    return g;
-}
-inline size_t packed_bytes(int w, int h, int R) { return packed_geom(w, h, R).plane_words * 2 * 4; }
-void launch_pack_parity(uint32_t* out, const uint32_t* img, int ipitch_px, const uint8_t* census, int cpitch, int w, int h, int R, hipStream_t s, Batch bt = kOnePair);
-
 // ---- PatchMatch (k_patchmatch.hip) ----
 // One PatchMatch problem = (source planes, target planes, NNF, cost).  The forward (1->2) and backward (2->1)
 // problems of a pair have the same size and run in the same launches (blockIdx.z / blockIdx.y selects one).
@@ -85,7 +62,6 @@ struct PmProblem {
     int16_t* nnf;        // short2, current
     int16_t* nnf_alt;    // short2, ping-pong partner for the sweeps
     float* spec = nullptr;   // speculative sweeps: phase A's cost of every pixel's rejection-path candidate (cost pitch), or NULL
-    const uint32_t* tq = nullptr;   // packed parity planes of the TARGET image (PmBatch::tg), or NULL: float4 gathers
     uint32_t* rng_work;       // [nblocks][64][6] XORWOW lane states read by the random search
     uint32_t* rng_work_next;  // ... written by it (ping-pong: four workgroups read each block's state, one advances it)
 };
@@ -95,7 +71,6 @@ struct PmBatch {
     int cpitch, npitch;  // elements
     int npairs = 1;      // a launch covers n * npairs problems
     size_t stride = 0;
-    PackedGeom tg = {0, 0, 0, 0, 0};   // geometry of PmProblem::tq
 };
 // RNG tables shared by both problems (same seed, same block ids: the reference re-initialises the states on
 // every baoCudaPatchMatch call, kernel.cu:160); see xorwow_host.cpp

@@ -43,7 +43,6 @@ __device__ __forceinline__ PmProblem pm_problem(const PmBatch& B, unsigned q)
     p.nnf = pair_ptr_opt(p.nnf, B.stride, pair);
     p.nnf_alt = pair_ptr_opt(p.nnf_alt, B.stride, pair);
     p.spec = pair_ptr_opt(p.spec, B.stride, pair);
-    p.tq = pair_ptr_opt(p.tq, B.stride, pair);
     p.rng_work = pair_ptr_opt(p.rng_work, B.stride, pair);
     p.rng_work_next = pair_ptr_opt(p.rng_work_next, B.stride, pair);
     return p;
@@ -162,64 +161,6 @@ __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L
         }
     }
     return cost_sum / weight_sum;
-}
-
-// The same evaluation with the target samples from the packed parity planes (eppm_internal.h: PackedGeom): the S samples of a
-// patch row are S consecutive 4-byte words of one plane -- 16-, 16- and 8-byte fetches for S = 10 where the float4 plane needs ten
-// 16-byte ones -- and no coordinate is clamped (the planes carry replicated borders).  Requires 0 <= x2 <= w, 0 <= y2 <= h.
-struct __attribute__((packed, aligned(4))) Words4 { uint32_t a, b, c, d; };
-struct __attribute__((packed, aligned(4))) Words2 { uint32_t a, b; };
-
-template <int RT, class LUT>
-__device__ __forceinline__ float search_patch_dist_packed(const LUT& L, const float4* __restrict__ s_src, int TW, int tx, int ty,
-                                                          const uint32_t* __restrict__ tq, const PackedGeom& g, int x2, int y2)
-{
-    constexpr int S = RT + 1;
-    static_assert(S % 4 == 2, "row = whole 16-byte fetches + one 8-byte fetch");
-    const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
-    const int xc = x2 + g.padx;
-    const rgbf c2 = texel_rgb(unpack_texel(tq[(unsigned)((xc & 1) * (int)g.plane_words + (y2 + g.pady) * g.nk + (xc >> 1))]));
-    const int xs0 = x2 - RT + g.padx;
-    // byte offset of sample (row 0, column 0); rows 2 apart
-    unsigned off = (unsigned)((xs0 & 1) * (int)g.plane_words + (y2 - RT + g.pady) * g.nk + (xs0 >> 1)) * 4u;
-    const unsigned rstep = (unsigned)g.nk * 8u;
-    const char* __restrict__ base = reinterpret_cast<const char*>(tq);
-    float cost_sum = 0.0f, weight_sum = 0.0f;
-#pragma unroll 2
-    for (int ii = 0; ii < S; ii++, off += rstep) {
-        uint32_t wd[S];
-#pragma unroll
-        for (int j0 = 0; j0 + 4 <= S; j0 += 4) {
-            const Words4 q = *reinterpret_cast<const Words4*>(base + off + j0 * 4);
-            wd[j0] = q.a; wd[j0 + 1] = q.b; wd[j0 + 2] = q.c; wd[j0 + 3] = q.d;
-        }
-        {
-            const Words2 q = *reinterpret_cast<const Words2*>(base + off + (S - 2) * 4);
-            wd[S - 2] = q.a; wd[S - 1] = q.b;
-        }
-        const float4* __restrict__ srow = s_src + (ty + 2 * ii) * TW + tx;
-#pragma unroll
-        for (int jj = 0; jj < S; jj++) {
-            float ct, wt;
-            patch_terms(srow[2 * jj], unpack_texel(wd[jj]), c1, c2, L.gsp[ii * S + jj], L.cnx, ct, wt);
-            cost_sum += ct;
-            weight_sum += wt;
-        }
-    }
-    return cost_sum / weight_sum;
-}
-
-// target samples from the packed planes when the problem has them and the candidate lies where they reach, else gathered
-template <int RT, class LUT>
-__device__ __forceinline__ float eval_patch(const Planes& P, const LUT& L, int R, const float4* __restrict__ s_src, int TW, int tx, int ty,
-                                            int x1, int y1, int x2, int y2, const uint32_t* __restrict__ tq, const PackedGeom& g)
-{
-#ifndef EPPM_PACKED_TARGET
-#define EPPM_PACKED_TARGET 1
-#endif
-    if (EPPM_PACKED_TARGET && RT != 0 && tq != nullptr && (unsigned)x2 <= (unsigned)P.w && (unsigned)y2 <= (unsigned)P.h)
-        return search_patch_dist_packed<(RT == 0 ? 9 : RT)>(L, s_src, TW, tx, ty, tq, g, x2, y2);
-    return search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, x1, y1, x2, y2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -353,6 +294,7 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
         s_own[threadIdx.x] = own; s_cst[threadIdx.x] = cst; s_spc[threadIdx.x] = spc;
     }
     bool from_nin = true;                  // SPEC: the chain carries a stored match (seed, or the own match of a pixel that rejected)
+    float cost_L = 0.0f;                   // SPEC: see the barrier after step 0
     __syncthreads();   // LUT ready
     const int t0 = r * CH;
     const int pitch16 = P.pitch << 4, wmax16 = (P.w - 1) << 4;
@@ -376,7 +318,7 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             if (SPEC) {
                 const int sl = grp * LPC + s, e = s_own[sl];
                 ox = (int)(int16_t)(e & 0xffff); oy = e >> 16;
-                cur_best = second_visit ? cost[cidx] : s_cst[sl];     // segment 1 may have lowered pixel L's cost at its first step
+                cur_best = second_visit ? cost_L : s_cst[sl];         // segment 1 may have lowered pixel L's cost at its first step
             } else {
                 cur_best = cost[cidx];
                 ox = nin[nidx * 2]; oy = nin[nidx * 2 + 1];           // the pixel's own match, needed on rejection: fetched with the rest
@@ -451,7 +393,12 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             }
             i += step;
         }
-        if (!REVERSE && s == 0) __syncthreads();   // (b)
+        if (!REVERSE && s == 0) {
+            __syncthreads();   // (b)
+            // SPEC: pixel L's cost as segment 1's first step left it, for segment 0's last step (fetched here, by value: a select
+            // between this global address and the LDS copy at the point of use would turn both loads into flat_load)
+            if (SPEC && active && seg == 0 && nseg > 1 && L_ < len) cost_L = cost[IS_ROW ? line * B.cpitch + L_ : L_ * B.cpitch + line];
+        }
     }
 }
 
@@ -522,7 +469,7 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
     const int pix = (int)s_list[tid], e = s_cand[tid];
     const int tx = pix & 15, ty = pix >> 4;
     const int px = bxx * kBlock + tx, py = byy * kBlock + ty;
-    pr.spec[py * B.cpitch + px] = eval_patch<RT>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16, pr.tq, B.tg);
+    pr.spec[py * B.cpitch + px] = search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16);
 }
 
 // Fallback for patch radii without a cooperative instantiation: the reference's one-thread-per-chain form,
@@ -867,7 +814,7 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     if (inimg) {
         float cv = INFINITY;
         if (evaluate) {
-            cv = eval_patch<RT>(P, L, R, s_src, TW, lane & 15, lane >> 4, x, y, gx, gy, pr.tq, B.tg);
+            cv = search_patch_dist<RT>(P, L, R, s_src, TW, lane & 15, lane >> 4, x, y, gx, gy);
         }
         s_cost[k][lane] = cv;
     }

@@ -281,27 +281,6 @@ void launch_pack(void* texels, int tpitch, const uint32_t* img, int ipitch, cons
     hipLaunchKernelGGL(k_pack, grid, block, 0, s, (float4*)texels, tpitch, img, ipitch, census, cpitch, w, h);
 }
 
-// packed parity planes (eppm_internal.h: PackedGeom): word (parity p, row r, k) = {R, G, B, census} of image pixel
-// (clamp(2k + p - padx), clamp(r - pady)): the clamp addressing of the texture model is applied once, here
-__global__ __launch_bounds__(256) void k_pack_parity(uint32_t* __restrict__ out_, const uint32_t* __restrict__ img_, int ipitch,
-                                                     const uint8_t* __restrict__ census_, int cpitch, int w, int h, PackedGeom g, size_t pstride)
-{
-    uint32_t* __restrict__ out = pair_ptr(out_, pstride, blockIdx.z);
-    const uint32_t* __restrict__ img = pair_ptr(img_, pstride, blockIdx.z);
-    const uint8_t* __restrict__ census = pair_ptr(census_, pstride, blockIdx.z);
-    const int k = blockIdx.x * blockDim.x + threadIdx.x, rp = blockIdx.y * blockDim.y + threadIdx.y;     // rp: row of the two stacked planes
-    if (k >= g.nk || rp >= 2 * g.rows) return;
-    const int par = rp / g.rows, r = rp - par * g.rows;
-    const int x = iclamp(2 * k + par - g.padx, 0, w - 1), y = iclamp(r - g.pady, 0, h - 1);
-    out[(size_t)par * g.plane_words + (size_t)r * g.nk + k] = (img[y * ipitch + x] & 0xffffffu) | ((uint32_t)census[y * cpitch + x] << 24);
-}
-void launch_pack_parity(uint32_t* out, const uint32_t* img, int ipitch_px, const uint8_t* census, int cpitch, int w, int h, int R, hipStream_t s, Batch bt)
-{
-    const PackedGeom g = packed_geom(w, h, R);
-    dim3 block(64, 4), grid((g.nk + 63) / 64, (2 * g.rows + 3) / 4, bt.n);
-    hipLaunchKernelGGL(k_pack_parity, grid, block, 0, s, out, img, ipitch_px, census, cpitch, w, h, g, bt.stride);
-}
-
 // RGB (3 B/px, tightly packed rows) -> RGBA with alpha 0 (bao_rgb2rgba, basic/bao_basic_cuda.h:258-267)
 __global__ __launch_bounds__(256) void k_rgb_to_rgba(uint32_t* __restrict__ out_, int pitch, const uint8_t* __restrict__ rgb_, int h, int w, size_t pstride)
 {
@@ -330,8 +309,7 @@ __global__ void k_probe(const float* __restrict__ x, float* __restrict__ y, int 
     if (which == 0) r = fast_exp(v);
     else if (which == 1) r = div_ad2(v);
     else if (which == 2) r = div_wmf2(v);
-    else if (which == 3) r = unorm8(v);
-    else r = unorm8_fast(v);
+    else r = unorm8(v);
     y[i] = r;
 }
 void launch_probe(const float* x, float* y, int n, int which, hipStream_t s)

@@ -271,15 +271,15 @@ int  eppm_resize_rgba(eppm_uchar4* d_out, size_t out_pitch, int outH, int outW, 
 int  eppm_resize_flow(eppm_float2* d_out, int outH, int outW, const eppm_float2* d_in, int h, int w, float ratio);
 /* test support: process-wide switches with which the parity tests steer launches onto a specific kernel variant (a host program
  * never needs them).  "c2f_no_split" = 1: the candidate refine is never split over several workgroups per tile, so that small
- * images run the LDS-window kernels too.  "sweep_spec": -1 (default) the sweeps of PatchMatch iteration >= 3 run in the
- * speculative two-launch form, 0 never, 1 always (also in eppm_pm_seg_propagate, which otherwise runs the classic form). */
+ * images run the LDS-window kernels too.  "sweep_spec": -1 (default) the sweeps of PatchMatch iterations >= 2 (the third on) run in the
+ * speculative two-launch form when a launch covers at least 100 000 pixels (two 1024x436 pairs, one 1920x1080 pair), 0 never, 1 always (also in eppm_pm_seg_propagate, which otherwise runs the classic form). */
 int  eppm_test_set_option(const char* name, int value);
 /* admissible spread (max - min, pixels) of a 16x16 tile's candidate centres for which the LDS-window refine kernels stage the
  * target window; wider tiles take the per-access path inside the same launch (patch_r 9 or 17) */
 int  eppm_probe_c2f_window(int patch_r, int* span_x, int* span_y);
 /* device-side arithmetic probes (parity of the shared float formulas): y[i] = f(x[i]) for n host floats */
 int  eppm_probe_fast_exp(const float* x, float* y, int n);
-int  eppm_probe_div_const(const float* x, float* y, int n, int which); /* 0: /(.1f*.1f) 1: /(.02f*.02f) 2: unorm8 (x = 0..255) 3: unorm8, the two-operation form of the packed planes */
+int  eppm_probe_div_const(const float* x, float* y, int n, int which); /* 0: /(.1f*.1f) 1: /(.02f*.02f) 2: unorm8 (x = 0..255) */
 
 /* ----------------------------------------------------------------------------------------
  * file formats used by the reference's CLI (main.cpp:56-69)

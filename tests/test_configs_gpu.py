@@ -526,8 +526,9 @@ def test_reference_main_cpp_unmodified_writes_the_same_flo(tmp_path):
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
 def test_bench_two_ranks_share_one_gpu(backend):
-    """backend nccl: RCCL refuses two ranks on one device, at the first collective -- the probe all-reduce after
-    init_process_group must catch that and every rank must fall back to gloo (the data path has no collective)."""
+    """backend nccl: RCCL refuses two ranks on one device, at the first collective -- the probe all-reduce on the RCCL group
+    must catch that, the ranks must AGREE on it over the gloo group that always exists, and the barrier and the MAX then go over
+    gloo on every rank (the data path has no collective)."""
     env = dict(os.environ, EPPM_BENCH_SHARE_GPU="1")
     env.pop("RANK", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--dist-backend", backend,
@@ -538,23 +539,26 @@ def test_bench_two_ranks_share_one_gpu(backend):
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["roofline"]["frac"] > 0 and d["roofline"]["avg_launch_ms"] > 0
-    assert ("falling back to gloo" in out.stderr) == (backend == "nccl")
+    assert ("barrier and MAX go over gloo" in out.stderr) == (backend == "nccl")
 
 
 # ---------------------------------------------------------------------------------------------------
 # opt-in approx-exp library (libeppm_hip_approx.so: v_exp_f32 instead of the shared exp formula)
 # ---------------------------------------------------------------------------------------------------
 def test_approx_exp_variant_within_tolerance():
-    """NOT bit-identical by design; BASELINE.json's tolerance for the flow on the bundled pair is 1e-3 px EPE (mean end-point
-    error against the oracle's flow): the variant must stay inside it, and must say what it is."""
-    env = dict(os.environ, EPPM_HIP_VARIANT="approx")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "approx_exp_epe.py")], env=env, capture_output=True, text=True, timeout=600)
+    """The opt-in libeppm_hip_approx.so is NOT bit-identical by design.  north_star's tolerance is 1e-3 px mean EPE on the bundled
+    Middlebury pair: the variant must stay inside it there, forwards and backwards.  On the synthetic shapes of BASELINE
+    configs[1], [3] and on the small fuzz images it does NOT (1e-2 .. 4e-2 px: a 1-ulp difference in a cost flips a strict `<`
+    between near-equal candidates and the flipped match propagates) -- recorded here with a regression bound of 5e-2 px and
+    reported per case by bench.py (approx_exp_variant.epe_by_case); which is why the variant is never `value` and why nothing
+    further was built inside "the tolerance".  For scale: another ORDER of the reference's own races moves the flow by
+    0.07 - 0.9 px on the same shape (tools/parity_envelope.py).  Measured against the exact library, which the other tests pin
+    to the oracle bit for bit."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "approx_exp_epe.py")], capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert "approx-exp" in d["library"], d
-    assert 0 < d["epe_mean_px"] <= 1e-3, d          # > 0: the variant really is a different arithmetic
-    env = dict(os.environ)
-    env.pop("EPPM_HIP_VARIANT", None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "approx_exp_epe.py")], env=env, capture_output=True, text=True, timeout=600)
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert "approx" not in d["library"] and d["epe_mean_px"] == 0.0 and d["pixels_differing"] == 0.0, d
+    assert "approx-exp" in d["library"] and "approx" not in d["against"].split("(")[0], d
+    for name, c in d["cases"].items():
+        limit = 1e-3 if name.startswith("bundled") else 5e-2
+        assert c["epe_mean_px"] <= limit, (name, c)
+    assert d["cases"]["bundled_640x480"]["epe_mean_px"] > 0          # the variant really is a different arithmetic

@@ -48,7 +48,6 @@ def test_div_const_bits(S):
     eq(S.probe_div_const(x, 1), (x / (np.float32(0.02) * np.float32(0.02))).astype(np.float32), "x/(.02f*.02f)")
     c = np.arange(256, dtype=np.float32)
     eq(S.probe_div_const(c, 2), (c / np.float32(255)).astype(np.float32), "unorm8")
-    eq(S.probe_div_const(c, 3), (c / np.float32(255)).astype(np.float32), "unorm8, two-operation form (texels of the packed parity planes)")
 
 
 def test_prepare_stages(S, O, crop):
@@ -117,10 +116,9 @@ def test_patchmatch_substages(S, O, L1):
 
 
 def test_patchmatch_evaluation_kernels_with_arbitrary_nnf(S, O, L1):
-    """The one-evaluation-per-lane kernels (random search, phase A of the speculative sweeps) read their target samples from the
-    packed parity planes when the candidate lies in [0, w] x [0, h] and gather from the float4 plane otherwise.  An NNF as a
-    caller of the stage launchers may hand over -- targets on the last row / column, one past them (the reference's inclusive
-    random range), and far outside the image -- takes every lane through one path or the other inside the same waves."""
+    """An NNF as a caller of the stage launchers may hand over -- targets on the last row / column, one past them (the
+    reference's inclusive random range), and far outside the image: the cost field and the speculative sweeps (phase A's
+    one-evaluation-per-lane kernel, phase B's walk) clamp every sample as the texture model does."""
     import eppm_amd
     i1, i2, c1, c2 = L1
     h, w = i1.shape

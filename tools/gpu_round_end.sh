@@ -1,6 +1,6 @@
 # Everything profiles/ of a round comes from, in one call (TAG=r03_x ...; PMC_ONLY=1: only the counter passes; SKIP_TESTS=1):
 #   GPU tests; the default bench line; rocprofv3 kernel stats of the same command and of a one-context run; PMC passes (SQ,
-#   SQ2, FETCH_SIZE, WRITE_SIZE in separate runs) for three shapes: 1024x436 at one and at four pairs per launch, 1920x1080 and
+#   SQ2, FETCH_SIZE, WRITE_SIZE in separate runs) for three shapes: 1024x436 at one and at eight pairs per launch, 1920x1080 and
 #   3840x2160 at patch radius 17 (BASELINE configs[3], [4]); bench lines for those shapes.
 set -x
 R=$GRAFT_REPO_ROOT
@@ -25,7 +25,7 @@ COMMON="--repeats 1 --no-cpu-baseline --no-extras"
 if [ -z "$PMC_ONLY" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python3 $R/bench.py --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_single -- python3 $R/bench.py --steps 30 --warmup 3 --batch 1 --inflight 1 $COMMON > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_batch4 -- python3 $R/bench.py --steps 32 --warmup 4 --batch 4 --inflight 1 $COMMON > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_batch8 -- python3 $R/bench.py --steps 32 --warmup 8 --batch 8 --inflight 1 $COMMON > /dev/null 2>&1
 fi
 # label | bench arguments
 while IFS='|' read -r label bargs; do
@@ -34,10 +34,10 @@ while IFS='|' read -r label bargs; do
   rocprofv3 --kernel-trace --pmc $SQ GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_$label -- python3 $R/bench.py $bargs $COMMON > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$label -- python3 $R/bench.py $bargs $COMMON > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$label -- python3 $R/bench.py $bargs $COMMON > /dev/null 2>&1
-  case $label in single|batch4) rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $O/pmc_sq2_$label -- python3 $R/bench.py $bargs $COMMON > /dev/null 2>&1 ;; esac
+  case $label in single|batch8) rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $O/pmc_sq2_$label -- python3 $R/bench.py $bargs $COMMON > /dev/null 2>&1 ;; esac
 done <<LIST
 single|--steps 8 --warmup 4 --batch 1 --inflight 1
-batch4|--steps 8 --warmup 4 --batch 4 --inflight 1
+batch8|--steps 16 --warmup 8 --batch 8 --inflight 1
 hd|$HD --steps 4 --warmup 2
 uhd17|$UHD --steps 2 --warmup 1
 LIST

@@ -7,7 +7,7 @@ H2D; driver .cpp:159-168) + compute_flow (the path, D2H, de-interleave; :217-306
   sync_batch      eppm_batch_set_images + eppm_batch_compute, B pairs per call on one batch context, registered memory
   pipelined       ONE host thread keeps K batch contexts of B pairs in flight (eppm_batch_set_images,
                   eppm_batch_compute_begin_into / eppm_batch_compute_end), registered memory: the PCIe copies of one context
-                  overlap the kernels of the others.  Default K x B = 3 x 4, the issue scheme of bench.py's `value`.
+                  overlap the kernels of the others.  Default K x B = 3 x 8, the issue scheme of bench.py's `value`.
   pipelined_staged  the same on unregistered memory
   class           the C++ drop-in class (tools/runeppm --pairs: set_data + compute_flow on bao_alloc-shaped blocks), default
                   and with set_option("pin_caller_buffers", 1)
@@ -38,7 +38,7 @@ def main():
             skip |= {sys.argv.index(name), sys.argv.index(name) + 1}
     pos = [a for i, a in enumerate(sys.argv[1:], 1) if i not in skip and not a.startswith("--")]
     w, h = (int(pos[0]), int(pos[1])) if len(pos) >= 2 else (1024, 436)
-    B, K = opt("--batch", 4), opt("--inflight", 3)
+    B, K = opt("--batch", 8), opt("--inflight", 3)
     NP = 12
     plain = [synth.make_pair(h, w, seed=1234 + i)[:2] for i in range(NP)]
     pinned = []
@@ -120,7 +120,7 @@ def main():
     dt_sync, flow_reg = sync_single(pinned, True)
     dt_staged, flow_staged = sync_single(plain, False)
     assert np.array_equal(flow_reg[0], flow_staged[0]) and np.array_equal(flow_reg[1], flow_staged[1]), "registered and staged flows differ"
-    dt_sb = sync_batch(pinned, 2 * B)
+    dt_sb = sync_batch(pinned, B)
     dt_pipe = pipelined(pinned, True, B, K)
     dt_pipe_staged = pipelined(plain, False, B, K)
     dt_pipe1 = pipelined(pinned, True, 1, K)
@@ -129,7 +129,7 @@ def main():
     res = {"unit": "Mflow-vectors/s",
            "sync": rate(dt_sync), "sync_ms_per_pair": dt_sync * 1e3,
            "sync_staged": rate(dt_staged), "sync_staged_ms_per_pair": dt_staged * 1e3,
-           "sync_batch": rate(dt_sb), "sync_batch_ms_per_pair": dt_sb * 1e3, "sync_batch_pairs_per_call": 2 * B,
+           "sync_batch": rate(dt_sb), "sync_batch_ms_per_pair": dt_sb * 1e3, "sync_batch_pairs_per_call": B,
            "pipelined": rate(dt_pipe), "pipelined_ms_per_pair": dt_pipe * 1e3, "pairs_per_launch": B, "contexts_in_flight": K,
            "pipelined_staged": rate(dt_pipe_staged), "pipelined_single_pair_contexts": rate(dt_pipe1),
            "class_sync": cls, "class_sync_pinned": cls_pin,

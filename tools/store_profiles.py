@@ -12,7 +12,7 @@ for f in glob.glob(f"{dst}/{tag}_*"):
 for name in ("bench_default.json", "bench_streams3.json", "bench_hd.json", "bench_4k_r17.json", "bench_under_rocprof.json", "bench_torchrun_2ranks_1gpu.json", "gpu_tests.txt"):
     if os.path.exists(f"{src}/{name}") and os.path.getsize(f"{src}/{name}") > 0:
         shutil.copy(f"{src}/{name}", f"{dst}/{tag}_{name}")
-for d in ("stats_default", "stats_single", "stats_batch4"):
+for d in ("stats_default", "stats_single", "stats_batch8"):
     f = glob.glob(f"{src}/{d}/*/*kernel_stats.csv")
     if f:
         shutil.copy(f[0], f"{dst}/{tag}_{d}_kernel_stats.csv")
@@ -49,7 +49,7 @@ all_srcs = sorted(os.path.relpath(f, ROOT) for f in glob.glob(f"{ROOT}/eppm_amd/
 sha_all = hashlib.sha256(b"".join(open(os.path.join(ROOT, f), "rb").read() for f in all_srcs)).hexdigest()
 REF = ("k_c2f_refine", "k_c2f_select")
 shapes = {}
-for key, labels in (("1024x436_r9", (("single", 1), ("batch4", 4))), ("1920x1080_r9", (("hd", 1),)), ("3840x2160_r17", (("uhd17", 1),))):
+for key, labels in (("1024x436_r9", (("single", 1), ("batch8", 8))), ("1920x1080_r9", (("hd", 1),)), ("3840x2160_r17", (("uhd17", 1),))):
     if not all(f"pmc_sq_{lb}" in summ and f"pmc_fetch_{lb}" in summ and f"pmc_write_{lb}" in summ for lb, _ in labels):
         continue
     dominant = {}

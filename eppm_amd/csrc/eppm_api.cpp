@@ -277,7 +277,8 @@ struct eppm_ctx {
     void *pk1[kMaxLevels] = {}, *pk2[kMaxLevels] = {};       // float4 texel planes {r,g,b,census}, linear (pitch = w)
     int16_t *nnf1 = nullptr, *nnf2 = nullptr, *nnf_tmp = nullptr, *nnf_tmp2 = nullptr;
     float *cost1 = nullptr, *cost2 = nullptr;
-    float *spec1 = nullptr, *spec2 = nullptr;   // speculative sweeps: cost of every pixel's rejection-path candidate (phase A)
+    float *spec1 = nullptr, *spec2 = nullptr;   // evaluation cache of the sweeps (PmProblem::spec / scand): four direction planes each
+    int32_t *scand1 = nullptr, *scand2 = nullptr;
     uint32_t* wmf_ws = nullptr;        // work lists + counters of the weighted median
     bool flow_pending = false;         // eppm_compute_begin issued, eppm_compute_end not yet
     float *flow[kMaxLevels] = {}, *flow_tmp[kMaxLevels] = {};
@@ -412,8 +413,10 @@ static int ctx_alloc(eppm_ctx* c)
     plane((void**)&c->nnf_tmp2, n2 * 4);
     plane((void**)&c->cost1, n2 * 4);
     plane((void**)&c->cost2, n2 * 4);
-    plane((void**)&c->spec1, n2 * 4);
-    plane((void**)&c->spec2, n2 * 4);
+    plane((void**)&c->spec1, n2 * 4 * 4);
+    plane((void**)&c->spec2, n2 * 4 * 4);
+    plane((void**)&c->scand1, n2 * 4 * 4);
+    plane((void**)&c->scand2, n2 * 4 * 4);
     plane((void**)&c->wmf_ws, wmf_workspace_words(c->W[L], c->H[L], c->prm.wmf_iters) * 4);
     plane((void**)&c->d_rgb, (size_t)h * w * 3 * 2);
     plane((void**)&c->d_color, (size_t)h * w * 4);
@@ -646,10 +649,11 @@ extern "C" int eppm_batch_set_images_device(eppm_ctx* c, int n, const void* cons
 }
 
 // ---- baoCudaPatchMatch (kernel.cu:1760-1826) for one problem or for the forward+backward pair at once ----
-static PmProblem mk_problem(const PlanesH& P, float* cost, int16_t* nnf, int16_t* nnf_alt, eppm_pm_rng* rng, int k, float* spec = nullptr)
+static PmProblem mk_problem(const PlanesH& P, float* cost, int16_t* nnf, int16_t* nnf_alt, eppm_pm_rng* rng, int k, float* spec = nullptr,
+                            int32_t* scand = nullptr)
 {
     PmProblem p;
-    p.P = P; p.cost = cost; p.nnf = nnf; p.nnf_alt = nnf_alt; p.spec = spec;
+    p.P = P; p.cost = cost; p.nnf = nnf; p.nnf_alt = nnf_alt; p.spec = spec; p.scand = scand;
     p.rng_work = rng ? rng->work[k][rng->cur[k]] : nullptr;
     p.rng_work_next = rng ? rng->work[k][rng->cur[k] ^ 1] : nullptr;
     return p;
@@ -732,8 +736,12 @@ static int compute_all(eppm_ctx* c)
     {
         PmBatch b;
         b.n = 2; b.cpitch = lw; b.npitch = lw; b.npairs = bt.n; b.stride = bt.stride;
-        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0, c->spec1);     // driver :223
-        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1, c->spec2);     // driver :224
+        b.cache_plane = (size_t)lw * lh;
+#ifndef EPPM_SWEEP_CACHE
+#define EPPM_SWEEP_CACHE 1
+#endif
+        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0, c->spec1, EPPM_SWEEP_CACHE ? c->scand1 : nullptr);     // driver :223
+        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1, c->spec2, EPPM_SWEEP_CACHE ? c->scand2 : nullptr);     // driver :224
         run_patchmatch(b, c->rng, c->lut_pm, c->prm, s);
     }
     stage_end(c, c->ev);
@@ -1122,8 +1130,12 @@ extern "C" int eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const ep
     CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
     void* spec = nullptr;
     const bool speculative = g_sweep_spec.load() == 1;         // the stand-alone entry point has no iteration count: classic unless forced
-    if (speculative) CHK(get_scratch(ds, cost_pitch * h, &spec, 4));
-    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0, (float*)spec);
+    // the evaluation cache of the sweeps lives for ONE call here (the planes of the next call may be other images): emptied first
+    const size_t plane_bytes = cost_pitch * h;
+    CHK(get_scratch(ds, plane_bytes * 8, &spec, 4));
+    HIPCHK(hipMemsetAsync((char*)spec + plane_bytes * 4, 0xff, plane_bytes * 4, g_stream));
+    b.cache_plane = plane_bytes / 4;
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0, (float*)spec, (int32_t*)((char*)spec + plane_bytes * 4));
     for (int d = 0; d < 4; d++)
         if (dir < 0 || dir == d) sweep(b, ds->lut_pm, g_prm, d, g_stream, speculative);
     if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
@@ -1290,9 +1302,11 @@ extern "C" void baoCudaPatchMatch(eppm_short2* d_disp_vec, float* d_cost, eppm_u
     g_launch_status = mk_planes(ds, &P, d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch);
     if (g_launch_status != EPPM_OK) return;
     void* spec = nullptr;
-    g_launch_status = get_scratch(ds, cost_pitch * h, &spec, 4);
+    const size_t plane_bytes = cost_pitch * h;
+    g_launch_status = get_scratch(ds, plane_bytes * 8, &spec, 4);
     if (g_launch_status != EPPM_OK) return;
-    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0, (float*)spec);
+    b.cache_plane = plane_bytes / 4;          // (k_pm_init_field empties the cache)
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0, (float*)spec, (int32_t*)((char*)spec + plane_bytes * 4));
     run_patchmatch(b, r, ds->lut_pm, g_prm, g_stream);
     if (b.p[0].nnf != (int16_t*)d_disp_vec && (g_launch_status = copy_d2d(d_disp_vec, b.p[0].nnf, disp_pitch * h)) != EPPM_OK) return;
     g_launch_status = finish();

@@ -61,7 +61,13 @@ struct PmProblem {
     float* cost;
     int16_t* nnf;        // short2, current
     int16_t* nnf_alt;    // short2, ping-pong partner for the sweeps
-    float* spec = nullptr;   // speculative sweeps: phase A's cost of every pixel's rejection-path candidate (cost pitch), or NULL
+    // Evaluation cache of the sweeps, one (candidate, cost) entry per pixel and sweep direction: four planes each (cost pitch),
+    // direction d at element offset d * PmBatch::cache_plane.  The patch cost is a pure function of (pixel, candidate) while the
+    // images stand, so a sweep that meets the candidate it evaluated for this pixel last time -- the neighbour's match did not
+    // change between two iterations, the normal case once the field has converged -- takes the cost from here.  spec doubles as
+    // phase A's hand-over plane to phase B (k_patchmatch.hip).  scand == NULL: no cache (every candidate is evaluated).
+    float* spec = nullptr;
+    int32_t* scand = nullptr;   // x | y << 16 of the cached candidate; -1 = empty (no candidate has both coordinates -1)
     uint32_t* rng_work;       // [nblocks][64][6] XORWOW lane states read by the random search
     uint32_t* rng_work_next;  // ... written by it (ping-pong: four workgroups read each block's state, one advances it)
 };
@@ -71,6 +77,7 @@ struct PmBatch {
     int cpitch, npitch;  // elements
     int npairs = 1;      // a launch covers n * npairs problems
     size_t stride = 0;
+    size_t cache_plane = 0;   // elements per direction plane of PmProblem::spec / scand
 };
 // RNG tables shared by both problems (same seed, same block ids: the reference re-initialises the states on
 // every baoCudaPatchMatch call, kernel.cu:160); see xorwow_host.cpp

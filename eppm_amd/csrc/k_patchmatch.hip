@@ -43,6 +43,7 @@ __device__ __forceinline__ PmProblem pm_problem(const PmBatch& B, unsigned q)
     p.nnf = pair_ptr_opt(p.nnf, B.stride, pair);
     p.nnf_alt = pair_ptr_opt(p.nnf_alt, B.stride, pair);
     p.spec = pair_ptr_opt(p.spec, B.stride, pair);
+    p.scand = pair_ptr_opt(p.scand, B.stride, pair);
     p.rng_work = pair_ptr_opt(p.rng_work, B.stride, pair);
     p.rng_work_next = pair_ptr_opt(p.rng_work_next, B.stride, pair);
     return p;
@@ -83,6 +84,10 @@ __global__ __launch_bounds__(64) void k_pm_init_field(PmBatch B, PmRngDev rng)
         if (x < w && y < h) {
             pr.nnf[(y * B.npitch + x) * 2 + 0] = (int16_t)(r1 % (uint32_t)(w + 1));
             pr.nnf[(y * B.npitch + x) * 2 + 1] = (int16_t)(r2 % (uint32_t)(h + 1));
+            if (pr.scand) {                      // new images: the sweeps' evaluation cache starts empty
+#pragma unroll
+                for (int d = 0; d < 4; d++) pr.scand[d * B.cache_plane + y * B.cpitch + x] = -1;
+            }
         }
     }
     // search stream position = 512 draws in (states are re-initialised on every call, kernel.cu:160)
@@ -185,6 +190,7 @@ __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L
 template <int LPC>
 __device__ __forceinline__ float dpp_prev_lane(float v)
 {
+    if (LPC == 4) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x93 /* quad_perm:[3,0,1,2] */, 0xf, 0xf, false));
     if (LPC == 16) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
@@ -204,7 +210,8 @@ template <int LPC> struct SweepTile { static constexpr int CPB = 256 / LPC, SEGS
 
 // SPEC: phase B of the speculative form (see k_pm_sweep_spec below): a step that follows a rejection takes its cost from
 // pr.spec; the stored match, cost and speculative cost of a chain's pixels are fetched once, before the first step, and
-// handed to the steps through LDS (they are the only memory a cheap step needs).  Requires L_ <= LPC.
+// handed to the steps through LDS (they are the only memory a cheap step needs).  Requires L_ <= kSpecMaxSteps.
+constexpr int kSpecMaxSteps = 16;
 template <int R, int LPC, bool IS_ROW, bool REVERSE, bool TILE, bool SPEC = false>
 __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, const float* __restrict__ lut, int L_, int nseg, int nseg_pad, int TW)
 {
@@ -213,9 +220,9 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
     static_assert(!(SPEC && TILE), "phase B evaluates rarely: it gathers its source samples");
     extern __shared__ float4 s_tile[];          // TILE: TROWS sample rows + LINES centre rows of TW texels
     __shared__ PatchLut L;
-    __shared__ int s_own[SPEC ? 256 : 1];       // SPEC: per chain and step, the pixel's stored match (x | y << 16),
-    __shared__ float s_cst[SPEC ? 256 : 1];     //       its stored cost
-    __shared__ float s_spc[SPEC ? 256 : 1];     //       and phase A's cost of the rejection-path candidate
+    __shared__ int s_own[SPEC ? CPB * kSpecMaxSteps : 1];       // SPEC: per chain and step, the pixel's stored match (x | y << 16),
+    __shared__ float s_cst[SPEC ? CPB * kSpecMaxSteps : 1];     //       its stored cost
+    __shared__ float s_spc[SPEC ? CPB * kSpecMaxSteps : 1];     //       and phase A's cost of the rejection-path candidate
     load_patch_lut(L, lut, R, threadIdx.x, 256);
     // 1-D grid, problem = id mod nprob: workgroups are dealt to the 8 XCDs by id mod 8, so with 8 problems (4 pairs x 2 directions)
     // each problem's planes stay in ONE XCD's L2 instead of all problems' planes competing for every L2
@@ -225,6 +232,10 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
     const int16_t* __restrict__ nin = pr.nnf;
     int16_t* __restrict__ nout = pr.nnf_alt;
     float* __restrict__ cost = pr.cost;
+    // this direction's planes of the evaluation cache (eppm_internal.h: PmProblem::spec / scand)
+    constexpr int DIR = IS_ROW ? (REVERSE ? 2 : 0) : (REVERSE ? 3 : 1);
+    float* __restrict__ cval = pr.spec ? pr.spec + DIR * B.cache_plane : nullptr;
+    int32_t* __restrict__ ccand = pr.scand ? pr.scand + DIR * B.cache_plane : nullptr;
     const int len = IS_ROW ? P.w : P.h, lines = IS_ROW ? P.h : P.w;
     const int grp = threadIdx.x / LPC, r = threadIdx.x % LPC;
     int line, seg, li = 0, line0 = 0, seg0 = 0;
@@ -281,27 +292,33 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
         }
     }
     if (SPEC) {
-        // lane r of a chain fetches what step r needs
-        int own = 0;
-        float cst = 0.0f, spc = 0.0f;
-        if (active && r < count) {
-            const int ir = i + r * step;
-            const int xr = IS_ROW ? ir : line, yr = IS_ROW ? line : ir;
-            own = (int)(uint16_t)nin[(yr * B.npitch + xr) * 2] | ((int)nin[(yr * B.npitch + xr) * 2 + 1] << 16);
-            cst = cost[yr * B.cpitch + xr];
-            spc = pr.spec[yr * B.cpitch + xr];
+        // the lanes of a chain fetch what its steps need: lane r the steps r, r + LPC, ...
+        for (int sr = r; sr < L_; sr += LPC) {
+            int own = 0;
+            float cst = 0.0f, spc = 0.0f;
+            if (active && sr < count) {
+                const int ir = i + sr * step;
+                const int xr = IS_ROW ? ir : line, yr = IS_ROW ? line : ir;
+                own = (int)(uint16_t)nin[(yr * B.npitch + xr) * 2] | ((int)nin[(yr * B.npitch + xr) * 2 + 1] << 16);
+                cst = cost[yr * B.cpitch + xr];
+                spc = cval[yr * B.cpitch + xr];
+            }
+            const int sl = grp * kSpecMaxSteps + sr;
+            s_own[sl] = own; s_cst[sl] = cst; s_spc[sl] = spc;
         }
-        s_own[threadIdx.x] = own; s_cst[threadIdx.x] = cst; s_spc[threadIdx.x] = spc;
     }
     bool from_nin = true;                  // SPEC: the chain carries a stored match (seed, or the own match of a pixel that rejected)
     float cost_L = 0.0f;                   // SPEC: see the barrier after step 0
     __syncthreads();   // LUT ready
     const int t0 = r * CH;
     const int pitch16 = P.pitch << 4, wmax16 = (P.w - 1) << 4;
-    int dj16[CH], di_[CH];                 // this lane's sample offsets (column in bytes): the same at every step
-    int lo_[CH];                           // TILE: tile index of the sample when the chain stands at along-line coordinate 0
+    // this lane's sample offsets (column in bytes), the same at every step: kept in registers by the classic form; phase B, which
+    // evaluates rarely and runs up to 25 samples per lane, recomputes them at use (registers are what limits its waves)
+    constexpr int NOFF = SPEC ? 1 : CH;
+    int dj16[NOFF], di_[NOFF];
+    int lo_[NOFF];                         // TILE: tile index of the sample when the chain stands at along-line coordinate 0
 #pragma unroll
-    for (int k = 0; k < CH; k++) {
+    for (int k = 0; k < NOFF; k++) {
         const int t = min(t0 + k, NS - 1);
         di_[k] = 2 * (t / S) - R;
         dj16[k] = (2 * (t % S) - R) * 16;
@@ -316,13 +333,16 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             float cur_best;
             int ox, oy;
             if (SPEC) {
-                const int sl = grp * LPC + s, e = s_own[sl];
+                const int sl = grp * kSpecMaxSteps + s, e = s_own[sl];
                 ox = (int)(int16_t)(e & 0xffff); oy = e >> 16;
                 cur_best = second_visit ? cost_L : s_cst[sl];         // segment 1 may have lowered pixel L's cost at its first step
             } else {
                 cur_best = cost[cidx];
                 ox = nin[nidx * 2]; oy = nin[nidx * 2 + 1];           // the pixel's own match, needed on rejection: fetched with the rest
             }
+            int hit_cand = -1;                                        // classic form: this pixel's cached evaluation, fetched with the rest
+            float hit_val = 0.0f;
+            if (!SPEC && ccand) { hit_cand = ccand[cidx]; hit_val = cval[cidx]; }
             if (IS_ROW) px = REVERSE ? max(px - 1, 0) : min(px + 1, P.w - 1);
             else        py = REVERSE ? max(py - 1, 0) : min(py + 1, P.h - 1);
             // A candidate equal to the pixel's current match would reproduce the stored cost bit for bit
@@ -331,7 +351,9 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             // neighbours sharing one offset -- make this the common case after the first iterations.
             float cv = cur_best;
             const bool differs = !(px == ox && py == oy);
-            if (SPEC && differs && from_nin) cv = s_spc[grp * LPC + s];           // phase A evaluated exactly this candidate
+            const int cpack = (px & 0xffff) | (py << 16);
+            if (SPEC && differs && from_nin) cv = s_spc[grp * kSpecMaxSteps + s];           // phase A evaluated exactly this candidate (now or earlier)
+            else if (!SPEC && differs && hit_cand == cpack) cv = hit_val;                   // evaluated in an earlier sweep of this direction
             else if (differs) {
             const rgbf c1 = texel_rgb(TILE ? s_tile[lc + i] : tex_px(P.pk1, P.pitch, P.w, P.h, x, y));
             const rgbf c2 = texel_rgb(tex_px(P.pk2, P.pitch, P.w, P.h, px, py));
@@ -347,9 +369,17 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
                 float4 q1[GB], q2[GB];
 #pragma unroll
                 for (int k = 0; k < GB; k++) {
-                    q1[k] = TILE ? s_tile[lo_[q0 + k] + i]
-                                 : texel_at(P.pk1, texel_off16(pitch16, wmax16, P.h - 1, (x << 4) + dj16[q0 + k], y + di_[q0 + k]));
-                    q2[k] = texel_at(P.pk2, texel_off16(pitch16, wmax16, P.h - 1, (px << 4) + dj16[q0 + k], py + di_[q0 + k]));
+                    const int qk = (q0 + k < CH) ? q0 + k : CH - 1;       // (the last batch may be partial: its spare slots repeat the last sample)
+                    int dj, di;
+                    if (SPEC) {
+                        int t0v = t0;
+                        asm volatile("" : "+v"(t0v));          // keeps the 25 offset pairs from being hoisted out of the step loop into registers
+                        const int t = min(t0v + qk, NS - 1);
+                        di = 2 * (t / S) - R; dj = (2 * (t % S) - R) * 16;
+                    } else { di = di_[qk]; dj = dj16[qk]; }
+                    q1[k] = TILE ? s_tile[lo_[SPEC ? 0 : qk] + i]
+                                 : texel_at(P.pk1, texel_off16(pitch16, wmax16, P.h - 1, (x << 4) + dj, y + di));
+                    q2[k] = texel_at(P.pk2, texel_off16(pitch16, wmax16, P.h - 1, (px << 4) + dj, py + di));
                 }
 #pragma unroll
                 for (int k = 0; k < GB; k++) {
@@ -375,6 +405,7 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             const int src = ((threadIdx.x & 63) / LPC) * LPC + (NL - 1);   // lane holding the complete sums (wave-relative)
             const float cs = __shfl(ac, src, 64), ws = __shfl(aw, src, 64);
             cv = cs / ws;
+            if (!SPEC && ccand && r == 0) { ccand[cidx] = cpack; cval[cidx] = cv; }
             }
             if (cv < cur_best) {
                 if (r == 0) {
@@ -422,6 +453,7 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
 {
     using LUT = typename SearchLut<RT>::type;
     constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT;
+    constexpr int DIR = IS_ROW ? (REVERSE ? 2 : 0) : (REVERSE ? 3 : 1);
     __shared__ float4 s_src[TW * TW];
     __shared__ LUT L;
     __shared__ uint32_t s_list[256];       // compacted work: pixel index inside the block
@@ -431,7 +463,31 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
     const int bxx = brest % gx, byy = brest / gx;
     const PmProblem pr = pm_problem(B, bq);
     const Planes P = to_dev(pr.P);
+    float* __restrict__ cval = pr.spec + DIR * B.cache_plane;
+    int32_t* __restrict__ ccand = pr.scand ? pr.scand + DIR * B.cache_plane : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x = bxx * kBlock + (tid & 15), y = byy * kBlock + (tid >> 4);
+    // the pixel the chain comes from: one step against the sweep direction; the first pixel of a line is never visited
+    const int qx = IS_ROW ? (REVERSE ? x + 1 : x - 1) : x, qy = IS_ROW ? y : (REVERSE ? y + 1 : y - 1);
+    bool need = false;
+    int cpack = 0;
+    if (x < P.w && y < P.h && qx >= 0 && qy >= 0 && qx < P.w && qy < P.h) {
+        const int qi = (qy * B.npitch + qx) * 2, ni = (y * B.npitch + x) * 2;
+        int cx = pr.nnf[qi], cy = pr.nnf[qi + 1];
+        if (IS_ROW) cx = REVERSE ? max(cx - 1, 0) : min(cx + 1, P.w - 1);
+        else        cy = REVERSE ? max(cy - 1, 0) : min(cy + 1, P.h - 1);
+        cpack = (cx & 0xffff) | (cy << 16);
+        need = !(cx == pr.nnf[ni] && cy == pr.nnf[ni + 1]);          // equal to the pixel's own match: rejected unevaluated
+        if (need && ccand && ccand[y * B.cpitch + x] == cpack) need = false;     // evaluated in an earlier sweep of this direction: the cost stands
+    }
+    // compaction: wave-level ballot + prefix, then the four wave counts: whole waves work or exit
+    const unsigned long long bal = __ballot(need);
+    if (lane == 0) s_wcount[wv] = __popcll(bal);
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int c = s_wcount[k]; if (k < wv) base += c; total += c; }
+    if (total == 0) return;                   // every candidate of the block is known (converged field): no tile, no table
     load_patch_lut(L, lut, R, tid, 256);
     if (RT != 0) {
         const int x0 = bxx * kBlock - RT, y0 = byy * kBlock - RT;
@@ -440,36 +496,18 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
             s_src[t] = P.pk1[(unsigned)(sy * P.pitch + sx)];
         }
     }
-    const int x = bxx * kBlock + (tid & 15), y = byy * kBlock + (tid >> 4);
-    // the pixel the chain comes from: one step against the sweep direction; the first pixel of a line is never visited
-    const int qx = IS_ROW ? (REVERSE ? x + 1 : x - 1) : x, qy = IS_ROW ? y : (REVERSE ? y + 1 : y - 1);
-    bool need = false;
-    int cx = 0, cy = 0;
-    if (x < P.w && y < P.h && qx >= 0 && qy >= 0 && qx < P.w && qy < P.h) {
-        const int qi = (qy * B.npitch + qx) * 2, ni = (y * B.npitch + x) * 2;
-        cx = pr.nnf[qi]; cy = pr.nnf[qi + 1];
-        if (IS_ROW) cx = REVERSE ? max(cx - 1, 0) : min(cx + 1, P.w - 1);
-        else        cy = REVERSE ? max(cy - 1, 0) : min(cy + 1, P.h - 1);
-        need = !(cx == pr.nnf[ni] && cy == pr.nnf[ni + 1]);          // equal to the pixel's own match: rejected unevaluated
-    }
-    // compaction: wave-level ballot + prefix, then the four wave counts: whole waves work or exit
-    const unsigned long long bal = __ballot(need);
-    if (lane == 0) s_wcount[wv] = __popcll(bal);
-    __syncthreads();                          // LUT, tile, wave counts
-    int base = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const int c = s_wcount[k]; if (k < wv) base += c; total += c; }
     if (need) {
         const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
         s_list[slot] = (uint32_t)tid;
-        s_cand[slot] = (cx & 0xffff) | (cy << 16);
+        s_cand[slot] = cpack;
     }
-    __syncthreads();
+    __syncthreads();                          // LUT, tile, list
     if (tid >= total) return;
     const int pix = (int)s_list[tid], e = s_cand[tid];
     const int tx = pix & 15, ty = pix >> 4;
     const int px = bxx * kBlock + tx, py = byy * kBlock + ty;
-    pr.spec[py * B.cpitch + px] = search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16);
+    cval[py * B.cpitch + px] = search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16);
+    if (ccand) ccand[py * B.cpitch + px] = e;
 }
 
 // Fallback for patch radii without a cooperative instantiation: the reference's one-thread-per-chain form,
@@ -595,9 +633,15 @@ bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int
     const bool is_row = (dir == 0 || dir == 2);
     const int len = is_row ? P.w : P.h, lines = is_row ? P.h : P.w;
     const int nseg = (len + seg_len - 1) / seg_len;
-    if (speculative && b.p[0].spec && (R == 9 || R == 17) && seg_len <= ((R == 9) ? EPPM_LPC9 : EPPM_LPC17)) {
-        if (R == 9) { launch_sweep_spec<9>(b, lut, R, dir, s); launch_sweep_b<9, EPPM_LPC9>(b, lut, seg_len, dir, nseg, lines, s); }
-        else { launch_sweep_spec<17>(b, lut, R, dir, s); launch_sweep_b<17, EPPM_LPC17>(b, lut, seg_len, dir, nseg, lines, s); }
+#ifndef EPPM_LPC9_SPEC
+#define EPPM_LPC9_SPEC 16     // lanes per chain in phase B at radius 9 (4 were tried -- a quarter of the waves, one round of workgroups --
+#endif                        // and lost: 50-56 vs 32-41 us per 8-pair launch, the evaluations after accepted candidates take four times as long)
+#ifndef EPPM_LPC17_SPEC
+#define EPPM_LPC17_SPEC 64    // ... at radius 17
+#endif
+    if (speculative && b.p[0].spec && (R == 9 || R == 17) && seg_len <= kSpecMaxSteps) {
+        if (R == 9) { launch_sweep_spec<9>(b, lut, R, dir, s); launch_sweep_b<9, EPPM_LPC9_SPEC>(b, lut, seg_len, dir, nseg, lines, s); }
+        else { launch_sweep_spec<17>(b, lut, R, dir, s); launch_sweep_b<17, EPPM_LPC17_SPEC>(b, lut, seg_len, dir, nseg, lines, s); }
         return true;
     }
     if (R == 9) {

@@ -10,23 +10,12 @@ HD="--width 1920 --height 1080 --batch 1 --inflight 1"
 UHD="--width 3840 --height 2160 --patch-r 17 --batch 1 --inflight 1"
 if [ -z "$PMC_ONLY" ]; then
 [ -n "$SKIP_TESTS" ] || timeout 2700 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 | tee gpurun_out/$T/gpu_tests.txt
-python bench.py --verify-config3 > gpurun_out/$T/bench_default.json 2> gpurun_out/$T/bench_default.err; cut -c1-220 gpurun_out/$T/bench_default.json
-python bench.py --batch 1 --inflight 3 --no-cpu-baseline --no-extras > gpurun_out/$T/bench_streams3.json 2>/dev/null
-python bench.py $HD --inflight 3 --steps 24 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/$T/bench_hd.json 2>/dev/null
-python bench.py $UHD --steps 4 --warmup 1 --repeats 3 --no-cpu-baseline --no-extras > gpurun_out/$T/bench_4k_r17.json 2>/dev/null
-# the driver's N > 1 launch form, two ranks sharing this box's one GPU (RCCL refuses two ranks per device: the ranks agree on gloo)
-EPPM_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 16 --warmup 4 --verify-config3 --no-cpu-baseline > gpurun_out/$T/bench_torchrun_2ranks_1gpu.json 2> gpurun_out/$T/bench_torchrun.err; cut -c1-160 gpurun_out/$T/bench_torchrun_2ranks_1gpu.json
 fi
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/$T
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_VMEM"
 SQ2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE"
 COMMON="--repeats 1 --no-cpu-baseline --no-extras"
-if [ -z "$PMC_ONLY" ]; then
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python3 $R/bench.py --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_single -- python3 $R/bench.py --steps 30 --warmup 3 --batch 1 --inflight 1 $COMMON > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_batch8 -- python3 $R/bench.py --steps 32 --warmup 8 --batch 8 --inflight 1 $COMMON > /dev/null 2>&1
-fi
 # label | bench arguments
 while IFS='|' read -r label bargs; do
   [ -z "$label" ] && continue
@@ -41,4 +30,20 @@ batch8|--steps 16 --warmup 8 --batch 8 --inflight 1
 hd|$HD --steps 4 --warmup 2
 uhd17|$UHD --steps 2 --warmup 1
 LIST
+# the constants the bench lines below report (valid for exactly these device sources), derived on the box from the passes above
+cd $R && python tools/store_profiles.py $T > gpurun_out/$T/pmc_constants_summary.json 2> gpurun_out/$T/store_profiles.err
+if [ -z "$PMC_ONLY" ]; then
+python bench.py --verify-config3 > gpurun_out/$T/bench_default.json 2> gpurun_out/$T/bench_default.err; cut -c1-220 gpurun_out/$T/bench_default.json
+python bench.py --batch 1 --inflight 3 --no-cpu-baseline --no-extras > gpurun_out/$T/bench_streams3.json 2>/dev/null
+python bench.py $HD --inflight 3 --steps 24 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/$T/bench_hd.json 2>/dev/null
+python bench.py $UHD --steps 4 --warmup 1 --repeats 3 --no-cpu-baseline --no-extras > gpurun_out/$T/bench_4k_r17.json 2>/dev/null
+# the driver's N > 1 launch form, two ranks sharing this box's one GPU (RCCL refuses two ranks per device: the ranks agree on gloo)
+EPPM_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 16 --warmup 4 --verify-config3 --no-cpu-baseline > gpurun_out/$T/bench_torchrun_2ranks_1gpu.json 2> gpurun_out/$T/bench_torchrun.err; cut -c1-160 gpurun_out/$T/bench_torchrun_2ranks_1gpu.json
+fi
+cd /tmp
+if [ -z "$PMC_ONLY" ]; then
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python3 $R/bench.py --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_single -- python3 $R/bench.py --steps 30 --warmup 3 --batch 1 --inflight 1 $COMMON > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_batch8 -- python3 $R/bench.py --steps 32 --warmup 8 --batch 8 --inflight 1 $COMMON > /dev/null 2>&1
+fi
 ls $O

@@ -259,8 +259,8 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
 #define EPPM_C2F_WAVES_MIN 2
 #endif
 #define EPPM_C2F_OCC __attribute__((amdgpu_waves_per_eu(EPPM_C2F_WAVES_MIN, EPPM_C2F_WAVES)))     // (min, max): radius 17 only fits 2
-// SPLIT: a launch with few tiles (level 1 of a 1024x436 pair: 448 tiles = 1.75 waves per SIMD) does not fill the chip
-// and runs latency bound.  Then a tile is given to 3 workgroups (one candidate column m each) or to 4 (one affine pass
+// SPLIT: a launch with few tiles (fewer than 256: under one wave per SIMD) does not fill the chip and runs latency bound.
+// Then a tile is given to 3 workgroups (one candidate column m each) or to 4 (one affine pass
 // each), whichever divides more evenly over the 256 CUs; the costs of a pixel (9 x 4 passes) go to a scratch plane and
 // k_c2f_select replays the reference's nested minimum and candidate loop.  Same costs, same selection order.
 template <int R, int SPLIT>
@@ -787,8 +787,10 @@ bool c2f_refine_wants_split(int w, int h, int R, int npairs)
     if (g_c2f_no_split.load()) return false;
     const int tiles = ((w + kBlock - 1) / kBlock) * ((h + kBlock - 1) / kBlock) * npairs;
 #ifndef EPPM_C2F_SPLIT_BELOW_WAVES
-#define EPPM_C2F_SPLIT_BELOW_WAVES (3 * 1024)        // fewer than 3 waves per SIMD on 256 CUs
+#define EPPM_C2F_SPLIT_BELOW_WAVES 1024              // fewer than 1 wave per SIMD on 256 CUs (at 256 threads per tile)
 #endif
+    // Round 2 split below 3 waves per SIMD, which sent level 1 of ONE 1024x436 pair (448 tiles) through the split gather kernel:
+    // 0.367 ms and a 16 MB scratch plane of 36 costs per pixel; the LDS-window kernel does the same launch in 0.364 ms without it.
     return (R == 9 || R == 17) && tiles * 4 < EPPM_C2F_SPLIT_BELOW_WAVES;
 }
 

@@ -809,7 +809,9 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     if (k == G) {
         if (quarter == 0) {
             // jump over the other 63 lanes' draws: v <- v * skip_mat over GF(2); Weyl counter by multiplication.
-            // Off the critical path: this wave has nothing else to do, the other G waves are evaluating guesses.
+            // Off the critical path: this wave has nothing else to do, the other G waves are evaluating guesses.  (Round 3 tried
+            // giving the jump to the last guess's wave after its evaluation -- six waves per workgroup, four workgroups per CU
+            // instead of three: slower, 1.40 -> 1.46 ms PatchMatch for one pair, -0.4 % batched: the jump then ends the workgroup.)
             const size_t so = ((size_t)block_id * 64 + lane) * 6;
             Xorwow st = load_state(s_state + lane * 6);
             const uint32_t v[5] = {st.v0, st.v1, st.v2, st.v3, st.v4};

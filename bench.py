@@ -4,24 +4,27 @@
 A step = one pass of the hot path (set_data's device part: prefilter + pyramid + census, then
 compute_flow: PatchMatch fwd/bwd at 1/4 res, L-R check, outlier removal, weighted median, hole fill,
 two coarse-to-fine levels, final smoothing) over ONE synthetic 1024x436 pair whose RGBA planes are
-already resident in HBM.  Consecutive steps are issued in groups of --batch (default 8) to batch contexts
-(eppm_create_batch: every kernel launch covers the group's pairs -- the quarter-resolution stages of ONE pair
+already resident in HBM; the float2 flow stays in HBM.  Consecutive steps are issued in groups of --batch (default 8) to
+batch contexts (eppm_create_batch: every kernel launch covers the group's pairs -- the quarter-resolution stages of ONE pair
 are too few pixels to fill 256 CUs), round robin over --inflight such contexts (default 3), each on its own HIP
 stream, so that the tail of one launch overlaps the next context's work; every step's work runs inside the timed
-region; `--batch 1` issues one context per step.
+region; `--batch 1` issues one context per step.  The timed window of exactly --steps steps is run --repeats (5) times,
+each bracketed by barrier + synchronize; the median is reported, min / max beside it.
 
 N > 1 (`--gpus N`): one process per GPU, each rank its own pairs (independent pairs, no data-path
 collective: SURVEY 8e); value = pairs of all ranks * W*H / max-over-ranks time.  When RANK is not in the
 environment (plain `python bench.py --gpus N`) this process only spawns the N rank processes -- before
 importing torch or touching HIP -- relays rank 0's JSON line and exits non-zero if any rank failed; under
-`torch.distributed.run` (RANK set) it is a rank itself.
+`torch.distributed.run` (RANK set) it is a rank itself.  `--verify-config3`: every rank runs its share of BASELINE configs[2]'s
+64 pairs through the host boundary and checks each flow against committed oracle hashes (`config3_verified`).
 
-Prints ONE JSON line: the contract fields, `roofline` (dominant kernel k_c2f_refine_tiled: algorithmic HBM
-bytes per launch / its mean HIP-event duration on the context's stream over the timed steps), and, on rank 0
-at N = 1: `valu_roofline` and `stage_ms` from a separate single-stream pass (no contention from other
-pairs), `latency_ms_per_pair`, `host_boundary` (PCIe-inclusive rates through eppm_set_images + eppm_compute),
-`cold_ms` (init + compute_flow, the window main.cpp:63-66 times), `config3` (8 distinct pairs per GPU:
-BASELINE.json configs[2]) and `cpu_baseline` (the CPU oracle on a bounded sample).
+Prints ONE JSON line: the contract fields, `roofline` (dominant kernel = the candidate refine; its launch duration by HIP
+events from a one-context pass of the same launches; bound "valu" with the HBM form beside it, from profiles/pmc_constants.json when
+that was measured on these device sources), `path_valu_roofline` (the whole path against the VALU issue peak) and, on rank 0 at
+N = 1: `valu_roofline` and `stage_ms` from a single-stream pass, `latency_ms_per_pair`, `host_boundary` (PCIe-inclusive rates of
+the reference API's own window -- host RGB in, host u/v out -- synchronous, batched and pipelined; tools/host_boundary.py),
+`cold_ms` (init + compute_flow, the window main.cpp:63-66 times), `config3` (8 distinct pairs per GPU: BASELINE.json
+configs[2]), `approx_exp_variant` (opt-in library, never `value`) and `cpu_baseline` (the CPU oracle on a bounded sample).
 """
 import argparse
 import hashlib

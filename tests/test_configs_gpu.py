@@ -532,7 +532,8 @@ def test_bench_two_ranks_share_one_gpu(backend):
     env = dict(os.environ, EPPM_BENCH_SHARE_GPU="1")
     env.pop("RANK", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--dist-backend", backend,
-                          "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                          "--no-extras", "--no-cpu-baseline"] + (["--verify-config3"] if backend == "gloo" else []),
+                         env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(line) == 1, out.stdout
@@ -540,6 +541,11 @@ def test_bench_two_ranks_share_one_gpu(backend):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["roofline"]["frac"] > 0 and d["roofline"]["avg_launch_ms"] > 0
     assert ("barrier and MAX go over gloo" in out.stderr) == (backend == "nccl")
+    if backend == "gloo":
+        # BASELINE configs[2] with its correctness bit: the two ranks' shares (pairs 0,2,4,.. and 1,3,5,..) of the 64 pairs, every flow
+        # equal to the committed oracle hash (tests/golden/MANIFEST_config3.json)
+        v = d["config3_verified"]
+        assert v["pairs"] == 64 and v["verified_pairs"] + v["inputs_differ_on_this_host"] == 64 and v["all_ok"], v
 
 
 # ---------------------------------------------------------------------------------------------------

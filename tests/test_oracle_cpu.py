@@ -899,3 +899,110 @@ def test_config3_manifest_covers_all_64_pairs():
     assert sorted(sum((shard.pairs_for_rank(64, r, 8) for r in range(8)), [])) == list(range(64))
     a, b, _, _ = synth.make_pair(man["h"], man["w"], seed=1234)
     assert hashlib.sha256(a.tobytes()).hexdigest() == man["pairs"]["0"]["img1_sha256"]
+
+
+# ---------------------------------------------------------------- the speculative sweeps and their evaluation cache, restated
+def test_speculative_sweep_form_and_evaluation_cache_equal_the_lockstep_sweeps(crop_stages):
+    """DESIGN.md 3.2 / 4, on the CPU: the two-launch form of a sweep -- phase A evaluates, for every visited pixel, the candidate
+    its chain tries when the previous pixel rejected (shift of that pixel's stored match), with no regard to the chains; phase B
+    walks the chains in lockstep order, takes phase A's cost on every step that follows a rejection (or starts a segment) and
+    evaluates only after an accepted candidate -- and the per-direction evaluation cache (a candidate evaluated for a pixel in an
+    earlier sweep of the same direction is not evaluated again) restated in Python on the oracle's patch cost: NNF and cost equal
+    orc_seg_propagate_dir's after every one of 12 sweeps (3 iterations x 4 directions, random searches in between), and the
+    evaluation counts show what each device kernel saves."""
+    st = crop_stages
+    i1, i2, c1, c2 = (st[k][:30, :40].copy() for k in ("img1_L2", "img2_L2", "cen1_L2", "cen2_L2"))
+    h, w = i1.shape
+    L = 10
+    evals = {"A": 0, "A_cached": 0, "B_fresh": 0}
+
+    def pd(x1, y1, x2, y2):
+        return np.float32(O.patch_dist(i1, i2, c1, c2, int(x1), int(y1), int(x2), int(y2)))
+
+    def shift(c, direction):
+        x, y = c
+        if direction == 0: return (min(x + 1, w - 1), y)
+        if direction == 1: return (x, min(y + 1, h - 1))
+        if direction == 2: return (max(x - 1, 0), y)
+        return (x, max(y - 1, 0))
+
+    cache = [dict() for _ in range(4)]           # per direction: pixel (y, x) -> (candidate, cost)
+
+    def sweep(cost, nnf, d):
+        nin = nnf.copy()                         # phase A and the seeds read the input plane, every visited pixel is written to nout
+        nout, cost = nnf.copy(), cost.copy()
+        is_row, rev = d in (0, 2), d >= 2
+        length, lines = (w, h) if is_row else (h, w)
+        step = -1 if rev else 1
+        at = (lambda line, i: (line, i)) if is_row else (lambda line, i: (i, line))      # (y, x) of position i on a line
+        get = lambda plane, p: (int(plane["x"][p]), int(plane["y"][p]))
+        # ---- phase A: the rejection-path candidate of every visited pixel (the first pixel of a line against the sweep is never visited)
+        spec = {}
+        for line in range(lines):
+            for i in range(length):
+                q = i - step
+                if q < 0 or q >= length:
+                    continue
+                p = at(line, i)
+                cand = shift(get(nin, at(line, q)), d)
+                if cand == get(nin, p):
+                    continue                     # equal to the pixel's own match: rejected unevaluated (skip rule)
+                hit = cache[d].get(p)
+                if hit is not None and hit[0] == cand:
+                    evals["A_cached"] += 1       # evaluated by an earlier sweep of this direction: the cost stands
+                else:
+                    evals["A"] += 1
+                    cache[d][p] = (cand, pd(p[1], p[0], cand[0], cand[1]))
+                spec[p] = cache[d][p][1]
+        # ---- phase B: the chains in lockstep order (segment 1 reaches forward pixel L before segment 0 does)
+        nseg = (length + L - 1) // L
+        for line in range(lines):
+            chains = []
+            for k in range(nseg):
+                if not rev:
+                    start = 0 if k == 0 else k * L - 1
+                    count = min(length - 1, start + L) - start
+                else:
+                    start = min((k + 1) * L, length - 1)
+                    count = start - k * L
+                chains.append(dict(start=start, count=count, carry=get(nin, at(line, start)), from_nin=True))
+            for s in range(L):
+                order = range(nseg - 1, -1, -1) if not rev else range(nseg)          # the order that matters only for pixel L
+                for k in order:
+                    ch = chains[k]
+                    if s >= ch["count"]:
+                        continue
+                    i = ch["start"] + step * (s + 1)
+                    p = at(line, i)
+                    cand = shift(ch["carry"], d)
+                    own = get(nout, p) if (not rev and k == 0 and s == L - 1 and nseg > 1) else get(nin, p)
+                    cur = cost[p]
+                    if cand == own:
+                        cv = cur
+                    elif ch["from_nin"]:
+                        cv = spec[p]             # phase A evaluated exactly this candidate
+                    else:
+                        evals["B_fresh"] += 1
+                        cv = pd(p[1], p[0], cand[0], cand[1])
+                    if cv < cur:
+                        nout["x"][p], nout["y"][p] = cand
+                        cost[p] = cv
+                        ch["carry"], ch["from_nin"] = cand, False
+                    else:
+                        ch["carry"], ch["from_nin"] = own, True
+        return cost, nout
+
+    nnf, states = O.gen_rand_field(w, h)
+    cost = O.cost_field(nnf, i1, i2, c1, c2)
+    ocost, onnf = cost, nnf
+    for it in range(3):
+        for d in range(4):
+            cost, nnf = sweep(cost, nnf, d)
+            ocost, onnf = O.seg_propagate_dir(ocost, onnf, i1, i2, c1, c2, d)
+            assert np.array_equal(nnf.view(np.int16), onnf.view(np.int16)), (it, d)
+            assert np.array_equal(cost.view(np.uint32), ocost.view(np.uint32)), (it, d)
+        states, ocost, onnf = O.random_search(states, ocost, onnf, i1, i2, c1, c2)
+        cost, nnf = ocost, onnf
+    visited = 12 * (h * w - min(h, w))          # roughly: every pixel but one per line, per sweep
+    assert evals["A_cached"] > 0 and evals["B_fresh"] > 0
+    assert evals["A"] + evals["B_fresh"] < visited      # fewer evaluations than the reference's one per visited pixel

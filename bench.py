@@ -144,6 +144,29 @@ def dominant_pmc(pmc, nb):
         return None
 
 
+def agree_on_group(dist, rank, probe):
+    """The data path needs no collective; the process group only carries the barrier and one MAX.  The gloo world group (already
+    initialised) is the control plane; `probe` (None, or a callable that builds the RCCL group and proves it with an all-reduce)
+    runs on top of it, and the ranks AGREE -- a MIN over gloo -- before any of them uses the result: a rank whose RCCL fails can
+    never sit in a gloo barrier while the others wait in an RCCL one.  Returns (control group, group for barrier / MAX)."""
+    import torch
+    ctl = dist.group.WORLD
+    grp, ok = None, 0
+    if probe is not None:
+        try:
+            grp = probe()
+            ok = 1
+        except Exception as e:
+            print(f"[bench] rank {rank}: nccl unusable ({e})", file=sys.stderr)
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)
+    if not int(flag.item()):
+        if probe is not None and rank == 0:
+            print("[bench] RCCL not usable on every rank; barrier and MAX go over gloo", file=sys.stderr)
+        grp = ctl
+    return ctl, grp
+
+
 def worker(args):
     import numpy as np
     rank = int(os.environ.get("RANK", "0"))
@@ -161,28 +184,18 @@ def worker(args):
     grp = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # The data path needs no collective; the process group only carries the barrier and one MAX.  gloo always comes up
-        # first, RCCL is probed on top of it, and the ranks AGREE (a MIN over gloo) before any of them uses it: a rank whose
-        # RCCL init fails can never sit in a gloo barrier while the others wait in an RCCL one.
-        import datetime
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        ctl = dist.group.WORLD
-        ok = 0
-        if args.dist_backend == "nccl":
-            try:
-                grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
-                probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe, group=grp)
-                torch.cuda.synchronize()
-                ok = int(int(probe.item()) == world)
-            except Exception as e:
-                print(f"[bench] rank {rank}: nccl unusable ({e})", file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)
-        if not int(flag.item()):
-            if args.dist_backend == "nccl" and rank == 0:
-                print("[bench] RCCL not usable on every rank; barrier and MAX go over gloo", file=sys.stderr)
-            grp = ctl
+
+        def probe_rccl():
+            import datetime
+            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe, group=g)          # communicators are created lazily: fail here, not inside the timed region
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError(f"all_reduce probe returned {probe.item()} for {world} ranks")
+            return g
+        ctl, grp = agree_on_group(dist, rank, probe_rccl if args.dist_backend == "nccl" else None)
     tdev = dev if (world > 1 and grp is not ctl) else torch.device("cpu")
 
     import eppm_amd

@@ -151,3 +151,50 @@ def test_bench_gpus_n_spawns_its_own_ranks(tmp_path):
     assert len(line) == 1 and '"n_gpus": 2' in line[0] and "--steps" in line[0], ok.stdout
     bad = subprocess.run([sys.executable, "-c", drv, "--fail-rank", "1"], capture_output=True, text=True, timeout=300)
     assert bad.returncode == 1 and "ranks failed" in bad.stderr, (bad.returncode, bad.stderr)
+
+
+def test_ranks_agree_on_the_backend_when_the_probe_fails_on_one_rank(tmp_path):
+    """bench.agree_on_group: two gloo ranks, the "RCCL" probe succeeds on rank 0 and raises on rank 1 (a partial failure): BOTH must
+    end up on the gloo group -- decided by a MIN over the gloo control group -- and a barrier + MAX over the agreed group completes.
+    With a probe that succeeds everywhere both take the probed group; without a probe both take gloo."""
+    stub = tmp_path / "rank.py"
+    stub.write_text(textwrap.dedent(f"""
+        import os, sys, json
+        sys.path.insert(0, {ROOT!r})
+        import torch, torch.distributed as dist
+        import bench
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        out = {{}}
+        def good():
+            return dist.new_group(backend="gloo")
+        for name, probe in (("good", good), ("none", None)):
+            ctl, grp = bench.agree_on_group(dist, rank, probe)
+            out[name] = grp is ctl
+            dist.barrier(group=grp)
+            t = torch.tensor([float(rank)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
+            assert t.item() == world - 1
+        # the partial failure: rank 0's probe succeeds, rank 1's raises
+        def partial_safe():
+            if rank == 1:
+                raise RuntimeError("simulated RCCL failure on rank 1")
+            return object()                                 # stands for a group only rank 0 believes in
+        ctl, grp = bench.agree_on_group(dist, rank, partial_safe)
+        out["partial"] = grp is ctl
+        dist.barrier(group=grp)
+        print(json.dumps(out), flush=True)
+        dist.destroy_process_group()
+    """))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(stub)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    import json
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, se[-2000:]
+        d = json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1])
+        assert d == {"good": False, "none": True, "partial": True}, (r, d)
+    assert "simulated RCCL failure" in outs[1][1] and "barrier and MAX go over gloo" in outs[0][1]

@@ -275,6 +275,7 @@ struct eppm_ctx {
     uint32_t *img1[kMaxLevels] = {}, *img2[kMaxLevels] = {}, *tmpu[kMaxLevels] = {};
     uint8_t *cen1[kMaxLevels] = {}, *cen2[kMaxLevels] = {};
     void *pk1[kMaxLevels] = {}, *pk2[kMaxLevels] = {};       // float4 texel planes {r,g,b,census}, linear (pitch = w)
+    uint32_t *pc1[kMaxLevels] = {}, *pc2[kMaxLevels] = {};   // the same texels in 4 bytes, at the levels the LDS-window refine runs on
     int16_t *nnf1 = nullptr, *nnf2 = nullptr, *nnf_tmp = nullptr, *nnf_tmp2 = nullptr;
     float *cost1 = nullptr, *cost2 = nullptr;
     float *spec1 = nullptr, *spec2 = nullptr;   // evaluation cache of the sweeps (PmProblem::spec / scand): four direction planes each
@@ -314,6 +315,8 @@ static PlanesH planes(const eppm_ctx* c, int l, bool swap)
     p.pk2 = swap ? c->pk1[l] : c->pk2[l];
     p.w = c->W[l]; p.h = c->H[l];
     p.pitch = c->W[l];
+    p.pc1 = swap ? c->pc2[l] : c->pc1[l];
+    p.pc2 = swap ? c->pc1[l] : c->pc2[l];
     return p;
 }
 
@@ -399,6 +402,10 @@ static int ctx_alloc(eppm_ctx* c)
         plane((void**)&c->tmpu[i], c->ipitch[i] * c->H[i]);
         plane(&c->pk1[i], n * 16);
         plane(&c->pk2[i], n * 16);
+        if (i < c->nl - 1) {                    // refine levels
+            plane((void**)&c->pc1[i], n * 4);
+            plane((void**)&c->pc2[i], n * 4);
+        }
         plane((void**)&c->cen1[i], c->cpitch[i] * c->H[i]);
         plane((void**)&c->cen2[i], c->cpitch[i] * c->H[i]);
         plane((void**)&c->flow[i], n * 8);
@@ -540,6 +547,7 @@ static int prepare(eppm_ctx* c)
             J.texels = k ? c->pk2[i] : c->pk1[i];   J.tpitch = c->W[i];
             J.img = k ? c->img2[i] : c->img1[i];    J.ipitch = (int)(c->ipitch[i] / 4);
             J.w = c->W[i]; J.h = c->H[i]; J.first_block = 0;
+            J.packed = k ? c->pc2[i] : c->pc1[i];
         }
     launch_census_batch(cb, s, bt);
     stage_end(c, c->ev_prep);

@@ -31,6 +31,10 @@ struct PlanesH {            // host-side mirror of eppm::Planes: float4 texel pl
     const void* pk1;
     const void* pk2;
     int w, h, pitch;
+    // optional (NULL: absent): the same texels in 4 bytes, {R, G, B, census} as one word per pixel, same pitch.  Kernels that stage
+    // a whole tile / window in LDS read these and convert while storing (a quarter of the HBM and L2 bytes for the same values)
+    const uint32_t* pc1 = nullptr;
+    const uint32_t* pc2 = nullptr;
 };
 
 // ---- prepare (k_prepare.hip) ----
@@ -43,7 +47,8 @@ void launch_gauss_decimate2(uint32_t* out0, const uint32_t* in0, uint32_t* out1,
 void launch_gauss_rgba2(uint32_t* out0, const uint32_t* in0, uint32_t* out1, const uint32_t* in1, int pitch_px, int h, int w, float sigma,
                         int radius, hipStream_t s, Batch bt = kOnePair);
 // census (+ texel plane) of several planes in one launch
-struct CensusJob { uint8_t* census; int cpitch; void* texels; int tpitch; const uint32_t* img; int ipitch; int w, h; int first_block; };
+struct CensusJob { uint8_t* census; int cpitch; void* texels; int tpitch; const uint32_t* img; int ipitch; int w, h; int first_block;
+                   uint32_t* packed = nullptr; };   // optional 4-byte texel plane {R,G,B,census}, pitch tpitch
 struct CensusBatch { int n; CensusJob job[2 * kMaxLevels]; };
 void launch_census_batch(CensusBatch& B, hipStream_t s, Batch bt = kOnePair);
 void launch_resize_rgba(uint32_t* out, int out_pitch_px, int outH, int outW, const uint32_t* in, int in_pitch_px, int h, int w,

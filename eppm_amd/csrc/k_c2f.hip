@@ -28,6 +28,14 @@ __device__ __forceinline__ Planes to_dev(const PlanesH& h, size_t pstride = 0, u
     return p;
 }
 
+// texel (sx, sy) for an LDS tile: from the 4-byte plane when the launch has one (converted here, bit for bit what the float4
+// plane holds: both come from make_texel), else from the float4 plane
+__device__ __forceinline__ float4 stage_texel(const uint32_t* __restrict__ pc, const float4* __restrict__ pk, unsigned idx)
+{
+    if (pc) { const uint32_t w = pc[idx]; return make_texel(w, w >> 24); }
+    return pk[idx];
+}
+
 // .cuh:511-537 as written (m outer over x, n inner over y), then the x post_scale of .cuh:135-142
 __global__ __launch_bounds__(256) void k_resize_flow(float* __restrict__ out_, int outH, int outW, const float* __restrict__ in_,
                                                      int h, int w, float ratio, float post_scale, size_t pstride)
@@ -475,6 +483,8 @@ void k_c2f_refine_win(PlanesH Ph, float* __restrict__ flow_, const float* __rest
     const int tid = grp * 256 + ptid;
     load_patch_lut(L, lut, R, tid, 512);
     const Planes P = to_dev(Ph, pstride, blockIdx.y);
+    const uint32_t* __restrict__ pc1 = pair_ptr_opt(Ph.pc1, pstride, blockIdx.y);
+    const uint32_t* __restrict__ pc2 = pair_ptr_opt(Ph.pc2, pstride, blockIdx.y);
     const int tiles_x = (P.w + kBlock - 1) / kBlock, tiles = tiles_x * ((P.h + kBlock - 1) / kBlock);
     const int per_xcd = (tiles + 7) / 8;
     const int slot = blockIdx.x >> 3;
@@ -485,7 +495,7 @@ void k_c2f_refine_win(PlanesH Ph, float* __restrict__ flow_, const float* __rest
     for (int t = tid; t < TWU * TWU; t += 512) {
         const int ry = t / TWU, rx = t % TWU;
         const int sy = iclamp(y0 + ry - R, 0, P.h - 1), sx = iclamp(x0 + rx - R, 0, P.w - 1);
-        s_src[ry * TW + rx] = P.pk1[(unsigned)(sy * P.pitch + sx)];
+        s_src[ry * TW + rx] = stage_texel(pc1, P.pk1, (unsigned)(sy * P.pitch + sx));
     }
     __syncthreads();
     const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
@@ -506,7 +516,7 @@ void k_c2f_refine_win(PlanesH Ph, float* __restrict__ flow_, const float* __rest
     if (coherent && mxx >= mnx) {
         for (int t = tid; t < WH * WW; t += 512) {
             const int sy = iclamp(wy0 + t / WW, 0, P.h - 1), sx = iclamp(wx0 + t % WW, 0, P.w - 1);
-            s_win[t] = P.pk2[(unsigned)(sy * P.pitch + sx)];
+            s_win[t] = stage_texel(pc2, P.pk2, (unsigned)(sy * P.pitch + sx));
         }
     }
     __syncthreads();
@@ -619,6 +629,8 @@ void k_c2f_refine_win4(PlanesH Ph, float* __restrict__ flow_, const float* __res
     const int tid = grp * 256 + ptid;
     load_patch_lut(L, lut, R, tid, 1024);
     const Planes P = to_dev(Ph, pstride, blockIdx.y);
+    const uint32_t* __restrict__ pc1 = pair_ptr_opt(Ph.pc1, pstride, blockIdx.y);
+    const uint32_t* __restrict__ pc2 = pair_ptr_opt(Ph.pc2, pstride, blockIdx.y);
     const int tiles_x = (P.w + kBlock - 1) / kBlock, tiles = tiles_x * ((P.h + kBlock - 1) / kBlock);
     const int per_xcd = (tiles + 7) / 8;
     const int slot = blockIdx.x >> 3;
@@ -629,7 +641,7 @@ void k_c2f_refine_win4(PlanesH Ph, float* __restrict__ flow_, const float* __res
     for (int t = tid; t < TWU * TWU; t += 1024) {
         const int ry = t / TWU, rx = t % TWU;
         const int sy = iclamp(y0 + ry - R, 0, P.h - 1), sx = iclamp(x0 + rx - R, 0, P.w - 1);
-        s_src[ry * TW + rx] = P.pk1[(unsigned)(sy * P.pitch + sx)];
+        s_src[ry * TW + rx] = stage_texel(pc1, P.pk1, (unsigned)(sy * P.pitch + sx));
     }
     __syncthreads();
     const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
@@ -650,7 +662,7 @@ void k_c2f_refine_win4(PlanesH Ph, float* __restrict__ flow_, const float* __res
     if (coherent && mxx >= mnx) {
         for (int t = tid; t < WH * WW; t += 1024) {
             const int sy = iclamp(wy0 + t / WW, 0, P.h - 1), sx = iclamp(wx0 + t % WW, 0, P.w - 1);
-            s_win[t] = P.pk2[(unsigned)(sy * P.pitch + sx)];
+            s_win[t] = stage_texel(pc2, P.pk2, (unsigned)(sy * P.pitch + sx));
         }
     }
     __syncthreads();

@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256) void k_census_batch(CensusBatch B, size_t pstr
     CensusJob J = B.job[j];
     J.census = pair_ptr(J.census, pstride, blockIdx.y);
     J.texels = pair_ptr_opt(J.texels, pstride, blockIdx.y);
+    J.packed = pair_ptr_opt(J.packed, pstride, blockIdx.y);
     J.img = pair_ptr(J.img, pstride, blockIdx.y);
     const int b = blockIdx.x - J.first_block, bw = (J.w + 63) / 64;
     __shared__ float lum[6][66];
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) void k_census_batch(CensusBatch B, size_t pstr
     r += (lum[ly + 1][lx + 1] > c) ? 128u : 0u;
     J.census[y * J.cpitch + x] = (uint8_t)r;
     if (J.texels) ((float4*)J.texels)[y * J.tpitch + x] = make_texel(J.img[y * J.ipitch + x], r);
+    if (J.packed) J.packed[y * J.tpitch + x] = (J.img[y * J.ipitch + x] & 0xffffffu) | (r << 24);
 }
 void launch_census_batch(CensusBatch& B, hipStream_t s, Batch bt)
 {

@@ -373,8 +373,9 @@ def worker(args):
             insts = dp["valu_insts"] / 2 * NB                      # wave64 VALU instructions per launch
             roof = {"bound": "valu", "kernel": kern, "achieved": insts / (dom_ms * 1e-3) / 1e9, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e9,
                     "unit": "G wave64-inst/s", "frac": insts / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S,
-                    "traffic": (2 * dp["fetch_size_kb"] + dp["write_size_kb"]) * 1024 / 2 * NB,
-                    "wave64_valu_insts_per_launch": insts, "hbm": hbm, "source": pmc.get("source"),
+                    "traffic": (2 * dp["fetch_size_kb"] + dp["write_size_kb"]) * 1024 / 2 * NB, "traffic_unit": "HBM-side bytes per launch",
+                    "wave64_valu_insts_per_launch": insts, "hbm": dict(hbm, traffic=(2 * dp["fetch_size_kb"] + dp["write_size_kb"]) * 1024 / 2 * NB),
+                    "source": pmc.get("source"),
                     "note": "the path has no dense contraction and is not HBM bound (3 600 patch samples x ~46 VALU instructions per pixel against 26 "
                             "algorithmic bytes): the bound that applies is vector-ALU issue, peak = 256 CUs x 4 SIMD x 2.4 GHz / 2 cycles per wave64 "
                             "instruction; the HBM form the contract names is in `hbm`; `traffic` = HBM bytes per launch from separate --pmc passes "

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""bench.py -- EPPM hot path on MI355X: Mflow-vectors/s on 1024x436 Sintel-shape pairs.
+"""bench.py -- EPPM hot path on MI355X: Mflow-vectors/s (`value`, `ms_per_step`) on 1024x436 Sintel-shape pairs, and the single-pair
+latency beside it (`latency_ms_per_pair`: one pair, one stream, nothing else in flight -- the "ms/frame-pair" half of BASELINE.json's metric).
 
 A step = one pass of the hot path (set_data's device part: prefilter + pyramid + census, then
 compute_flow: PatchMatch fwd/bwd at 1/4 res, L-R check, outlier removal, weighted median, hole fill,
@@ -11,20 +12,27 @@ stream, so that the tail of one launch overlaps the next context's work; every s
 region; `--batch 1` issues one context per step.  The timed window of exactly --steps steps is run --repeats (5) times,
 each bracketed by barrier + synchronize; the median is reported, min / max beside it.
 
+The line proves its own correctness: the pairs of the timed region are pairs (rank * P + j) mod 64 of BASELINE configs[2]'s 64 pairs
+(seeds 1234 + index), whose CPU-oracle flows are committed as sha256 (tests/golden/MANIFEST_config3.json); after the last repeat
+every flow the timed region wrote is hashed and compared: `timed_region_verified: {ok, of}` at every N.
+
 N > 1 (`--gpus N`): one process per GPU, each rank its own pairs (independent pairs, no data-path
 collective: SURVEY 8e); value = pairs of all ranks * W*H / max-over-ranks time.  When RANK is not in the
 environment (plain `python bench.py --gpus N`) this process only spawns the N rank processes -- before
 importing torch or touching HIP -- relays rank 0's JSON line and exits non-zero if any rank failed; under
-`torch.distributed.run` (RANK set) it is a rank itself.  `--verify-config3`: every rank runs its share of BASELINE configs[2]'s
-64 pairs through the host boundary and checks each flow against committed oracle hashes (`config3_verified`).
+`torch.distributed.run` (RANK set) it is a rank itself.  At N > 1 (or with `--verify-config3`) every rank also runs its share of
+configs[2]'s 64 pairs (pair i -> rank i mod N) through the host boundary and checks each flow against the same hashes
+(`config3_verified`; a pair whose synthetic images differ on this host counts as unverified, never as OK).
 
-Prints ONE JSON line: the contract fields, `roofline` (dominant kernel = the candidate refine; its launch duration by HIP
-events from a one-context pass of the same launches; bound "valu" with the HBM form beside it, from profiles/pmc_constants.json when
-that was measured on these device sources), `path_valu_roofline` (the whole path against the VALU issue peak) and, on rank 0 at
-N = 1: `valu_roofline` and `stage_ms` from a single-stream pass, `latency_ms_per_pair`, `host_boundary` (PCIe-inclusive rates of
-the reference API's own window -- host RGB in, host u/v out -- synchronous, batched and pipelined; tools/host_boundary.py),
-`cold_ms` (init + compute_flow, the window main.cpp:63-66 times), `config3` (8 distinct pairs per GPU: BASELINE.json
-configs[2]), `approx_exp_variant` (opt-in library, never `value`) and `cpu_baseline` (the CPU oracle on a bounded sample).
+Prints ONE JSON line: the contract fields, `timed_region_verified`, `roofline` (dominant kernel = the candidate refine; its launch
+duration by HIP events from a one-context pass of the same launches; bound "valu" with the HBM form beside it, from
+profiles/pmc_constants.json when that was measured on these device sources), `path_valu_roofline` (the whole path against the VALU
+issue peak) and, on rank 0 at N = 1: `latency_ms_per_pair`, `stage_ms` and `valu_roofline` from a single-stream pass, `other_configs`
+(BASELINE configs[3] 1920x1080 and configs[4] 3840x2160 at patch radius 17: value, ms per pair, fraction of the VALU floor, flow
+checked against the committed oracle hash), `host_boundary` (PCIe-inclusive rates of the reference API's own window -- host RGB in,
+host u/v out -- synchronous, batched and pipelined; tools/host_boundary.py), `cold_ms` (init + compute_flow, the window
+main.cpp:63-66 times), `config3` (8 distinct pairs per GPU: BASELINE.json configs[2]) and `cpu_baseline` (the CPU oracle on a bounded
+sample).
 """
 import argparse
 import hashlib
@@ -64,11 +72,13 @@ def parse_args(known_only=False):
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed window of exactly --steps steps is run this many times back to back; the median is reported (min/max beside it)")
-    ap.add_argument("--verify-config3", action="store_true",
+    ap.add_argument("--verify-config3", dest="verify_config3", action="store_true", default=None,
                     help="BASELINE configs[2] with a correctness bit: this rank's share of the 64 pairs (pair i -> rank i mod N, seeds 1234+i) through the "
-                         "host boundary, every flow checked against tests/golden/MANIFEST_config3.json")
+                         "host boundary, every flow checked against tests/golden/MANIFEST_config3.json.  Default: on when --gpus > 1")
+    ap.add_argument("--no-verify-config3", dest="verify_config3", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip host_boundary / cold / config3 / single-stream legs (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip host_boundary / cold / config3 / single-stream / other-config legs (profiling runs)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the 1920x1080 and 3840x2160 R=17 legs (other_configs)")
     return ap.parse_known_args()[0] if known_only else ap.parse_args()
 
 
@@ -174,10 +184,21 @@ def worker(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the HIP runtime starts: RCCL needs dmabuf IPC on this pool
+    verify3 = (world > 1) if args.verify_config3 is None else bool(args.verify_config3)
+    other_cfgs = world == 1 and not args.no_extras and not args.no_other_configs and (args.width, args.height, args.patch_r) == (W, H, 9)
+    S = max(1, args.inflight)
+    NB = max(1, args.batch)
+    NC3 = 0 if args.no_extras else args.pairs_per_gpu        # pairs of the config-3 leg
+    NP = max(S * max(1, args.batch), NC3)
+    plan = InputPlan(args, rank, world, NP, verify3, other_cfgs)
+    plan.generate()                 # worker processes, before this process starts the GPU runtime
     import torch
     import torch.distributed as dist
     if os.environ.get("EPPM_BENCH_SHARE_GPU"):      # test hook: several ranks on one GPU (gloo only)
         local_rank = 0
+    ndev = torch.cuda.device_count()
+    if ndev and local_rank >= ndev:                 # a launcher that hands every rank one visible device (HIP_VISIBLE_DEVICES per rank)
+        local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ctl = None                      # gloo group: control plane (backend agreement); `grp` carries the barrier and the MAX of the wall time
@@ -202,8 +223,6 @@ def worker(args):
     from eppm_amd import synth
     w, h = args.width, args.height
     params = eppm_amd.Params(patch_r=args.patch_r)
-    S = max(1, args.inflight)
-    NB = max(1, args.batch)
     engs = []
     for _ in range(S):
         e = eppm_amd.EPPM(device=local_rank, params=params)
@@ -217,11 +236,9 @@ def worker(args):
         rgba = np.zeros((h, w, 4), np.uint8)
         rgba[..., :3] = img
         return torch.from_numpy(rgba).to(dev)
-    NC3 = 0 if args.no_extras else args.pairs_per_gpu        # pairs of the config-3 leg
-    NP = max(S * max(1, args.batch), NC3)
     host_pairs, inputs = [], []
     for j in range(NP):
-        img1, img2, gu_j, gv_j = synth.make_pair(h, w, seed=1234 + rank * NP + j)
+        img1, img2, gu_j, gv_j = plan.timed_pair(j)
         if j == 0:
             gu, gv = gu_j, gv_j
         host_pairs.append((img1, img2))
@@ -284,6 +301,12 @@ def worker(args):
         barrier()
         dts.append(all_max(time.perf_counter() - t0))
     dt = float(np.median(dts))
+    # every flow the timed region wrote (step i -> buffer i mod S*NB) against the committed oracle hash of its pair
+    tv = plan.verify_timed([(j, inputs[j][2]) for j in sorted({i % (S * NB) for i in range(args.steps)})], host_pairs)
+    if world > 1:
+        t = torch.tensor(tv, dtype=torch.int64)
+        dist.all_reduce(t, group=ctl)
+        tv = [int(x) for x in t]
     dom_timed = []
     for e in tengs:
         dom_timed += e.stage_times(clear=True)
@@ -347,8 +370,8 @@ def worker(args):
                              "batch": {"value": world * NC3 * w * h / dt3b / 1e6, "ms_per_pair": dt3b / NC3 * 1e3, "pairs_per_launch": NC3,
                                        "stage_ms_per_pair": bst}}
 
-    if args.verify_config3:
-        extras["config3_verified"] = verify_config3(args, rank, world, local_rank, params, dist, ctl)
+    if verify3:
+        extras["config3_verified"] = verify_config3(args, rank, world, local_rank, params, dist, ctl, plan)
 
     if rank == 0:
         def per_launch(records):
@@ -398,6 +421,9 @@ def worker(args):
                        "inputs": "device-resident RGBA", "outputs": "device-resident float2 flow",
                        "pairs_per_step_per_gpu": 1, "pairs_in_flight_per_gpu": S * NB, "pairs_per_launch": NB, "contexts_in_flight": S,
                        "width": w, "height": h},
+            "timed_region_verified": {"ok": tv[0], "of": tv[1], "inputs_differ_on_this_host": tv[2], "all_ok": tv[0] == tv[1] and tv[1] > 0,
+                                      "what": "sha256 of every flow the last repeat of the timed region left in HBM (all ranks) == the CPU oracle's flow of that "
+                                              "pair, tests/golden/MANIFEST_config3.json" if plan.man3 else plan.why_unverifiable},
             "roofline": roof,
             "epe_vs_synthetic_gt": epe_gt,
         }
@@ -409,7 +435,10 @@ def worker(args):
             if isinstance(out["host_boundary"], dict) and "pipelined" in out["host_boundary"]:
                 out["host_boundary"]["pipelined_over_value"] = out["host_boundary"]["pipelined"] / out["value"]
             out["cold_ms"] = cold_window(args, local_rank, params, host_pairs[0])
-            out["approx_exp_variant"] = approx_variant_leg(args)
+            if other_cfgs:
+                for e in engs + bengs:          # the 4K context needs no room, but the timings should not share the chip with idle-but-resident contexts' streams
+                    e.synchronize()
+                out["other_configs"] = other_configs(plan, local_rank, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h)
         print(json.dumps(out), flush=True)
@@ -417,32 +446,31 @@ def worker(args):
         dist.destroy_process_group()
 
 
-def verify_config3(args, rank, world, local_rank, params, dist, ctl):
+def verify_config3(args, rank, world, local_rank, params, dist, ctl, plan):
     """BASELINE configs[2] with a correctness bit: this rank's share of the 64 pairs (pair i -> rank i mod world: eppm_amd/shard.py;
     seeds 1234 + i) goes through the host boundary of a batch context (eppm_batch_set_images / eppm_batch_compute) and the
     sha256 of every flow is compared with tests/golden/MANIFEST_config3.json (the CPU oracle's flows, computed once in the build
-    container).  Rank 0 reports how many of the 64 verified; a mismatch is named on stderr."""
+    container).  Rank 0 reports how many of the 64 verified; a mismatch is named on stderr.  A pair whose synthetic images do not
+    hash to the manifest's (another numpy / libm than the build container's) is UNVERIFIED: `all_ok` needs all 64 verified."""
     import hashlib as H
-    import numpy as np
     import torch
     import eppm_amd
-    from eppm_amd import shard, synth
-    man = json.load(open(os.path.join(ROOT, "tests", "golden", "MANIFEST_config3.json")))
+    man = plan.man3
+    if man is None:
+        return {"error": plan.why_unverifiable}
     w, h = man["w"], man["h"]
-    mine = shard.pairs_for_rank(man["n_pairs"], rank, world)
-    if (args.width, args.height, args.patch_r) != (w, h, 9):
-        return {"error": "the config-3 goldens are for 1024x436, patch_r 9"}
+    mine = plan.share3
     B = eppm_amd.EPPMBatch(h, w, 8, device=local_rank, params=params)
     ok = bad_inputs = 0
     t0 = time.perf_counter()
     for g in range(0, len(mine), 8):
         idx = mine[g:g + 8]
-        pairs = [synth.make_pair(h, w, seed=man["seed0"] + i)[:2] for i in idx]
+        pairs = [plan.pair3(i)[:2] for i in idx]
         B.set_data(pairs)
         for i, (a, b), (u, v) in zip(idx, pairs, B.compute_flow()):
             rec = man["pairs"][str(i)]
             if H.sha256(a.tobytes()).hexdigest() != rec["img1_sha256"] or H.sha256(b.tobytes()).hexdigest() != rec["img2_sha256"]:
-                bad_inputs += 1          # numpy / libm of this host generates other images than the build container's: not a flow error
+                bad_inputs += 1          # numpy / libm of this host generates other images than the build container's: cannot be verified
             elif H.sha256(u.tobytes() + v.tobytes()).hexdigest() == rec["flow_sha256"]:
                 ok += 1
             else:
@@ -452,8 +480,141 @@ def verify_config3(args, rank, world, local_rank, params, dist, ctl):
     t = torch.tensor([ok, bad_inputs, len(mine)], dtype=torch.int64)
     if world > 1:
         dist.all_reduce(t, group=ctl)
-    return {"verified_pairs": int(t[0]), "pairs": int(t[2]), "inputs_differ_on_this_host": int(t[1]), "all_ok": int(t[0]) + int(t[1]) == int(t[2]) and int(t[2]) == man["n_pairs"],
-            "seconds_rank0_incl_synthesis": dt}
+    n_ok, n_bad, n = int(t[0]), int(t[1]), int(t[2])
+    return {"verified_pairs": n_ok, "pairs": n, "unverifiable_inputs_differ_on_this_host": n_bad, "mismatches": n - n_ok - n_bad,
+            "all_ok": n_ok == n and n == man["n_pairs"], "state": "verified" if n_ok == n else ("mismatch" if n - n_ok - n_bad else "unverifiable"),
+            "seconds_rank0": dt}
+
+
+class InputPlan:
+    """Which synthetic pairs this rank needs, generated up front by worker processes (eppm_amd.synth.make_pairs_parallel):
+      * the timed region's pairs: indices (rank * NP + j) mod 64 of BASELINE configs[2]'s 64 pairs (seed 1234 + index), so that every
+        flow of the timed region has a committed oracle hash (tests/golden/MANIFEST_config3.json) at any number of ranks;
+      * with config-3 verification: this rank's share i = rank mod world of the 64 pairs;
+      * rank 0 at N = 1: the 1920x1080 and 3840x2160 pairs of BASELINE configs[3], [4] (tests/golden/MANIFEST_large.json)."""
+
+    def __init__(self, args, rank, world, NP, verify3, other):
+        from eppm_amd import shard
+        self.h, self.w, self.rank, self.NP = args.height, args.width, rank, NP
+        self.man3, self.large, self.why_unverifiable = None, None, None
+        try:
+            self.man3 = json.load(open(os.path.join(ROOT, "tests", "golden", "MANIFEST_config3.json")))
+            self.large = json.load(open(os.path.join(ROOT, "tests", "golden", "MANIFEST_large.json")))
+        except Exception as e:
+            self.why_unverifiable = f"no golden manifest: {e}"
+        if self.man3 and (args.width, args.height, args.patch_r) != (self.man3["w"], self.man3["h"], 9):
+            self.man3, self.why_unverifiable = None, "the committed oracle hashes are for 1024x436 at patch_r 9, default parameters"
+        n64 = self.man3["n_pairs"] if self.man3 else 64
+        self.seed0 = self.man3["seed0"] if self.man3 else 1234
+        self.timed_idx = [(rank * NP + j) % n64 for j in range(NP)]
+        self.share3 = shard.pairs_for_rank(n64, rank, world) if (verify3 and self.man3) else []
+        self.other = ["hd_1234", "uhd_r17_1234"] if (other and self.large) else []
+        self._pairs = {}
+
+    def _jobs(self):
+        jobs = [(self.h, self.w, self.seed0 + i, 20.0) for i in dict.fromkeys(self.timed_idx + self.share3)]
+        jobs += [(self.large[k]["h"], self.large[k]["w"], self.large[k]["seed"], self.large[k]["max_flow"]) for k in self.other]
+        return jobs
+
+    def generate(self):
+        from eppm_amd import synth
+        jobs = self._jobs()
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        for j, p in zip(jobs, synth.make_pairs_parallel(jobs, workers=max(1, min(32, (os.cpu_count() or 1) // (2 * world))))):
+            self._pairs[j] = p
+
+    def timed_pair(self, j):
+        return self._pairs[(self.h, self.w, self.seed0 + self.timed_idx[j], 20.0)]
+
+    def pair3(self, i):
+        return self._pairs[(self.h, self.w, self.seed0 + i, 20.0)]
+
+    def large_pair(self, name):
+        r = self.large[name]
+        return self._pairs[(r["h"], r["w"], r["seed"], r["max_flow"])]
+
+    def verify_timed(self, flows, host_pairs):
+        """flows: [(j, device tensor (h, w, 2) float32)] -> [ok, of, inputs_differ]"""
+        if self.man3 is None:
+            return [0, 0, 0]
+        ok = bad = 0
+        for j, f in flows:
+            rec = self.man3["pairs"][str(self.timed_idx[j])]
+            a, b = host_pairs[j]
+            if hashlib.sha256(a.tobytes()).hexdigest() != rec["img1_sha256"] or hashlib.sha256(b.tobytes()).hexdigest() != rec["img2_sha256"]:
+                bad += 1
+                continue
+            uv = f.cpu().numpy()
+            if hashlib.sha256(uv[..., 0].tobytes() + uv[..., 1].tobytes()).hexdigest() == rec["flow_sha256"]:
+                ok += 1
+            else:
+                print(f"[bench] rank {self.rank}: timed-region pair {self.timed_idx[j]} (buffer {j}): flow differs from the golden", file=sys.stderr)
+        return [ok, len(flows), bad]
+
+
+def other_configs(plan, device, dev):
+    """BASELINE configs[3] and [4] in the driver's line: 1920x1080 (one pair per launch, three contexts in flight) and 3840x2160 at
+    patch radius 17 (contexts in flight: 2): device-resident inputs, the same window definition as `value` at a few steps, the flow
+    of every context checked against the committed CPU-oracle hash (tests/golden/MANIFEST_large.json), and the fraction of the
+    VALU-issue floor of that shape (profiles/pmc_constants.json)."""
+    import numpy as np
+    import torch
+    import eppm_amd
+    out = {}
+    for name, key, nctx, steps in (("hd_1234", "hd", 3, 12), ("uhd_r17_1234", "uhd_r17", 2, 4)):
+        if name not in plan.other:
+            continue
+        try:
+            rec = plan.large[name]
+            h, w, R = rec["h"], rec["w"], rec["patch_r"]
+            a, b = plan.large_pair(name)[:2]
+            inputs_ok = hashlib.sha256(a.tobytes()).hexdigest() == rec["img1_sha256"] and hashlib.sha256(b.tobytes()).hexdigest() == rec["img2_sha256"]
+            prm = eppm_amd.Params(patch_r=R)
+            engs = []
+            for _ in range(nctx):
+                e = eppm_amd.EPPM(device=device, params=prm)
+                e.init(h, w)
+                engs.append(e)
+
+            def to_dev(img):
+                rgba = np.zeros((h, w, 4), np.uint8)
+                rgba[..., :3] = img
+                return torch.from_numpy(rgba).to(dev)
+            da, db = to_dev(a), to_dev(b)
+            flows = [torch.empty((h, w, 2), dtype=torch.float32, device=dev) for _ in range(nctx)]
+
+            def run(n):
+                for i in range(n):
+                    e = engs[i % nctx]
+                    e.set_data_device(da.data_ptr(), db.data_ptr(), w * 4)
+                    e.compute_flow_device(flows[i % nctx].data_ptr())
+                for e in engs:
+                    e.synchronize()
+            run(nctx)
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run(steps)
+                ts.append((time.perf_counter() - t0) / steps)
+            dt = float(np.median(ts))
+            ok = 0
+            for f in flows:
+                uv = f.cpu().numpy()
+                ok += int(hashlib.sha256(uv[..., 0].tobytes() + uv[..., 1].tobytes()).hexdigest() == rec["flow_sha256"])
+            for e in engs:
+                e.close()
+            del da, db, flows
+            pv = path_valu_roofline(pmc_constants(w, h, R), 1, dt)
+            out[key] = {"workload": f"single {w}x{h} synthetic pair per step (seed {rec['seed']}, |flow| <= {rec['max_flow']:g}), full 3-level pyramid, patch_r={R}; "
+                                    f"device-resident RGBA in, float2 flow left in HBM; {nctx} single-pair contexts in flight, {steps} steps, median of 3 windows",
+                        "value": w * h / dt / 1e6, "unit": "Mflow-vectors/s", "ms_per_step": dt * 1e3, "contexts_in_flight": nctx,
+                        "path_valu_roofline": {"frac": pv["frac"], "floor_ms_per_pair": pv["floor_ms_per_pair"]} if pv else None,
+                        "verified": {"ok": ok if inputs_ok else 0, "of": nctx, "state": "verified" if (inputs_ok and ok == nctx) else ("mismatch" if inputs_ok else "unverifiable: inputs differ on this host"),
+                                     "against": f"tests/golden/MANIFEST_large.json[{name}].flow_sha256 (the CPU oracle's flow)"}}
+        except Exception as ex:                  # a reported extra, never a reason to lose the line
+            out[key] = {"error": str(ex)[:300]}
+    return out
 
 
 def single_stream_legs(args, eng, inputs, pitch, pmc, alg_bytes):
@@ -527,66 +688,36 @@ def cold_window(args, device, params, pair):
     return float(np.median(ts))
 
 
-def approx_variant_leg(args):
-    """The opt-in libeppm_hip_approx.so (v_exp_f32 instead of the shared exp formula; NOT bit-identical, never `value`): its
-    throughput on the same workload and its EPE against the oracle on the bundled pair, each in a child process."""
-    if os.environ.get("EPPM_HIP_VARIANT"):
-        return None
-    env = dict(os.environ, EPPM_HIP_VARIANT="approx")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
-        env.pop(k, None)
-    try:
-        cmd = [sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", str(min(args.steps, 60)), "--warmup", str(args.warmup),
-               "--batch", str(args.batch), "--inflight", str(args.inflight), "--width", str(args.width), "--height", str(args.height), "--patch-r", str(args.patch_r)]
-        b = json.loads([ln for ln in subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600).stdout.splitlines() if ln.startswith("{")][-1])
-        env2 = dict(env)
-        env2.pop("EPPM_HIP_VARIANT", None)
-        e = json.loads([ln for ln in subprocess.run([sys.executable, os.path.join(ROOT, "tools", "approx_exp_epe.py")], env=env2, capture_output=True,
-                                                    text=True, timeout=900).stdout.splitlines() if ln.startswith("{")][-1])
-        return {"value": b["value"], "unit": b["unit"], "ms_per_step": b["ms_per_step"], "epe_vs_oracle_px": e["epe_mean_px"], "epe_pair": e["pair"],
-                "tolerance_px": 1e-3, "library": e["library"], "worst_case_mean_px": e["worst_case_mean_px"],
-                "epe_by_case": {k: {"mean": c["epe_mean_px"], "p99": c["epe_p99_px"], "max": c["epe_max_px"]} for k, c in e["cases"].items()},
-                "note": "opt-in build, not bit-identical to the oracle; EPE measured against the exact library (= the oracle bit for bit); the headline value is the exact library"}
-    except Exception as ex:                      # a reported extra, never a reason to lose the line
-        return {"error": str(ex)[:200]}
-
-
 def cpu_baseline(w, h):
-    """The CPU oracle (oracle/, a port of the reference's kernel semantics: the reference has no CPU path) timed on this
-    host on bounded samples: the workload's own pair once per OpenMP thread count in {16, 32, 64} (the lockstep sweeps
-    synchronise every step: 16-32 threads are fastest on a 256-thread host, all 256 are 9x slower) -- the best one is
-    reported -- and ONE thread on the pair's centre quarter (w/2 x h/2: a quarter of the vectors, about 12 s)."""
+    """The CPU oracle (oracle/, a port of the reference's kernel semantics: the reference has no CPU path) timed on this host on a
+    bounded sample: the workload's own pair (seed 1234), whole path, five runs on 16 OpenMP threads (the lockstep sweeps synchronise
+    every step: 16-32 threads are fastest on the GPU box's 256-thread host, 128 take twice and 256 nine times as long,
+    tools/orc_threads.py), median reported; and ONE thread on the pair's centre 256x128 crop."""
     from oracle import oracle as O
     from eppm_amd import synth
-    a, b, _, _ = synth.make_pair(h, w, seed=1234)
+    a, b, _, _ = synth.make_pair_cached(h, w, seed=1234)
     O.compute_flow(a[:32, :32].copy(), b[:32, :32].copy())      # build + warm
     n_all = O.num_threads()
     ncpu = os.cpu_count() or 1
-    tried = {}
-    for n in [c for c in (16, 32, 64) if c <= ncpu] or [ncpu]:
-        O.set_num_threads(n)
-        t0 = time.perf_counter()
-        O.compute_flow(a, b)
-        tried[n] = time.perf_counter() - t0
-    n_best = min(tried, key=tried.get)
-    O.set_num_threads(n_best)
-    runs = [tried[n_best]]
-    for _ in range(4):                       # median of 5 runs at the best thread count (SURVEY 8d)
+    n = min(16, ncpu)
+    O.set_num_threads(n)
+    runs = []
+    for _ in range(5):                       # median of 5 runs (SURVEY 8d)
         t0 = time.perf_counter()
         O.compute_flow(a, b)
         runs.append(time.perf_counter() - t0)
     dt = float(sorted(runs)[len(runs) // 2])
-    qh, qw = h // 2, w // 2
-    qa, qb = a[h // 4:h // 4 + qh, w // 4:w // 4 + qw].copy(), b[h // 4:h // 4 + qh, w // 4:w // 4 + qw].copy()
+    qh, qw = min(h, 128), min(w, 256)
+    y0, x0 = (h - qh) // 2, (w - qw) // 2
+    qa, qb = a[y0:y0 + qh, x0:x0 + qw].copy(), b[y0:y0 + qh, x0:x0 + qw].copy()
     O.set_num_threads(1)
     t0 = time.perf_counter()
     O.compute_flow(qa, qb)
     dt1 = time.perf_counter() - t0
     O.set_num_threads(n_all)
-    return {"value": w * h / dt / 1e6, "unit": "Mflow-vectors/s", "cores": n_best, "kind": "port",
+    return {"value": w * h / dt / 1e6, "unit": "Mflow-vectors/s", "cores": n, "kind": "port",
             "sample": f"1 pair {w}x{h} (the workload's own pair, seed 1234), whole path, median of {len(runs)} runs = {dt:.2f} s (min {min(runs):.2f}, max "
-                      f"{max(runs):.2f}), OpenMP oracle on {n_best} of {ncpu} hardware threads (one run each by thread count: "
-                      + ", ".join(f"{k}: {v:.1f} s" for k, v in tried.items()) + ")",
+                      f"{max(runs):.2f}), OpenMP oracle on {n} of {ncpu} hardware threads",
             "single_thread": {"value": qw * qh / dt1 / 1e6, "unit": "Mflow-vectors/s", "cores": 1,
                               "sample": f"centre {qw}x{qh} crop of the same pair, whole path once, {dt1:.1f} s, one thread"}}
 

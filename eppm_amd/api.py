@@ -65,6 +65,7 @@ class EPPM:
         self._ctx = C.c_void_p()
         self._device = device
         self._params = params
+        self._pending_out = None
         self.h = self.w = 0
 
     # -- reference interface ---------------------------------------------------------------
@@ -126,6 +127,7 @@ class EPPM:
             check(lib().eppm_compute_begin(self._ctx), "eppm_compute_begin")
         else:
             u, v = self._out(out)
+            self._pending_out = (u, v)      # the copy engine writes these planes until compute_flow_end: keep them alive
             check(lib().eppm_compute_begin_into(self._ctx, u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "eppm_compute_begin_into")
 
     def compute_flow_end(self, out=None):
@@ -133,6 +135,7 @@ class EPPM:
         self._need()
         u, v = self._out(out)
         check(lib().eppm_compute_end(self._ctx, u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "eppm_compute_end")
+        self._pending_out = None
         return u, v
 
     # -- device-resident variants (no PCIe in the timed region) ----------------------------
@@ -216,6 +219,7 @@ class EPPMBatch:
         check(lib().eppm_create_batch(C.byref(self._ctx), int(h), int(w), int(device),
                                       C.byref(params) if params is not None else None, int(npairs)), "eppm_create_batch")
         self.h, self.w, self.npairs, self.n = int(h), int(w), int(npairs), 0
+        self._pending_out = None
 
     @staticmethod
     def _ptrs(arrs):
@@ -264,11 +268,13 @@ class EPPMBatch:
             check(lib().eppm_compute_begin(self._ctx), "eppm_compute_begin")
         else:
             u, v = self._outs(out)
+            self._pending_out = (u, v)      # the copy engine writes these planes until compute_flow_end: keep them alive
             check(lib().eppm_batch_compute_begin_into(self._ctx, self._ptrs(u), self._ptrs(v)), "eppm_batch_compute_begin_into")
 
     def compute_flow_end(self, out=None):
         u, v = self._outs(out)
         check(lib().eppm_batch_compute_end(self._ctx, self._ptrs(u), self._ptrs(v)), "eppm_batch_compute_end")
+        self._pending_out = None
         return list(zip(u, v))
 
     def synchronize(self):

@@ -15,7 +15,7 @@ def lib_path(variant=None):
 
 
 def _stale():
-    outs = [lib_path(""), lib_path("approx")]
+    outs = [lib_path("")]
     if not all(os.path.exists(o) for o in outs):
         return True
     t = min(os.path.getmtime(o) for o in outs)
@@ -25,8 +25,11 @@ def _stale():
     return any(os.path.getmtime(s) > t for s in srcs if os.path.isfile(s))
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP kernel + the C ABI into eppm_amd/lib/libeppm_hip.so, the opt-in libeppm_hip_approx.so and the runeppm CLI."""
+def build(force=False, verbose=False, approx=False):
+    """Compile every HIP kernel + the C ABI into eppm_amd/lib/libeppm_hip.so and the runeppm CLI; approx=True also builds the opt-in
+    libeppm_hip_approx.so (`make approx`: v_exp_f32 arithmetic, not bit-identical, never part of the default build)."""
+    if approx:
+        subprocess.check_call(["make", "-C", _CSRC, "-j", str(min(8, os.cpu_count() or 1)), "approx"], stdout=None if verbose else subprocess.DEVNULL)
     if not force and not _stale():
         return lib_path("")
     if not os.path.exists("/opt/rocm/bin/hipcc"):

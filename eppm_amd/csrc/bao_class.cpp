@@ -16,8 +16,9 @@ namespace {
 struct SeenBlock { const void* table; const void* base; size_t bytes; bool pinned; };
 struct ClassPriv {
     SeenBlock blk[8];
-    int n = 0, next = 0;
+    int n = 0, next = 0, evictions = 0;
     bool pin = false;
+    bool verify_always = false;     // set_option("verify_tables_every_call", 1): no table is trusted from an earlier call
 };
 void release_block(SeenBlock& b)
 {
@@ -31,9 +32,11 @@ bool seen(ClassPriv* pr, const void* table, const void* base, size_t bytes, bool
         if (pr->blk[i].table == table && pr->blk[i].base == base && pr->blk[i].bytes == bytes) return true;
     if (!add) return false;
     int slot = pr->n < 8 ? pr->n++ : (pr->next++ & 7);
-    if (pr->blk[slot].base) release_block(pr->blk[slot]);
+    if (pr->blk[slot].base) { release_block(pr->blk[slot]); pr->evictions++; }
     pr->blk[slot] = SeenBlock{table, base, bytes, false};
-    if (pr->pin && eppm_host_register((void*)base, bytes) == EPPM_OK) pr->blk[slot].pinned = true;
+    // a caller that cycles through more blocks than the ring holds would pin and unpin one per call (each costs as much as several
+    // staged copies): after 16 evictions new blocks are no longer pinned and go through the context's staging buffers
+    if (pr->pin && pr->evictions < 16 && eppm_host_register((void*)base, bytes) == EPPM_OK) pr->blk[slot].pinned = true;
     return false;
 }
 }  // namespace
@@ -67,6 +70,7 @@ bool bao_flow_patchmatch_multiscale_cuda::set_option(const char* name, long long
     else if (!strcmp(name, "propagation")) p->propagation = (int)value;
     else if (!strcmp(name, "levels")) p->levels = (int)value;
     else if (!strcmp(name, "pin_caller_buffers")) ((ClassPriv*)m_priv)->pin = (value != 0);
+    else if (!strcmp(name, "verify_tables_every_call")) ((ClassPriv*)m_priv)->verify_always = (value != 0);
     else return false;
     return true;
 }
@@ -77,7 +81,7 @@ void bao_flow_patchmatch_multiscale_cuda::_destroy()
     m_ctx = NULL;
     ClassPriv* pr = (ClassPriv*)m_priv;
     for (int i = 0; i < pr->n; i++) release_block(pr->blk[i]);
-    pr->n = pr->next = 0;
+    pr->n = pr->next = pr->evictions = 0;
     free(m_stage); free(m_u); free(m_v);
     m_stage = NULL; m_u = NULL; m_v = NULL;
 }
@@ -111,7 +115,10 @@ static const unsigned char* contiguous_rgb(void* priv, unsigned char*** img, int
     const size_t row = (size_t)w * 3;
     for (int i = 0; i < h; i++)
         if (img[i][0] != base + (size_t)i * row || img[i][w - 1] != base + (size_t)i * row + (size_t)3 * (w - 1)) return NULL;
-    if (seen(pr, img, base, row * h, false)) return base;
+    // A table verified once is trusted afterwards for as long as (table, base, size) and both ends of every row stay the same: the
+    // caller must not rewrite the INTERIOR pixel pointers of a table it has passed before (bao_alloc never does).  A caller that
+    // does sets "verify_tables_every_call" and pays the full walk (h*w pointer reads) per call.
+    if (!pr->verify_always && seen(pr, img, base, row * h, false)) return base;
     for (int i = 0; i < h; i++) {
         unsigned char** r = img[i];
         const unsigned char* b = base + (size_t)i * row;

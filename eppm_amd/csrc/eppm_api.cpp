@@ -12,6 +12,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
@@ -114,38 +116,85 @@ static int pyr_init_dim(int* arrH, int* arrW, int h, int w, int maxDepth, double
 // legs, driver :159-168, :299-306, read and write the caller's memory too)
 // ---------------------------------------------------------------------------------------------------
 namespace {
-struct HostBlock { size_t bytes; bool owned; };
+// refs: eppm_host_register calls outstanding on the block (several owners may register the same block -- runeppm --gpus N --pin
+// shares its images between the workers' objects -- and it is unpinned when the LAST of them unregisters); users: DMA transfers of
+// contexts in flight on it (held from the look-up that decides "read / write in place" until the transfer has completed: a look-up
+// and its hipMemcpyAsync are one critical step with respect to unregistration).
+struct HostBlock { size_t bytes; bool owned; int refs; int users; };
 std::mutex g_reg_mu;
+std::condition_variable g_reg_cv;
 std::map<uintptr_t, HostBlock> g_reg;
+std::multimap<uintptr_t, uintptr_t> g_reg_alias;       // pointer registered INSIDE an existing block -> that block's base
+std::map<uintptr_t, HostBlock>::iterator covering(const void* p, size_t bytes)          // g_reg_mu held
+{
+    auto it = g_reg.upper_bound((uintptr_t)p);
+    if (it == g_reg.begin()) return g_reg.end();
+    --it;
+    return ((uintptr_t)p + bytes <= it->first + it->second.bytes) ? it : g_reg.end();
+}
 bool host_registered(const void* p, size_t bytes)
 {
     if (!p) return false;
     std::lock_guard<std::mutex> lk(g_reg_mu);
-    auto it = g_reg.upper_bound((uintptr_t)p);
-    if (it == g_reg.begin()) return false;
-    --it;
-    return (uintptr_t)p + bytes <= it->first + it->second.bytes;
+    return covering(p, bytes) != g_reg.end();
 }
+// the block covering [p, p + bytes) marked in use (0 when there is none): the caller DMAs from / into it, then host_release(base)
+uintptr_t host_acquire(const void* p, size_t bytes)
+{
+    if (!p) return 0;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = covering(p, bytes);
+    if (it == g_reg.end()) return 0;
+    it->second.users++;
+    return it->first;
+}
+void host_release(uintptr_t base)
+{
+    if (!base) return;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_reg.find(base);
+    if (it != g_reg.end() && it->second.users > 0 && --it->second.users == 0) g_reg_cv.notify_all();
+}
+struct HostHold {                       // releases what a call acquired, on every return path
+    std::vector<uintptr_t> v;
+    bool add(const void* p, size_t bytes) { const uintptr_t b = host_acquire(p, bytes); if (b) v.push_back(b); return b != 0; }
+    void release() { for (uintptr_t b : v) host_release(b); v.clear(); }
+    ~HostHold() { release(); }
+};
 }  // namespace
 
 extern "C" int eppm_host_register(void* p, size_t bytes)
 {
     if (!p || !bytes) return set_err(EPPM_ERR_ARG, "eppm_host_register: NULL or empty block");
-    if (host_registered(p, bytes)) return EPPM_OK;
+    std::lock_guard<std::mutex> lk(g_reg_mu);          // held across the check and hipHostRegister: two threads registering one block
+    auto it = covering(p, bytes);
+    if (it != g_reg.end()) {
+        it->second.refs++;
+        if (it->first != (uintptr_t)p) g_reg_alias.emplace((uintptr_t)p, it->first);
+        return EPPM_OK;
+    }
     HIPCHK(hipHostRegister(p, bytes, hipHostRegisterPortable));
-    std::lock_guard<std::mutex> lk(g_reg_mu);
-    g_reg[(uintptr_t)p] = HostBlock{bytes, false};
+    g_reg[(uintptr_t)p] = HostBlock{bytes, false, 1, 0};
     return EPPM_OK;
 }
 extern "C" int eppm_host_unregister(void* p)
 {
-    {
-        std::lock_guard<std::mutex> lk(g_reg_mu);
-        auto it = g_reg.find((uintptr_t)p);
-        if (it == g_reg.end() || it->second.owned) return set_err(EPPM_ERR_ARG, "eppm_host_unregister: not a block registered with eppm_host_register");
-        g_reg.erase(it);
-    }
-    HIPCHK(hipHostUnregister(p));
+    std::unique_lock<std::mutex> lk(g_reg_mu);
+    uintptr_t base = (uintptr_t)p;
+    auto al = g_reg_alias.find(base);
+    auto it = g_reg.find(base);
+    if (al != g_reg_alias.end()) { it = g_reg.find(al->second); g_reg_alias.erase(al); }
+    if (it == g_reg.end() || it->second.owned) return set_err(EPPM_ERR_ARG, "eppm_host_unregister: not a block registered with eppm_host_register");
+    if (--it->second.refs > 0) return EPPM_OK;          // another owner still holds the registration
+    // last owner: wait for the transfers in flight on the block (a context of another thread between its look-up and the end of its
+    // copy); bounded, so that unregistering under one's own pending eppm_compute_begin_into is an error and not a deadlock
+    base = it->first;
+    const bool idle = g_reg_cv.wait_for(lk, std::chrono::seconds(5), [&] { auto q = g_reg.find(base); return q == g_reg.end() || q->second.users == 0; });
+    it = g_reg.find(base);
+    if (it == g_reg.end()) return EPPM_OK;
+    if (!idle) { it->second.refs = 1; return set_err(EPPM_ERR_STATE, "eppm_host_unregister: a transfer is still in flight on the block (eppm_compute_end pending?)"); }
+    g_reg.erase(it);
+    HIPCHK(hipHostUnregister((void*)base));
     return EPPM_OK;
 }
 extern "C" int eppm_host_is_registered(const void* p, size_t bytes) { return host_registered(p, bytes) ? 1 : 0; }
@@ -154,17 +203,19 @@ extern "C" int eppm_host_alloc(void** p, size_t bytes)
     if (!p || !bytes) return set_err(EPPM_ERR_ARG, "eppm_host_alloc: NULL or empty block");
     HIPCHK(hipHostMalloc(p, bytes, hipHostMallocPortable));
     std::lock_guard<std::mutex> lk(g_reg_mu);
-    g_reg[(uintptr_t)*p] = HostBlock{bytes, true};
+    g_reg[(uintptr_t)*p] = HostBlock{bytes, true, 1, 0};
     return EPPM_OK;
 }
 extern "C" int eppm_host_free(void* p)
 {
     if (!p) return EPPM_OK;
     {
-        std::lock_guard<std::mutex> lk(g_reg_mu);
+        std::unique_lock<std::mutex> lk(g_reg_mu);
         auto it = g_reg.find((uintptr_t)p);
         if (it == g_reg.end() || !it->second.owned) return set_err(EPPM_ERR_ARG, "eppm_host_free: not a block from eppm_host_alloc");
-        g_reg.erase(it);
+        if (!g_reg_cv.wait_for(lk, std::chrono::seconds(5), [&] { auto q = g_reg.find((uintptr_t)p); return q == g_reg.end() || q->second.users == 0; }))
+            return set_err(EPPM_ERR_STATE, "eppm_host_free: a transfer is still in flight on the block (eppm_compute_end pending?)");
+        g_reg.erase((uintptr_t)p);
     }
     HIPCHK(hipHostFree(p));
     return EPPM_OK;
@@ -299,6 +350,7 @@ struct eppm_ctx {
     int rgb_cur = 0;
     float* h_flow = nullptr;            // npairs x (u plane | v plane)
     std::vector<float*> out_u, out_v;   // per active pair: where eppm_compute_begin_into sent the planes directly (NULL: staging)
+    HostHold out_hold;                  // the registered blocks those planes lie in, in use until eppm_compute_end
     bool have_images = false, have_flow = false;
     int timing = 0;                     // 0 off, 1 every stage, 2 only the dominant kernel (the candidate refine)
     std::vector<StageEv> ev;
@@ -354,6 +406,7 @@ extern "C" int eppm_destroy(eppm_ctx* c)
     if (!c) return EPPM_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->out_hold.release();
     clear_events(c, c->ev);
     clear_events(c, c->ev_prep);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -560,7 +613,7 @@ static int prepare(eppm_ctx* c)
 // host RGB of pairs 0..n-1 -> H2D -> RGBA planes (bao_rgb2rgba, alpha = 0) -> prepare.  An image inside memory registered with
 // eppm_host_register / eppm_host_alloc is read by the copy engine where it lies; any other image goes through the context's pinned
 // staging (one host copy), which is double-buffered.
-static int set_images_host(eppm_ctx* c, int n, const uint8_t* const* rgb1, const uint8_t* const* rgb2, size_t row_stride)
+static int set_images_host_impl(eppm_ctx* c, int n, const uint8_t* const* rgb1, const uint8_t* const* rgb2, size_t row_stride, HostHold& hold)
 {
     if (row_stride < (size_t)c->w * 3) return set_err(EPPM_ERR_ARG, "eppm_set_images: row_stride %zu < 3*w", row_stride);
     HIPCHK(hipSetDevice(c->device));
@@ -569,11 +622,12 @@ static int set_images_host(eppm_ctx* c, int n, const uint8_t* const* rgb1, const
         if (!rgb1[k] || !rgb2[k]) return set_err(EPPM_ERR_ARG, "eppm_set_images: NULL image");
     uint8_t* stage = nullptr;
     bool staged = false, direct = false;
+    // (`hold`: registered blocks read in place stay in use until their DMA has completed -- the end of the call)
     for (int k = 0; k < n; k++)
         for (int f = 0; f < 2; f++) {
             const uint8_t* src = f ? rgb2[k] : rgb1[k];
             uint8_t* dst = c->of_pair(c->d_rgb, k) + (size_t)f * img;
-            if (host_registered(src, span)) {
+            if (hold.add(src, span)) {
                 if (row_stride == row) HIPCHK(hipMemcpyAsync(dst, src, img, hipMemcpyHostToDevice, c->stream));
                 else HIPCHK(hipMemcpy2DAsync(dst, row, src, row_stride, row, c->h, hipMemcpyHostToDevice, c->stream));
                 direct = true;
@@ -612,6 +666,13 @@ static int set_images_host(eppm_ctx* c, int n, const uint8_t* const* rgb1, const
     // set_data's contract (a synchronous cudaMemcpy in the reference, driver :165-166): when the call returns the caller may reuse
     // its images.  Staged images were copied above; for images read in place, wait for their DMA (the kernels are queued already).
     if (direct) HIPCHK(hipEventSynchronize(c->ev_h2d));
+    return r;
+}
+static int set_images_host(eppm_ctx* c, int n, const uint8_t* const* rgb1, const uint8_t* const* rgb2, size_t row_stride)
+{
+    HostHold hold;
+    const int r = set_images_host_impl(c, n, rgb1, rgb2, row_stride, hold);
+    if (r != EPPM_OK && !hold.v.empty()) (void)hipStreamSynchronize(c->stream);     // nothing may still read the blocks when `hold` lets them go
     return r;
 }
 
@@ -822,7 +883,7 @@ static int compute_begin(eppm_ctx* c, int n_out, float* const* u, float* const* 
         float* du = (u && k < n_out) ? u[k] : nullptr;
         float* dv = (v && k < n_out) ? v[k] : nullptr;
         const float* src = c->of_pair(c->d_uv, k);
-        if (du && dv && host_registered(du, n * 4) && host_registered(dv, n * 4)) {
+        if (du && dv && host_registered(du, n * 4) && host_registered(dv, n * 4) && c->out_hold.add(du, n * 4) && c->out_hold.add(dv, n * 4)) {
             HIPCHK(hipMemcpyAsync(du, src, n * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipMemcpyAsync(dv, src + n, n * 4, hipMemcpyDeviceToHost, c->stream));
             c->out_u[k] = du; c->out_v[k] = dv;
@@ -858,7 +919,9 @@ static int compute_end(eppm_ctx* c, int n_out, float* const* u, float* const* v)
 {
     if (!c->flow_pending) return set_err(EPPM_ERR_STATE, "eppm_compute_end without eppm_compute_begin");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    const hipError_t es = hipStreamSynchronize(c->stream);
+    c->out_hold.release();              // the copy engine has left the caller's planes (or the stream is broken)
+    HIPCHK(es);
     c->flow_pending = false;
     const size_t n = (size_t)c->h * c->w;
     for (int k = 0; k < n_out && k < c->n_active; k++) {

@@ -82,7 +82,10 @@ int  eppm_set_images(eppm_ctx* ctx, const uint8_t* rgb1, const uint8_t* rgb2, si
  * identical results.  Register the buffers a program reuses from pair to pair once (hipHostRegister underneath: the cost of a
  * registration is that of pinning the pages, paid once); eppm_host_alloc returns pinned memory that counts as registered.
  * eppm_set_images returns when the images have been read (set_data is a synchronous cudaMemcpy in the reference,
- * driver .cpp:165-166); a block must stay registered until the calls using it have returned. */
+ * driver .cpp:165-166).  Registrations are counted: registering a block (or a range inside a registered block) again adds an owner,
+ * eppm_host_unregister removes one, and the pages are unpinned when the last owner unregisters -- after the transfers other contexts
+ * have in flight on the block completed (an unregister under one's own pending eppm_compute_begin_into fails with EPPM_ERR_STATE
+ * after a bounded wait instead of deadlocking).  Thread-safe. */
 int  eppm_host_register(void* p, size_t bytes);
 int  eppm_host_unregister(void* p);
 int  eppm_host_is_registered(const void* p, size_t bytes);   /* 1 / 0 */
@@ -123,7 +126,9 @@ int  eppm_batch_get_plane(eppm_ctx* ctx, int pair, const char* name, int level, 
 int  eppm_compute(eppm_ctx* ctx, float* u, float* v);
 /* The same in two halves, for a host thread that keeps several contexts in flight (PCIe copies of one pair overlap
  * the kernels of another): begin enqueues the path and the device-to-host copy and returns at once; end waits for
- * this context's stream and writes u, v.  eppm_set_images on a context waits for that context's previous work. */
+ * this context's stream and writes u, v.  eppm_set_images on a context does NOT drain its stream: the staging buffers are
+ * double-buffered with an event each, images in registered memory are read by DMA and the call returns once that DMA is done; u, v
+ * handed to eppm_compute_begin_into must stay allocated until eppm_compute_end has returned. */
 int  eppm_compute_begin(eppm_ctx* ctx);
 int  eppm_compute_end(eppm_ctx* ctx, float* u, float* v);
 /* eppm_compute_begin with the destination named up front: planes in registered memory (eppm_host_register) are written by the

@@ -40,7 +40,7 @@ def main():
     w, h = (int(pos[0]), int(pos[1])) if len(pos) >= 2 else (1024, 436)
     B, K = opt("--batch", 8), opt("--inflight", 3)
     NP = 12
-    plain = [synth.make_pair(h, w, seed=1234 + i)[:2] for i in range(NP)]
+    plain = [p[:2] for p in synth.make_pairs_parallel([(h, w, 1234 + i, 20.0) for i in range(NP)])]
     pinned = []
     for a, b in plain:                                   # the same pairs in registered memory
         pa, pb = eppm_amd.pinned_empty((h, w, 3)), eppm_amd.pinned_empty((h, w, 3))

@@ -86,7 +86,7 @@ static bool apply_opt(eppm_params& p, const std::string& name, long long v)
     else if (name == "seed") p.seed = (unsigned long long)v;
     else if (name == "propagation") p.propagation = (int)v;
     else if (name == "levels") p.levels = (int)v;
-    else if (name == "pin_caller_buffers") return true;      // an option of the class, not of eppm_params
+    else if (name == "pin_caller_buffers" || name == "verify_tables_every_call") return true;      // options of the class, not of eppm_params
     else return false;
     return true;
 }
@@ -173,14 +173,17 @@ int main(int argc, char** argv)
         std::vector<double> t_begin(o.gpus, 0.0), t_end(o.gpus, 0.0);
         const auto epoch = std::chrono::steady_clock::now();
         auto now = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - epoch).count(); };
+        int ndev = 1;
+        if (eppm_device_count(&ndev) != EPPM_OK || ndev < 1) ndev = 1;
         for (int g = 0; g < o.gpus; g++)
             workers.emplace_back([&, g]() {
+                const int dev = g % ndev;          // more workers than devices: they share (one context each; all read the same pinned images)
                 if (o.batch > 1) {       // batch context through the C ABI: B pairs per launch sequence
                     eppm_params prm;
                     eppm_default_params(&prm);
                     for (auto& kv : o.opts) apply_opt(prm, kv.first, kv.second);
                     eppm_ctx* c = nullptr;
-                    if (eppm_create_batch(&c, h, w, g, &prm, o.batch) != EPPM_OK) { failed[g] = 1; ready++; return; }
+                    if (eppm_create_batch(&c, h, w, dev, &prm, o.batch) != EPPM_OK) { failed[g] = 1; ready++; return; }
                     std::vector<std::vector<float>> bu(o.batch, std::vector<float>((size_t)h * w)), bv(o.batch, std::vector<float>((size_t)h * w));
                     std::vector<const uint8_t*> a1(o.batch, img1.store.data()), a2(o.batch, img2.store.data());
                     std::vector<float*> pu(o.batch), pv(o.batch);
@@ -205,7 +208,7 @@ int main(int argc, char** argv)
                     return;
                 }
                 bao_flow_patchmatch_multiscale_cuda e;
-                e.set_device(g);
+                e.set_device(dev);
                 for (auto& kv : o.opts) e.set_option(kv.first.c_str(), kv.second);
                 e.init(h, w);
                 if (!e.handle()) { failed[g] = 1; ready++; return; }

@@ -1,4 +1,4 @@
-"""Copies the outputs of tools/gpu_round_end.sh (gpurun_out/<tag>/) into profiles/<tag>_* as per-kernel summaries and writes
+"""Copies the outputs of tools/gpu.sh round (gpurun_out/<tag>/) into profiles/<tag>_* as per-kernel summaries and writes
 profiles/pmc_constants.json: PMC-derived constants per shape -- the dominant kernel (the candidate refine) per launch size and the
 whole path per kernel group -- each valid only for the device sources it was measured on (sha256 inside; bench.py emits null
 when they have changed since).  Usage: store_profiles.py r03_x"""
@@ -9,7 +9,7 @@ src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 for f in glob.glob(f"{dst}/{tag}_*"):
     os.remove(f)
-for name in ("bench_default.json", "bench_streams3.json", "bench_hd.json", "bench_4k_r17.json", "bench_under_rocprof.json", "bench_torchrun_2ranks_1gpu.json", "gpu_tests.txt"):
+for name in ("bench_default.json", "bench_like_driver.json", "bench_streams3.json", "bench_under_rocprof.json", "bench_torchrun_2ranks_1gpu.json", "gpu_tests.txt"):
     if os.path.exists(f"{src}/{name}") and os.path.getsize(f"{src}/{name}") > 0:
         shutil.copy(f"{src}/{name}", f"{dst}/{tag}_{name}")
 for d in ("stats_default", "stats_single", "stats_batch8"):
@@ -67,7 +67,7 @@ for key, labels in (("1024x436_r9", (("single", 1), ("batch8", 8))), ("1920x1080
         g["kernel_us_per_pair"] += float(r["avg_us"]) * float(r["calls"]) / np_
     for g in by.values():
         g["valu_issue_frac_under_pmc"] = g["valu_insts_per_pair"] / (g["kernel_us_per_pair"] * 1e-6) / VALU_PEAK if g["kernel_us_per_pair"] else None
-    shapes[key] = {"source": f"profiles/{tag}_pmc_*.csv (tools/gpu_round_end.sh, tools/store_profiles.py)", "kernel_sources": all_srcs, "sources_sha256": sha_all,
+    shapes[key] = {"source": f"profiles/{tag}_pmc_*.csv (tools/gpu.sh round, tools/store_profiles.py)", "kernel_sources": all_srcs, "sources_sha256": sha_all,
                    "dominant": dominant,
                    "path": {"pairs_per_launch": nb, "valu_insts_per_pair": sum(g["valu_insts_per_pair"] for g in by.values()),
                             "kernel_us_per_pair_one_context": sum(g["kernel_us_per_pair"] for g in by.values()), "by_kernel_group": by}}

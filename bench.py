@@ -63,6 +63,9 @@ def parse_args(known_only=False):
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--patch-r", type=int, default=9)
+    ap.add_argument("--propagation", type=int, default=0, choices=[0, 1, 2],
+                    help="0: the reference's live segmented sweeps (baoSegPropagate; the parity default); 1: jump flood (baoJumpPropagate, disabled in the "
+                         "reference); 2: 4-neighbour propagation (10 x baoParallelPropagate, disabled).  Information only: 1 and 2 compute other flows")
     ap.add_argument("--inflight", type=int, default=3,
                     help="pairs in flight per GPU: steps are issued round robin over this many contexts, each on its own HIP stream")
     ap.add_argument("--batch", type=int, default=8,
@@ -185,7 +188,7 @@ def worker(args):
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the HIP runtime starts: RCCL needs dmabuf IPC on this pool
     verify3 = (world > 1) if args.verify_config3 is None else bool(args.verify_config3)
-    other_cfgs = world == 1 and not args.no_extras and not args.no_other_configs and (args.width, args.height, args.patch_r) == (W, H, 9)
+    other_cfgs = world == 1 and not args.no_extras and not args.no_other_configs and (args.width, args.height, args.patch_r, args.propagation) == (W, H, 9, 0)
     S = max(1, args.inflight)
     NB = max(1, args.batch)
     NC3 = 0 if args.no_extras else args.pairs_per_gpu        # pairs of the config-3 leg
@@ -222,7 +225,7 @@ def worker(args):
     import eppm_amd
     from eppm_amd import synth
     w, h = args.width, args.height
-    params = eppm_amd.Params(patch_r=args.patch_r)
+    params = eppm_amd.Params(patch_r=args.patch_r, propagation=args.propagation)
     engs = []
     for _ in range(S):
         e = eppm_amd.EPPM(device=local_rank, params=params)
@@ -415,6 +418,8 @@ def worker(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "repeats": len(dts), "value_min": vals[0], "value_max": vals[-1], "ms_per_step_by_repeat": [d / args.steps * 1e3 for d in dts],
             "config": {"workload": f"single {w}x{h} Sintel-shape synthetic pair per step, full 3-level pyramid, patch_r={args.patch_r}, "
+                                   + ("" if args.propagation == 0 else f"PROPAGATION MODE {args.propagation} (not the reference's live scheme: other flows), ") +
+                                   
                                    f"default defs.h parameters; {world} rank(s), independent pairs; inputs: RGBA planes resident in HBM before the "
                                    "timed region; outputs: interleaved float2 flow left in HBM (the PCIe-inclusive window of the reference API -- host "
                                    "RGB in, host u/v out -- is `host_boundary`)",
@@ -502,7 +507,7 @@ class InputPlan:
             self.large = json.load(open(os.path.join(ROOT, "tests", "golden", "MANIFEST_large.json")))
         except Exception as e:
             self.why_unverifiable = f"no golden manifest: {e}"
-        if self.man3 and (args.width, args.height, args.patch_r) != (self.man3["w"], self.man3["h"], 9):
+        if self.man3 and (args.width, args.height, args.patch_r, args.propagation) != (self.man3["w"], self.man3["h"], 9, 0):
             self.man3, self.why_unverifiable = None, "the committed oracle hashes are for 1024x436 at patch_r 9, default parameters"
         n64 = self.man3["n_pairs"] if self.man3 else 64
         self.seed0 = self.man3["seed0"] if self.man3 else 1234

@@ -314,6 +314,8 @@ struct eppm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t stream_pm = nullptr;    // experiment (EPPM_PM_LANE): the quarter-resolution stages on a stream of their own (priority / CU mask)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     eppm_params prm;
     int h = 0, w = 0, nl = 0;
     int npairs = 1, n_active = 1;
@@ -331,6 +333,7 @@ struct eppm_ctx {
     float *cost1 = nullptr, *cost2 = nullptr;
     float *spec1 = nullptr, *spec2 = nullptr;   // evaluation cache of the sweeps (PmProblem::spec / scand): four direction planes each
     int32_t *scand1 = nullptr, *scand2 = nullptr;
+    uint32_t *wl1 = nullptr, *wl2 = nullptr;    // work lists of the speculative sweeps (PmProblem::wl)
     uint32_t* wmf_ws = nullptr;        // work lists + counters of the weighted median
     bool flow_pending = false;         // eppm_compute_begin issued, eppm_compute_end not yet
     float *flow[kMaxLevels] = {}, *flow_tmp[kMaxLevels] = {};
@@ -420,6 +423,9 @@ extern "C" int eppm_destroy(eppm_ctx* c)
     if (c->ev_h2d) (void)hipEventDestroy(c->ev_h2d);
     if (c->h_flow) (void)hipHostFree(c->h_flow);
     rng_free(c->rng);
+    if (c->stream_pm) { (void)hipStreamSynchronize(c->stream_pm); (void)hipStreamDestroy(c->stream_pm); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return EPPM_OK;
@@ -477,6 +483,8 @@ static int ctx_alloc(eppm_ctx* c)
     plane((void**)&c->spec2, n2 * 4 * 4);
     plane((void**)&c->scand1, n2 * 4 * 4);
     plane((void**)&c->scand2, n2 * 4 * 4);
+    plane((void**)&c->wl1, pm_worklist_words(c->W[L], c->H[L], c->prm.seg_len) * 4);
+    plane((void**)&c->wl2, pm_worklist_words(c->W[L], c->H[L], c->prm.seg_len) * 4);
     plane((void**)&c->wmf_ws, wmf_workspace_words(c->W[L], c->H[L], c->prm.wmf_iters) * 4);
     plane((void**)&c->d_rgb, (size_t)h * w * 3 * 2);
     plane((void**)&c->d_color, (size_t)h * w * 4);
@@ -519,9 +527,41 @@ extern "C" int eppm_create_batch(eppm_ctx** out, int h, int w, int device, const
         delete c;
         return set_err(EPPM_ERR_ARG, "eppm_create: unsupported size %dx%d", w, h);
     }
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e = hipSuccess;
+    {
+        // EPPM_MAIN_MASK=K: the context's stream runs on all CUs but the first K of every XCD (bit i of a CU mask = CU i / 8 of XCD i % 8)
+        const char* mm = getenv("EPPM_MAIN_MASK");
+        const int km = mm ? atoi(mm) : 0;
+        if (km > 0 && km < 32) {
+            uint32_t mask[8];
+            for (int i = 0; i < 256; i++) { if (i % 32 == 0) mask[i / 32] = 0; if (i / 8 >= km) mask[i / 32] |= 1u << (i % 32); }
+            e = hipExtStreamCreateWithCUMask(&c->stream, 8, mask);
+        } else {
+            e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        }
+    }
     if (e != hipSuccess) { delete c; return set_err(EPPM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->own_stream = true;
+    if (const char* lane = getenv("EPPM_PM_LANE")) {
+        hipError_t e2 = hipSuccess;
+        if (!strncmp(lane, "prio", 4)) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            e2 = hipStreamCreateWithPriority(&c->stream_pm, hipStreamNonBlocking, hi);
+        } else if (!strncmp(lane, "mask:", 5)) {
+            const int k = atoi(lane + 5);
+            uint32_t mask[8];
+            for (int i = 0; i < 256; i++) { if (i % 32 == 0) mask[i / 32] = 0; if (i / 8 < k) mask[i / 32] |= 1u << (i % 32); }
+            e2 = hipExtStreamCreateWithCUMask(&c->stream_pm, 8, mask);
+        } else if (!strncmp(lane, "plain", 5)) {
+            e2 = hipStreamCreateWithFlags(&c->stream_pm, hipStreamNonBlocking);
+        }
+        if (e2 != hipSuccess) { eppm_destroy(c); return set_err(EPPM_ERR_HIP, "EPPM_PM_LANE stream: %s", hipGetErrorString(e2)); }
+        if (c->stream_pm) {
+            (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+        }
+    }
     int r = ctx_alloc(c);
     if (r != EPPM_OK) { eppm_destroy(c); return r; }
     *out = c;
@@ -719,10 +759,10 @@ extern "C" int eppm_batch_set_images_device(eppm_ctx* c, int n, const void* cons
 
 // ---- baoCudaPatchMatch (kernel.cu:1760-1826) for one problem or for the forward+backward pair at once ----
 static PmProblem mk_problem(const PlanesH& P, float* cost, int16_t* nnf, int16_t* nnf_alt, eppm_pm_rng* rng, int k, float* spec = nullptr,
-                            int32_t* scand = nullptr)
+                            int32_t* scand = nullptr, uint32_t* wl = nullptr)
 {
     PmProblem p;
-    p.P = P; p.cost = cost; p.nnf = nnf; p.nnf_alt = nnf_alt; p.spec = spec; p.scand = scand;
+    p.P = P; p.cost = cost; p.nnf = nnf; p.nnf_alt = nnf_alt; p.spec = spec; p.scand = scand; p.wl = wl;
     p.rng_work = rng ? rng->work[k][rng->cur[k]] : nullptr;
     p.rng_work_next = rng ? rng->work[k][rng->cur[k] ^ 1] : nullptr;
     return p;
@@ -743,7 +783,11 @@ static void search(PmBatch& b, eppm_pm_rng* rng, const float* lut, const eppm_pa
 #ifndef EPPM_SPEC_FROM_ITER
 #define EPPM_SPEC_FROM_ITER 2
 #endif
-static std::atomic<int> g_sweep_spec{-1};      // test support ("sweep_spec"): -1 by iteration, 0 never, 1 always
+static std::atomic<int> g_sweep_spec{-1};      // test support ("sweep_spec"): -1 by iteration, 0 never, 1 always, 2 always and without the work list
+#ifndef EPPM_SWEEP_LIST
+#define EPPM_SWEEP_LIST 1          // work list of the speculative sweeps: phase B walks only the chains phase A found an accepted candidate on
+#endif
+static bool sweep_list_on() { return EPPM_SWEEP_LIST && g_sweep_spec.load() != 2; }
 // A launch over one 1024x436 pair (two problems of 28 k pixels) is too small for the two-launch form to pay: phase A's evaluations
 // are one wave per SIMD, and the classic kernel at 32 lanes per chain finishes in 27 us where phase A + phase B take 19 + 16.  From
 // about a hundred thousand pixels per launch on (two such pairs; one 1920x1080 or 3840x2160 pair) the speculative form wins.
@@ -781,6 +825,7 @@ static void neighbor(PmBatch& b, const float* lut, const eppm_params& prm, int l
 // returns with the NNF of problem k in b.p[k].nnf (an even number of sweeps: the caller's buffer)
 static void run_patchmatch(PmBatch& b, eppm_pm_rng* rng, const float* lut, const eppm_params& prm, hipStream_t s)
 {
+    b.sweep_seq = 0;
     launch_pm_init_field(b, rng->dev(), s);
     launch_pm_cost_field(b, lut, prm.patch_r, s);
     for (int it = 0; it < prm.num_iter; it++) {
@@ -802,15 +847,22 @@ static int compute_all(eppm_ctx* c)
     const int lw = c->W[L], lh = c->H[L];
 
     stage_begin(c, c->ev, "patchmatch");
+    hipStream_t s_main = s;
+    if (c->stream_pm) {
+        (void)hipEventRecord(c->ev_fork, s_main);
+        (void)hipStreamWaitEvent(c->stream_pm, c->ev_fork, 0);
+        s = c->stream_pm;
+    }
     {
         PmBatch b;
         b.n = 2; b.cpitch = lw; b.npitch = lw; b.npairs = bt.n; b.stride = bt.stride;
         b.cache_plane = (size_t)lw * lh;
+        b.wl_units = pm_worklist_units(lw, lh, c->prm.seg_len);
 #ifndef EPPM_SWEEP_CACHE
 #define EPPM_SWEEP_CACHE 1
 #endif
-        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0, c->spec1, EPPM_SWEEP_CACHE ? c->scand1 : nullptr);     // driver :223
-        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1, c->spec2, EPPM_SWEEP_CACHE ? c->scand2 : nullptr);     // driver :224
+        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0, c->spec1, EPPM_SWEEP_CACHE ? c->scand1 : nullptr, sweep_list_on() ? c->wl1 : nullptr);     // driver :223
+        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1, c->spec2, EPPM_SWEEP_CACHE ? c->scand2 : nullptr, sweep_list_on() ? c->wl2 : nullptr);     // driver :224
         run_patchmatch(b, c->rng, c->lut_pm, c->prm, s);
     }
     stage_end(c, c->ev);
@@ -826,6 +878,11 @@ static int compute_all(eppm_ctx* c)
     launch_fill_holes(c->nnf_tmp, c->nnf1, c->img1[L], (int)(c->ipitch[L] / 4), lw, lh, lw, s, bt);          // driver :240
     std::swap(c->nnf1, c->nnf_tmp);
     launch_nnf2flow(c->flow[L], lw, c->nnf1, lw, lw, lh, s, bt);                                             // driver :258
+    if (c->stream_pm) {
+        (void)hipEventRecord(c->ev_join, c->stream_pm);
+        (void)hipStreamWaitEvent(s_main, c->ev_join, 0);
+        s = s_main;
+    }
     stage_end(c, c->ev);
 
     static const char* up_names[] = {"upsample_L0", "upsample_L1", "upsample_L2", "upsample_L3", "upsample_L4", "upsample_L5", "upsample_L6"};
@@ -1050,8 +1107,8 @@ namespace {
 struct DevState {
     float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
     int lut_R = -1;
-    void* scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[5] = {0, 0, 0, 0, 0};
+    void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
     std::map<std::tuple<int, int, int, unsigned long long>, eppm_pm_rng*> rngs;
 };
 std::mutex g_mu;
@@ -1200,13 +1257,20 @@ extern "C" int eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const ep
     PlanesH P;
     CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
     void* spec = nullptr;
-    const bool speculative = g_sweep_spec.load() == 1;         // the stand-alone entry point has no iteration count: classic unless forced
+    const bool speculative = g_sweep_spec.load() >= 1;         // the stand-alone entry point has no iteration count: classic unless forced
     // the evaluation cache of the sweeps lives for ONE call here (the planes of the next call may be other images): emptied first
     const size_t plane_bytes = cost_pitch * h;
     CHK(get_scratch(ds, plane_bytes * 8, &spec, 4));
     HIPCHK(hipMemsetAsync((char*)spec + plane_bytes * 4, 0xff, plane_bytes * 4, g_stream));
     b.cache_plane = plane_bytes / 4;
-    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0, (float*)spec, (int32_t*)((char*)spec + plane_bytes * 4));
+    void* wl = nullptr;                                        // work list of the speculative form: lengths and stamps cleared per call
+    if (speculative && sweep_list_on()) {
+        b.wl_units = pm_worklist_units(w, h, g_prm.seg_len);
+        const size_t wl_bytes = pm_worklist_words(w, h, g_prm.seg_len) * 4;
+        CHK(get_scratch(ds, wl_bytes, &wl, 5));
+        HIPCHK(hipMemsetAsync(wl, 0, wl_bytes, g_stream));
+    }
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0, (float*)spec, (int32_t*)((char*)spec + plane_bytes * 4), (uint32_t*)wl);
     for (int d = 0; d < 4; d++)
         if (dir < 0 || dir == d) sweep(b, ds->lut_pm, g_prm, d, g_stream, speculative);
     if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
@@ -1377,7 +1441,11 @@ extern "C" void baoCudaPatchMatch(eppm_short2* d_disp_vec, float* d_cost, eppm_u
     g_launch_status = get_scratch(ds, plane_bytes * 8, &spec, 4);
     if (g_launch_status != EPPM_OK) return;
     b.cache_plane = plane_bytes / 4;          // (k_pm_init_field empties the cache)
-    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0, (float*)spec, (int32_t*)((char*)spec + plane_bytes * 4));
+    void* wl = nullptr;
+    b.wl_units = pm_worklist_units(w, h, g_prm.seg_len);
+    g_launch_status = get_scratch(ds, pm_worklist_words(w, h, g_prm.seg_len) * 4, &wl, 5);       // (k_pm_init_field clears it)
+    if (g_launch_status != EPPM_OK) return;
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0, (float*)spec, (int32_t*)((char*)spec + plane_bytes * 4), sweep_list_on() ? (uint32_t*)wl : nullptr);
     run_patchmatch(b, r, ds->lut_pm, g_prm, g_stream);
     if (b.p[0].nnf != (int16_t*)d_disp_vec && (g_launch_status = copy_d2d(d_disp_vec, b.p[0].nnf, disp_pitch * h)) != EPPM_OK) return;
     g_launch_status = finish();

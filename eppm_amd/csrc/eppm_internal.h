@@ -73,6 +73,12 @@ struct PmProblem {
     // phase A's hand-over plane to phase B (k_patchmatch.hip).  scand == NULL: no cache (every candidate is evaluated).
     float* spec = nullptr;
     int32_t* scand = nullptr;   // x | y << 16 of the cached candidate; -1 = empty (no candidate has both coordinates -1)
+    // Work list of the speculative sweeps (k_patchmatch.hip): phase A names the chains on which some candidate of the rejection path
+    // would be ACCEPTED -- every other chain leaves its pixels as they are, and phase B walks the listed chains only.  Layout:
+    // word 0, 1: list lengths of the even / odd sweeps of a run (ping-pong: a sweep's phase A clears the other one);
+    // [16, 16 + units): stamp per unit (two adjacent segments of a line) = 1 + number of the last sweep that listed it;
+    // [16 + units, 16 + 2 * units): the list.  NULL: phase B walks every chain.
+    uint32_t* wl = nullptr;
     uint32_t* rng_work;       // [nblocks][64][6] XORWOW lane states read by the random search
     uint32_t* rng_work_next;  // ... written by it (ping-pong: four workgroups read each block's state, one advances it)
 };
@@ -83,7 +89,12 @@ struct PmBatch {
     int npairs = 1;      // a launch covers n * npairs problems
     size_t stride = 0;
     size_t cache_plane = 0;   // elements per direction plane of PmProblem::spec / scand
+    int wl_units = 0;         // capacity of PmProblem::wl (pm_worklist_units)
+    int sweep_seq = 0;        // number of the next sweep of this PatchMatch run (0, 1, ..): launch_pm_sweep counts
 };
+// units (pairs of adjacent segments of a line) of the larger of the row and column sweeps; words of PmProblem::wl
+int pm_worklist_units(int w, int h, int seg_len);
+inline size_t pm_worklist_words(int w, int h, int seg_len) { return 16 + 2 * (size_t)pm_worklist_units(w, h, seg_len); }
 // RNG tables shared by both problems (same seed, same block ids: the reference re-initialises the states on
 // every baoCudaPatchMatch call, kernel.cu:160); see xorwow_host.cpp
 struct PmRngDev {
@@ -98,7 +109,7 @@ void launch_pm_init_field(const PmBatch& b, const PmRngDev& rng, hipStream_t s);
 void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t s);
 // one directional sweep; returns true when the result is in nnf_alt (caller swaps nnf/nnf_alt)
 // speculative: the two-launch form for iterations in which few candidates are accepted (k_patchmatch.hip, k_pm_sweep_spec); same results
-bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s, bool speculative = false);
+bool launch_pm_sweep(PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s, bool speculative = false);
 // one jump-flood launch (step = neighbour distance); reads nnf, writes nnf_alt (caller swaps)
 void launch_pm_jump(const PmBatch& b, const float* lut, int R, int step, hipStream_t s);
 // one 4-neighbour propagation launch (d_neighbor_propagate); reads nnf, writes nnf_alt (caller swaps)

@@ -44,6 +44,7 @@ __device__ __forceinline__ PmProblem pm_problem(const PmBatch& B, unsigned q)
     p.nnf_alt = pair_ptr_opt(p.nnf_alt, B.stride, pair);
     p.spec = pair_ptr_opt(p.spec, B.stride, pair);
     p.scand = pair_ptr_opt(p.scand, B.stride, pair);
+    p.wl = pair_ptr_opt(p.wl, B.stride, pair);
     p.rng_work = pair_ptr_opt(p.rng_work, B.stride, pair);
     p.rng_work_next = pair_ptr_opt(p.rng_work_next, B.stride, pair);
     return p;
@@ -93,6 +94,9 @@ __global__ __launch_bounds__(64) void k_pm_init_field(PmBatch B, PmRngDev rng)
     // search stream position = 512 draws in (states are re-initialised on every call, kernel.cu:160)
 #pragma unroll
     for (int k = 0; k < 6; k++) pr.rng_work[so + k] = rng.iter_tab[so + k];
+    // a new run: sweep numbers start at 0 again, so the work list's lengths and stamps do
+    if (pr.wl)
+        for (int wi = block_id * 64 + lane; wi < 16 + B.wl_units; wi += rng.gx * rng.gy * 64) pr.wl[wi] = 0u;
 }
 
 void launch_pm_init_field(const PmBatch& b, const PmRngDev& rng, hipStream_t s)
@@ -215,6 +219,9 @@ constexpr int kSpecMaxSteps = 16;
 template <int R, int LPC, bool IS_ROW, bool REVERSE, bool TILE, bool SPEC = false>
 __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, const float* __restrict__ lut, int L_, int nseg, int nseg_pad, int TW)
 {
+    // SPEC with a work list (pr.wl): the workgroup's CPB chains are CPB / 2 listed units (a unit = segments 2u, 2u + 1 of a line, so
+    // that segments 0 and 1 -- the two visitors of pixel L -- always sit in one workgroup); a workgroup past the end of the list
+    // returns at once.  Chains that are not listed keep their pixels: phase A has copied the whole field to the output plane.
     constexpr int S = R + 1, NS = S * S, CH = (NS + LPC - 1) / LPC, CPB = 256 / LPC;
     constexpr int SEGS = SweepTile<LPC>::SEGS, LINES = SweepTile<LPC>::LINES, TROWS = S + LINES - 1;
     static_assert(!(SPEC && TILE), "phase B evaluates rarely: it gathers its source samples");
@@ -252,7 +259,17 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
         line = chain / nseg_pad;
         seg = chain % nseg_pad;
     }
-    const bool active = (line < lines) && (seg < nseg);
+    bool listed = true;
+    if (SPEC && pr.wl) {
+        const uint32_t nlist = pr.wl[B.sweep_seq & 1];
+        if (bxx * (CPB / 2) >= nlist) return;                         // (uniform over the workgroup, before any barrier)
+        const unsigned slot = bxx * CPB + grp, upl = (unsigned)(nseg + 1) >> 1;
+        listed = (slot >> 1) < nlist;
+        const unsigned unit = listed ? pr.wl[16 + B.wl_units + (slot >> 1)] : 0u;
+        line = (int)(unit / upl);
+        seg = (int)(unit % upl) * 2 + (int)(slot & 1);
+    }
+    const bool active = listed && (line < lines) && (seg < nseg);
     int start, count, i, step;
     if (!REVERSE) {
         start = (seg == 0) ? 0 : seg * L_ - 1;
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
         px = nin[sidx * 2];
         py = nin[sidx * 2 + 1];
         // the one pixel of the line no chain visits keeps its value
-        const bool copier = REVERSE ? (seg == nseg - 1) : (seg == 0);
+        const bool copier = (REVERSE ? (seg == nseg - 1) : (seg == 0)) && !(SPEC && pr.wl);     // (work list: phase A copied every pixel)
         if (copier && r == 0) {
             const int u = REVERSE ? len - 1 : 0;
             const int uidx = IS_ROW ? (line * B.npitch + u) : (u * B.npitch + line);
@@ -448,8 +465,16 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
 //      rejection takes its cost from phase A's plane; only a step that follows an ACCEPTED candidate evaluates (cooperatively,
 //      as in the classic form).  In the converged iterations phase B is ten compare-and-select steps.
 // ---------------------------------------------------------------------------------------------------
+//
+// Work list (pr.wl): phase A also knows which chains can change anything.  A chain leaves the rejection path only where a
+// rejection-path candidate is ACCEPTED, i.e. where E(i, shift(nin[i-1])) < cost[i]; a chain without such a pixel rejects at every
+// step (by induction it never carries anything but stored matches) and writes back what it read.  So phase A copies the field to
+// the output plane, tests every visited pixel (evaluated now, taken from the cache, or skipped by the skip rule: never accepted)
+// and appends the UNIT of a pixel that would accept -- segments 2u and 2u + 1 of its line, so that segments 0 and 1, the two
+// visitors of pixel L, are always listed together -- to the list, once (a stamp per unit holds the number of the last sweep that
+// listed it).  Phase B walks the listed chains only: from the fifth iteration on that is one chain in ten.
 template <int RT, bool IS_ROW, bool REVERSE>
-__global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* __restrict__ lut, int R, int gx)
+__global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* __restrict__ lut, int R, int gx, int L_, int nseg)
 {
     using LUT = typename SearchLut<RT>::type;
     constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT;
@@ -471,14 +496,32 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
     const int qx = IS_ROW ? (REVERSE ? x + 1 : x - 1) : x, qy = IS_ROW ? y : (REVERSE ? y + 1 : y - 1);
     bool need = false;
     int cpack = 0;
-    if (x < P.w && y < P.h && qx >= 0 && qy >= 0 && qx < P.w && qy < P.h) {
-        const int qi = (qy * B.npitch + qx) * 2, ni = (y * B.npitch + x) * 2;
-        int cx = pr.nnf[qi], cy = pr.nnf[qi + 1];
-        if (IS_ROW) cx = REVERSE ? max(cx - 1, 0) : min(cx + 1, P.w - 1);
-        else        cy = REVERSE ? max(cy - 1, 0) : min(cy + 1, P.h - 1);
-        cpack = (cx & 0xffff) | (cy << 16);
-        need = !(cx == pr.nnf[ni] && cy == pr.nnf[ni + 1]);          // equal to the pixel's own match: rejected unevaluated
-        if (need && ccand && ccand[y * B.cpitch + x] == cpack) need = false;     // evaluated in an earlier sweep of this direction: the cost stands
+    uint32_t* __restrict__ wl = pr.wl;
+    const unsigned upl = (unsigned)(nseg + 1) >> 1, seq1 = (unsigned)B.sweep_seq + 1u;
+    // lists the unit of pixel (px, py) for this sweep, once
+    auto list_unit = [&](int px, int py) {
+        const int along = IS_ROW ? px : py, ln = IS_ROW ? py : px;
+        const unsigned seg = (!REVERSE && along < L_) ? 0u : (unsigned)(along / L_);
+        const unsigned unit = (unsigned)ln * upl + (seg >> 1);
+        if (atomicMax(&wl[16 + unit], seq1) < seq1) wl[16 + B.wl_units + atomicAdd(&wl[B.sweep_seq & 1], 1u)] = unit;
+    };
+    if (wl && blockIdx.x < nprob && tid == 0) wl[(B.sweep_seq + 1) & 1] = 0u;        // the next sweep's list length (the previous sweep is done with it)
+    if (x < P.w && y < P.h) {
+        const int ni = (y * B.npitch + x) * 2;
+        const int ox = pr.nnf[ni], oy = pr.nnf[ni + 1];
+        if (wl) { pr.nnf_alt[ni] = (int16_t)ox; pr.nnf_alt[ni + 1] = (int16_t)oy; }   // a pixel no listed chain visits keeps its match
+        if (qx >= 0 && qy >= 0 && qx < P.w && qy < P.h) {
+            const int qi = (qy * B.npitch + qx) * 2;
+            int cx = pr.nnf[qi], cy = pr.nnf[qi + 1];
+            if (IS_ROW) cx = REVERSE ? max(cx - 1, 0) : min(cx + 1, P.w - 1);
+            else        cy = REVERSE ? max(cy - 1, 0) : min(cy + 1, P.h - 1);
+            cpack = (cx & 0xffff) | (cy << 16);
+            need = !(cx == ox && cy == oy);                              // equal to the pixel's own match: rejected unevaluated
+            if (need && ccand && ccand[y * B.cpitch + x] == cpack) {     // evaluated in an earlier sweep of this direction: the cost stands
+                need = false;
+                if (wl && cval[y * B.cpitch + x] < pr.cost[y * B.cpitch + x]) list_unit(x, y);
+            }
+        }
     }
     // compaction: wave-level ballot + prefix, then the four wave counts: whole waves work or exit
     const unsigned long long bal = __ballot(need);
@@ -506,8 +549,10 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
     const int pix = (int)s_list[tid], e = s_cand[tid];
     const int tx = pix & 15, ty = pix >> 4;
     const int px = bxx * kBlock + tx, py = byy * kBlock + ty;
-    cval[py * B.cpitch + px] = search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16);
+    const float cv = search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16);
+    cval[py * B.cpitch + px] = cv;
     if (ccand) ccand[py * B.cpitch + px] = e;
+    if (wl && cv < pr.cost[py * B.cpitch + px]) list_unit(px, py);
 }
 
 // Fallback for patch radii without a cooperative instantiation: the reference's one-thread-per-chain form,
@@ -572,16 +617,21 @@ __global__ __launch_bounds__(1024) void k_pm_seg_propagate(PmBatch B, const floa
 
 // phase A of the speculative form for one direction
 template <int RT>
-static void launch_sweep_spec(const PmBatch& b, const float* lut, int R, int dir, hipStream_t s)
+static void launch_sweep_spec(const PmBatch& b, const float* lut, int R, int dir, int seg_len, int nseg, hipStream_t s)
 {
     const int w = b.p[0].P.w, h = b.p[0].P.h, gx = (w + kBlock - 1) / kBlock, gy = (h + kBlock - 1) / kBlock;
     dim3 grid(gx * gy * (b.n * b.npairs)), block(256);
     switch (dir) {
-        case 0: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, false>), grid, block, 0, s, b, lut, R, gx); break;
-        case 1: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, false>), grid, block, 0, s, b, lut, R, gx); break;
-        case 2: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, true>), grid, block, 0, s, b, lut, R, gx); break;
-        default: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, true>), grid, block, 0, s, b, lut, R, gx); break;
+        case 0: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, false>), grid, block, 0, s, b, lut, R, gx, seg_len, nseg); break;
+        case 1: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, false>), grid, block, 0, s, b, lut, R, gx, seg_len, nseg); break;
+        case 2: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, true>), grid, block, 0, s, b, lut, R, gx, seg_len, nseg); break;
+        default: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, true>), grid, block, 0, s, b, lut, R, gx, seg_len, nseg); break;
     }
+}
+int pm_worklist_units(int w, int h, int seg_len)
+{
+    const int ur = h * (((w + seg_len - 1) / seg_len + 1) / 2), uc = w * (((h + seg_len - 1) / seg_len + 1) / 2);
+    return ur > uc ? ur : uc;
 }
 // phase B
 template <int R, int LPC>
@@ -627,8 +677,9 @@ static void launch_sweep_r(const PmBatch& b, const float* lut, int seg_len, int 
     else launch_sweep_t<R, LPC, false>(b, lut, seg_len, dir, nseg, lines, s);
 }
 
-bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s, bool speculative)
+bool launch_pm_sweep(PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s, bool speculative)
 {
+    struct Count { PmBatch& b; ~Count() { b.sweep_seq++; } } count{b};      // every sweep of a run has its number (the work list's stamps)
     const PlanesH& P = b.p[0].P;
     const bool is_row = (dir == 0 || dir == 2);
     const int len = is_row ? P.w : P.h, lines = is_row ? P.h : P.w;
@@ -640,8 +691,8 @@ bool launch_pm_sweep(const PmBatch& b, const float* lut, int R, int seg_len, int
 #define EPPM_LPC17_SPEC 64    // ... at radius 17
 #endif
     if (speculative && b.p[0].spec && (R == 9 || R == 17) && seg_len <= kSpecMaxSteps) {
-        if (R == 9) { launch_sweep_spec<9>(b, lut, R, dir, s); launch_sweep_b<9, EPPM_LPC9_SPEC>(b, lut, seg_len, dir, nseg, lines, s); }
-        else { launch_sweep_spec<17>(b, lut, R, dir, s); launch_sweep_b<17, EPPM_LPC17_SPEC>(b, lut, seg_len, dir, nseg, lines, s); }
+        if (R == 9) { launch_sweep_spec<9>(b, lut, R, dir, seg_len, nseg, s); launch_sweep_b<9, EPPM_LPC9_SPEC>(b, lut, seg_len, dir, nseg, lines, s); }
+        else { launch_sweep_spec<17>(b, lut, R, dir, seg_len, nseg, s); launch_sweep_b<17, EPPM_LPC17_SPEC>(b, lut, seg_len, dir, nseg, lines, s); }
         return true;
     }
     if (R == 9) {

@@ -97,17 +97,22 @@ def test_patchmatch_substages(S, O, L1):
         for d in range(4):
             # both forms of the sweep on the same state: classic, and speculative (phase A + phase B; the context path uses it
             # from the fourth iteration on, here it also meets the first iterations' many accepted candidates)
-            try:
-                assert L.eppm_test_set_option(b"sweep_spec", 1) == 0
-                scost, snnf = S.pm_seg_propagate(cost, nnf, P, d)
-            finally:
-                L.eppm_test_set_option(b"sweep_spec", -1)
+            spec = {}
+            for mode in (1, 2):         # 1: phase B walks the chains phase A listed (work list); 2: phase B walks every chain
+                try:
+                    assert L.eppm_test_set_option(b"sweep_spec", mode) == 0
+                    spec[mode] = S.pm_seg_propagate(cost, nnf, P, d)
+                finally:
+                    L.eppm_test_set_option(b"sweep_spec", -1)
+            scost, snnf = spec[1]
             cost, nnf = S.pm_seg_propagate(cost, nnf, P, d)
             ocost, onnf = O.seg_propagate_dir(ocost, onnf, i1, i2, c1, c2, d)
             eq(nnf, onnf, f"NNF after propagate dir {d} iter {it}")
             eq(cost, ocost, f"cost after propagate dir {d} iter {it}")
             eq(snnf, onnf, f"NNF after speculative propagate dir {d} iter {it}")
             eq(scost, ocost, f"cost after speculative propagate dir {d} iter {it}")
+            eq(spec[2][1], onnf, f"NNF after speculative propagate without work list dir {d} iter {it}")
+            eq(spec[2][0], ocost, f"cost after speculative propagate without work list dir {d} iter {it}")
         cost, nnf = S.pm_random_search(rng, cost, nnf, P)
         ostates, ocost, onnf = O.random_search(ostates, ocost, onnf, i1, i2, c1, c2)
         eq(nnf, onnf, f"NNF after random search iter {it}")
@@ -413,7 +418,7 @@ def test_sweep_and_search_parameter_extremes(frames, params):
     eq(u, ou, f"u {params}"); eq(v, ov, f"v {params}")
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("params,region", [
     (dict(), (slice(40, 231), slice(100, 421))),
     (dict(seg_len=16, num_iter=5), (slice(40, 231), slice(100, 421))),        # the longest segments phase B takes (16 lanes per chain)
@@ -426,7 +431,8 @@ def test_sweep_and_search_parameter_extremes(frames, params):
 def test_speculative_sweeps_forced_on_and_off(frames, params, region, mode):
     """The speculative two-launch sweeps (phase A evaluates every pixel's rejection-path candidate in parallel, phase B walks
     the chains) against the classic dependent-step kernel: forced for EVERY iteration (mode 1: also the first ones, where most
-    steps follow an accepted candidate and phase B evaluates) and forced off (mode 0), both == the oracle bit for bit."""
+    steps follow an accepted candidate and phase B evaluates; with the work list -- phase B walks only the chains on which phase A
+    found a candidate that would be accepted -- and, mode 2, without it) and forced off (mode 0), all == the oracle bit for bit."""
     import eppm_amd
     a, b = frames
     L = eppm_amd.lib()

@@ -10,6 +10,7 @@
 #   abk         VARIANTS: per-kernel averages under rocprofv3 (BENCH_ARGS, FILTER=k_pm)
 #   pmc         PMC="counters.." in one pass of BENCH_ARGS -> gpurun_out/pmc_$TAG + per-kernel summary
 #   tcp         TA/TCP/TD counters per kernel (is a gather kernel L1 bound?)
+#   pmiter      every PatchMatch launch of one run in order, with durations (BENCH_ARGS)
 #   clock       shader clock and power under load                      inflight    throughput vs contexts in flight
 #   round       everything profiles/ of a round comes from (TAG=r04_x; PMC_ONLY=1, SKIP_TESTS=1)
 set -o pipefail
@@ -32,7 +33,7 @@ PY
 }
 case $MODE in
 test)
-  cd $R && timeout ${TEST_TIMEOUT:-3000} python -m pytest tests -m gpu ${PYTEST_ARGS:--x -q} 2>&1 | tail -${TAIL:-15} | tee $O/gpu_tests_latest.txt ;;
+  cd $R && timeout ${TEST_TIMEOUT:-3000} python -m pytest tests -m gpu ${PYTEST_ARGS:--x -q} ${K:+-k "$K"} 2>&1 | tail -${TAIL:-15} | tee $O/gpu_tests_latest.txt ;;
 bench)
   cd $R && python bench.py $BENCH_ARGS > $O/bench_latest.json 2> $O/bench_latest.err; tail -3 $O/bench_latest.err; cut -c1-400 $O/bench_latest.json ;;
 quick)
@@ -63,6 +64,11 @@ abk)
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$v -- python3 $R/bench.py --steps 16 --warmup 8 ${BENCH_ARGS:---batch 8 --inflight 1} --repeats 1 $QUIET > $O/ks_$v.log 2>&1
     echo "== $v"; kstats $O/ks_$v "${FILTER:-k_}"
   done ;;
+pmiter)
+  # every PatchMatch launch of one run in order (BENCH_ARGS: default 8 pairs per launch, one context)
+  prof_env; rm -rf $O/pmiter_$TAG
+  rocprofv3 --kernel-trace --output-format csv -d $O/pmiter_$TAG -- python3 $R/bench.py --steps 16 --warmup 8 ${BENCH_ARGS:---batch 8 --inflight 1} --repeats 1 $QUIET > $O/pmiter_$TAG.log 2>&1
+  python3 $R/tools/pm_by_iteration.py $O/pmiter_$TAG | tee $O/pmiter_$TAG.txt ;;
 pmc)
   prof_env; rm -rf $O/pmc_$TAG
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $O/pmc_$TAG -- python3 $R/bench.py ${BENCH_ARGS:---steps 16 --warmup 8 --batch 8 --inflight 1} --repeats 1 $QUIET > $O/pmc_$TAG.log 2>&1

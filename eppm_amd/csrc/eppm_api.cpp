@@ -461,10 +461,8 @@ static int ctx_alloc(eppm_ctx* c)
         plane((void**)&c->tmpu[i], c->ipitch[i] * c->H[i]);
         plane(&c->pk1[i], n * 16);
         plane(&c->pk2[i], n * 16);
-        if (i < c->nl - 1) {                    // refine levels
-            plane((void**)&c->pc1[i], n * 4);
-            plane((void**)&c->pc2[i], n * 4);
-        }
+        plane((void**)&c->pc1[i], n * 4);      // (the refine levels' window kernels and the PatchMatch level's random search)
+        plane((void**)&c->pc2[i], n * 4);
         plane((void**)&c->cen1[i], c->cpitch[i] * c->H[i]);
         plane((void**)&c->cen2[i], c->cpitch[i] * c->H[i]);
         plane((void**)&c->flow[i], n * 8);

@@ -39,6 +39,8 @@ __device__ __forceinline__ PmProblem pm_problem(const PmBatch& B, unsigned q)
     const unsigned pair = q / (unsigned)B.n;
     p.P.pk1 = pair_ptr_opt(p.P.pk1, B.stride, pair);
     p.P.pk2 = pair_ptr_opt(p.P.pk2, B.stride, pair);
+    p.P.pc1 = pair_ptr_opt(p.P.pc1, B.stride, pair);
+    p.P.pc2 = pair_ptr_opt(p.P.pc2, B.stride, pair);
     p.cost = pair_ptr_opt(p.cost, B.stride, pair);
     p.nnf = pair_ptr_opt(p.nnf, B.stride, pair);
     p.nnf_alt = pair_ptr_opt(p.nnf_alt, B.stride, pair);
@@ -136,9 +138,13 @@ template <> struct SearchLut<0> { using type = PatchLut; };          // any radi
 __device__ __forceinline__ float patch_dist_any(const Planes& P, const PatchLut& L, int R, int x1, int y1, int x2, int y2) { return patch_dist(P, L, R, x1, y1, x2, y2); }
 template <int M> __device__ __forceinline__ float patch_dist_any(const Planes&, const PatchLutT<M>&, int, int, int, int, int) { return 0.0f; }   // never called (RT != 0)
 
-template <int RT, class LUT>
+// PK: the target texels are gathered from the 4-byte plane pc2 = {R, G, B, census} and converted at use (make_texel, the function
+// that built the float4 plane: the same bits).  A 64-lane gather of 4 bytes costs the L1 38 clocks where one of 16 bytes costs 52-78
+// (tools/ubench/gather_rate.hip), the conversion 12 VALU instructions per texel: for launches whose search runs at the L1's lane
+// rate with VALU slots to spare -- radius 17, or one small pair per launch -- not for the batched radius-9 launches (VALU bound).
+template <int RT, bool PK = false, class LUT>
 __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L, int R, const float4* __restrict__ s_src, int TW,
-                                                   int tx, int ty, int x1, int y1, int x2, int y2)
+                                                   int tx, int ty, int x1, int y1, int x2, int y2, const uint32_t* __restrict__ pc2 = nullptr)
 {
     if (RT == 0) return patch_dist_any(P, L, R, x1, y1, x2, y2);
     constexpr int S = RT + 1;
@@ -152,16 +158,20 @@ __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L
         const float4* __restrict__ srow = s_src + (ty + 2 * ii) * TW + tx;
         for (int j0 = 0; j0 < S; j0 += 5) {
             float4 q1[5], q2[5];
+            uint32_t w2[PK ? 5 : 1];
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 const int jj = min(j0 + k, S - 1);
                 q1[k] = srow[2 * jj];
-                q2[k] = texel_at(P.pk2, r2 + ((unsigned)iclamp(x2 + 2 * jj - RT, 0, P.w - 1) << 4));
+                const unsigned o2 = r2 + ((unsigned)iclamp(x2 + 2 * jj - RT, 0, P.w - 1) << 4);
+                if (PK) w2[k] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(pc2) + (o2 >> 2));
+                else q2[k] = texel_at(P.pk2, o2);
             }
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 if (j0 + k < S) {
                     float ct, wt;
+                    if (PK) q2[k] = make_texel(w2[k], w2[k] >> 24);
                     patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.cnx, ct, wt);
                     cost_sum += ct;
                     weight_sum += wt;
@@ -199,6 +209,46 @@ __device__ __forceinline__ float dpp_prev_lane(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
+// One patch evaluation spread over the LPC lanes of a DPP row (16) or of a whole wave (64), for kernels whose source samples lie in
+// the (kBlock + 2 RT)^2 LDS tile of a 16x16 block: the S*S samples are dealt to the lanes in contiguous chunks, each lane forms the
+// terms of its chunk, and the two running sums hop lane to lane while every lane adds its chunk -- the reference's order of additions,
+// as in the cooperative sweep.  r = lane within the group; every lane of the group returns the cost.
+template <int RT, int LPC, class LUT>
+__device__ __forceinline__ float coop_patch_dist(const Planes& P, const LUT& L, const float4* __restrict__ s_src, int TW, int tx, int ty,
+                                                 int x2, int y2, int r)
+{
+    constexpr int S = RT + 1, NS = S * S, CH = (NS + LPC - 1) / LPC, NL = (NS + CH - 1) / CH;
+    const int pitch16 = P.pitch << 4, wmax16 = (P.w - 1) << 4;
+    const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
+    const rgbf c2 = texel_rgb(texel_at(P.pk2, texel_off(pitch16, P.w, P.h, x2, y2)));
+    const int t0 = r * CH;
+    float tc[CH], tw[CH];
+    float4 q2[CH];
+    int so[CH];
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int t = min(t0 + k, NS - 1), ii = t / S, jj = t - ii * S;
+        so[k] = (ty + 2 * ii) * TW + tx + 2 * jj;
+        q2[k] = texel_at(P.pk2, texel_off16(pitch16, wmax16, P.h - 1, (x2 + 2 * jj - RT) << 4, y2 + 2 * ii - RT));
+    }
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        tc[k] = 0.0f; tw[k] = 0.0f;
+        if (t0 + k < NS) patch_terms(s_src[so[k]], q2[k], c1, c2, L.gsp[t0 + k], L.cnx, tc[k], tw[k]);
+    }
+    float ac = 0.0f, aw = 0.0f;
+#pragma unroll
+    for (int ln = 0; ln < NL; ln++) {
+        if (ln > 0) { ac = dpp_prev_lane<LPC>(ac); aw = dpp_prev_lane<LPC>(aw); }
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+            if (ln * CH + q < NS) { ac += tc[q]; aw += tw[q]; }
+        }
+    }
+    const int src = ((threadIdx.x & 63) / LPC) * LPC + (NL - 1);      // lane holding the complete sums (wave-relative)
+    return __shfl(ac, src, 64) / __shfl(aw, src, 64);
+}
+
 // LPC = lanes per chain (16, 32 or 64)
 #ifdef EPPM_SWEEP_WAVES
 #define EPPM_SWEEP_OCC __attribute__((amdgpu_waves_per_eu(EPPM_SWEEP_WAVES, EPPM_SWEEP_WAVES)))
@@ -215,10 +265,14 @@ template <int LPC> struct SweepTile { static constexpr int CPB = 256 / LPC, SEGS
 // SPEC: phase B of the speculative form (see k_pm_sweep_spec below): a step that follows a rejection takes its cost from
 // pr.spec; the stored match, cost and speculative cost of a chain's pixels are fetched once, before the first step, and
 // handed to the steps through LDS (they are the only memory a cheap step needs).  Requires L_ <= kSpecMaxSteps.
+// PRE (always with SPEC): the per-step global loads happen before the first step.  The classic form uses it for launches that cannot
+// fill the chip (one 1024x436 pair): once the field has converged nearly every step is answered by the evaluation cache, and what a
+// step then waits for is the round trip of its own loads -- 1.3 us per step, ten steps deep; fetched up front they cost one round trip.
 constexpr int kSpecMaxSteps = 16;
-template <int R, int LPC, bool IS_ROW, bool REVERSE, bool TILE, bool SPEC = false>
+template <int R, int LPC, bool IS_ROW, bool REVERSE, bool TILE, bool SPEC = false, bool PRE = SPEC>
 __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, const float* __restrict__ lut, int L_, int nseg, int nseg_pad, int TW)
 {
+    static_assert(PRE || !SPEC, "phase B fetches its chains' pixels up front");
     // SPEC with a work list (pr.wl): the workgroup's CPB chains are CPB / 2 listed units (a unit = segments 2u, 2u + 1 of a line, so
     // that segments 0 and 1 -- the two visitors of pixel L -- always sit in one workgroup); a workgroup past the end of the list
     // returns at once.  Chains that are not listed keep their pixels: phase A has copied the whole field to the output plane.
@@ -227,9 +281,10 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
     static_assert(!(SPEC && TILE), "phase B evaluates rarely: it gathers its source samples");
     extern __shared__ float4 s_tile[];          // TILE: TROWS sample rows + LINES centre rows of TW texels
     __shared__ PatchLut L;
-    __shared__ int s_own[SPEC ? CPB * kSpecMaxSteps : 1];       // SPEC: per chain and step, the pixel's stored match (x | y << 16),
-    __shared__ float s_cst[SPEC ? CPB * kSpecMaxSteps : 1];     //       its stored cost
-    __shared__ float s_spc[SPEC ? CPB * kSpecMaxSteps : 1];     //       and phase A's cost of the rejection-path candidate
+    __shared__ int s_own[PRE ? CPB * kSpecMaxSteps : 1];       // PRE: per chain and step, the pixel's stored match (x | y << 16),
+    __shared__ float s_cst[PRE ? CPB * kSpecMaxSteps : 1];     //      its stored cost,
+    __shared__ float s_spc[PRE ? CPB * kSpecMaxSteps : 1];     //      phase A's cost of the rejection-path candidate (classic form: the cached cost)
+    __shared__ int s_ccd[(PRE && !SPEC) ? CPB * kSpecMaxSteps : 1];   // classic form: and the cached candidate
     load_patch_lut(L, lut, R, threadIdx.x, 256);
     // 1-D grid, problem = id mod nprob: workgroups are dealt to the 8 XCDs by id mod 8, so with 8 problems (4 pairs x 2 directions)
     // each problem's planes stay in ONE XCD's L2 instead of all problems' planes competing for every L2
@@ -308,20 +363,22 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             nout[uidx * 2 + 1] = nin[uidx * 2 + 1];
         }
     }
-    if (SPEC) {
+    if (PRE) {
         // the lanes of a chain fetch what its steps need: lane r the steps r, r + LPC, ...
         for (int sr = r; sr < L_; sr += LPC) {
-            int own = 0;
+            int own = 0, ccd = -1;
             float cst = 0.0f, spc = 0.0f;
             if (active && sr < count) {
                 const int ir = i + sr * step;
                 const int xr = IS_ROW ? ir : line, yr = IS_ROW ? line : ir;
                 own = (int)(uint16_t)nin[(yr * B.npitch + xr) * 2] | ((int)nin[(yr * B.npitch + xr) * 2 + 1] << 16);
                 cst = cost[yr * B.cpitch + xr];
-                spc = cval[yr * B.cpitch + xr];
+                if (cval) spc = cval[yr * B.cpitch + xr];
+                if (!SPEC && ccand) ccd = ccand[yr * B.cpitch + xr];
             }
             const int sl = grp * kSpecMaxSteps + sr;
             s_own[sl] = own; s_cst[sl] = cst; s_spc[sl] = spc;
+            if (!SPEC) s_ccd[sl] = ccd;
         }
     }
     bool from_nin = true;                  // SPEC: the chain carries a stored match (seed, or the own match of a pixel that rejected)
@@ -349,7 +406,7 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             const bool second_visit = (!REVERSE) && (seg == 0) && (s == L_ - 1) && (nseg > 1);   // pixel L, after segment 1
             float cur_best;
             int ox, oy;
-            if (SPEC) {
+            if (PRE) {
                 const int sl = grp * kSpecMaxSteps + s, e = s_own[sl];
                 ox = (int)(int16_t)(e & 0xffff); oy = e >> 16;
                 cur_best = second_visit ? cost_L : s_cst[sl];         // segment 1 may have lowered pixel L's cost at its first step
@@ -359,7 +416,10 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             }
             int hit_cand = -1;                                        // classic form: this pixel's cached evaluation, fetched with the rest
             float hit_val = 0.0f;
-            if (!SPEC && ccand) { hit_cand = ccand[cidx]; hit_val = cval[cidx]; }
+            if (!PRE && ccand) { hit_cand = ccand[cidx]; hit_val = cval[cidx]; }
+            // (fetched up front: at pixel L's second visit the entry may predate segment 1's evaluation; a stale entry is still a
+            // valid (candidate, cost) pair -- at worst this step evaluates what the entry written meanwhile would have answered)
+            if (PRE && !SPEC) { hit_cand = s_ccd[grp * kSpecMaxSteps + s]; hit_val = s_spc[grp * kSpecMaxSteps + s]; }
             if (IS_ROW) px = REVERSE ? max(px - 1, 0) : min(px + 1, P.w - 1);
             else        py = REVERSE ? max(py - 1, 0) : min(py + 1, P.h - 1);
             // A candidate equal to the pixel's current match would reproduce the stored cost bit for bit
@@ -445,7 +505,7 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             __syncthreads();   // (b)
             // SPEC: pixel L's cost as segment 1's first step left it, for segment 0's last step (fetched here, by value: a select
             // between this global address and the LDS copy at the point of use would turn both loads into flat_load)
-            if (SPEC && active && seg == 0 && nseg > 1 && L_ < len) cost_L = cost[IS_ROW ? line * B.cpitch + L_ : L_ * B.cpitch + line];
+            if (PRE && active && seg == 0 && nseg > 1 && L_ < len) cost_L = cost[IS_ROW ? line * B.cpitch + L_ : L_ * B.cpitch + line];
         }
     }
 }
@@ -545,10 +605,31 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
         s_cand[slot] = cpack;
     }
     __syncthreads();                          // LUT, tile, list
+#ifndef EPPM_SPEC_COOP17_MAX
+#define EPPM_SPEC_COOP17_MAX 32
+#endif
+    // Radius 17: one lane's evaluation is a serial chain of 324 samples (75 us), the 45 KB tile allows three workgroups per CU, and in
+    // the converged iterations a block has a handful of evaluations left: then a whole wave takes one evaluation (6 samples per lane,
+    // ordered 54-hop sum), four at a time.  (At radius 9 the same with 16 lanes per evaluation was measured and lost: its registers
+    // cost the early iterations -- every block of the launch -- more than the late ones gain.)
+    if (RT == 17 && total <= EPPM_SPEC_COOP17_MAX) {
+        for (int slot = tid >> 6; slot < total; slot += 4) {
+            const int pix = (int)s_list[slot], e = s_cand[slot];
+            const int px = bxx * kBlock + (pix & 15), py = byy * kBlock + (pix >> 4);
+            const float cv = coop_patch_dist<(RT == 17 ? 17 : 1), 64>(P, L, s_src, TW, pix & 15, pix >> 4, (int)(int16_t)(e & 0xffff), e >> 16, tid & 63);
+            if ((tid & 63) == 0) {
+                cval[py * B.cpitch + px] = cv;
+                if (ccand) ccand[py * B.cpitch + px] = e;
+                if (wl && cv < pr.cost[py * B.cpitch + px]) list_unit(px, py);
+            }
+        }
+        return;
+    }
     if (tid >= total) return;
     const int pix = (int)s_list[tid], e = s_cand[tid];
     const int tx = pix & 15, ty = pix >> 4;
     const int px = bxx * kBlock + tx, py = byy * kBlock + ty;
+    // (radius 17: gathering the 4-byte target plane here as the search does changes nothing: 57.5 vs 57.6 ms PatchMatch at 3840x2160)
     const float cv = search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16);
     cval[py * B.cpitch + px] = cv;
     if (ccand) ccand[py * B.cpitch + px] = e;
@@ -649,7 +730,7 @@ static void launch_sweep_b(const PmBatch& b, const float* lut, int seg_len, int 
     }
 }
 
-template <int R, int LPC, bool TILE>
+template <int R, int LPC, bool TILE, bool PRE = false>
 static void launch_sweep_t(const PmBatch& b, const float* lut, int seg_len, int dir, int nseg, int lines, hipStream_t s)
 {
     constexpr int CPB = 256 / LPC, SEGS = SweepTile<LPC>::SEGS, LINES = SweepTile<LPC>::LINES;
@@ -659,20 +740,25 @@ static void launch_sweep_t(const PmBatch& b, const float* lut, int seg_len, int 
     const size_t lds = TILE ? (size_t)(R + 1 + 2 * LINES - 1) * TW * 16 : 0;
     dim3 grid(wgs * (b.n * b.npairs)), block(256);
     switch (dir) {
-        case 0: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, false, TILE>), grid, block, lds, s, b, lut, seg_len, nseg, nseg_pad, TW); break;
-        case 1: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, false, TILE>), grid, block, lds, s, b, lut, seg_len, nseg, nseg_pad, TW); break;
-        case 2: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, true, TILE>), grid, block, lds, s, b, lut, seg_len, nseg, nseg_pad, TW); break;
-        default: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, true, TILE>), grid, block, lds, s, b, lut, seg_len, nseg, nseg_pad, TW); break;
+        case 0: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, false, TILE, false, PRE>), grid, block, lds, s, b, lut, seg_len, nseg, nseg_pad, TW); break;
+        case 1: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, false, TILE, false, PRE>), grid, block, lds, s, b, lut, seg_len, nseg, nseg_pad, TW); break;
+        case 2: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, true, TILE, false, PRE>), grid, block, lds, s, b, lut, seg_len, nseg, nseg_pad, TW); break;
+        default: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, true, TILE, false, PRE>), grid, block, lds, s, b, lut, seg_len, nseg, nseg_pad, TW); break;
     }
 }
 #ifndef EPPM_SWEEP_TILE
 #define EPPM_SWEEP_TILE 1
 #endif
 // source tile in LDS while it stays small (16 KiB at R = 9 and the default segment length of 10); very long segments gather
-template <int R, int LPC>
+template <int R, int LPC, bool PRE = false>
 static void launch_sweep_r(const PmBatch& b, const float* lut, int seg_len, int dir, int nseg, int lines, hipStream_t s)
 {
     const size_t lds = (size_t)(R + 2 * SweepTile<LPC>::LINES) * ((SweepTile<LPC>::SEGS * seg_len + 2 * R) | 1) * 16;
+    if (PRE && seg_len <= kSpecMaxSteps && b.p[0].scand) {
+        if (EPPM_SWEEP_TILE && lds <= 32 * 1024) launch_sweep_t<R, LPC, true, PRE>(b, lut, seg_len, dir, nseg, lines, s);
+        else launch_sweep_t<R, LPC, false, PRE>(b, lut, seg_len, dir, nseg, lines, s);
+        return;
+    }
     if (EPPM_SWEEP_TILE && lds <= 32 * 1024) launch_sweep_t<R, LPC, true>(b, lut, seg_len, dir, nseg, lines, s);
     else launch_sweep_t<R, LPC, false>(b, lut, seg_len, dir, nseg, lines, s);
 }
@@ -703,8 +789,11 @@ bool launch_pm_sweep(PmBatch& b, const float* lut, int R, int seg_len, int dir, 
 #ifndef EPPM_LPC_SWITCH_WAVES
 #define EPPM_LPC_SWITCH_WAVES (2 * 1024)
 #endif
-        if (chains * EPPM_LPC9 / 64 < EPPM_LPC_SWITCH_WAVES) launch_sweep_r<9, 2 * EPPM_LPC9>(b, lut, seg_len, dir, nseg, lines, s);
-        else launch_sweep_r<9, EPPM_LPC9>(b, lut, seg_len, dir, nseg, lines, s);
+#ifndef EPPM_SWEEP_PRE
+#define EPPM_SWEEP_PRE 1      // the classic form fetches its chains' pixels up front: 0 never, 1 launches that cannot fill the chip, 2 always
+#endif
+        if (chains * EPPM_LPC9 / 64 < EPPM_LPC_SWITCH_WAVES) launch_sweep_r<9, 2 * EPPM_LPC9, (EPPM_SWEEP_PRE >= 1)>(b, lut, seg_len, dir, nseg, lines, s);
+        else launch_sweep_r<9, EPPM_LPC9, (EPPM_SWEEP_PRE >= 2)>(b, lut, seg_len, dir, nseg, lines, s);
         return true;
     }
     if (R == 17) { launch_sweep_r<17, EPPM_LPC17>(b, lut, seg_len, dir, nseg, lines, s); return true; }
@@ -820,7 +909,7 @@ void launch_pm_neighbor(const PmBatch& b, const float* lut, int R, hipStream_t s
 // pixels, the costs meet in LDS and wave 0 replays the reference's in-order strict-< selection.  The four
 // quarter-workgroups of a block draw the same numbers (cheap); only quarter 0 advances the stored state.
 // ---------------------------------------------------------------------------------------------------
-template <int RT>
+template <int RT, bool PK = false>
 __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
                                                           int search_range, int G)
 {
@@ -911,7 +1000,7 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     if (inimg) {
         float cv = INFINITY;
         if (evaluate) {
-            cv = search_patch_dist<RT>(P, L, R, s_src, TW, lane & 15, lane >> 4, x, y, gx, gy);
+            cv = search_patch_dist<RT, PK>(P, L, R, s_src, TW, lane & 15, lane >> 4, x, y, gx, gy, pr.P.pc2);
         }
         s_cost[k][lane] = cv;
     }
@@ -935,7 +1024,17 @@ void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float*
                              hipStream_t s)
 {
     dim3 grid(rng.gx * rng.gy * 4 * b.n * b.npairs), block(64 * (num_guess + 1));      // + the wave that advances the RNG states
-    if (R == 9) hipLaunchKernelGGL(k_pm_random_search<9>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+#ifndef EPPM_SEARCH_PK9_MAX_PIXELS
+#define EPPM_SEARCH_PK9_MAX_PIXELS 0           // radius 9: launches up to this many pixels gather the 4-byte target plane (measured: slower at every size)
+#endif
+#ifndef EPPM_SEARCH_PK17
+#define EPPM_SEARCH_PK17 1
+#endif
+    const bool have_pc = b.p[0].P.pc2 && (b.n < 2 || b.p[1].P.pc2);
+    const long long pixels = (long long)b.n * b.npairs * b.p[0].P.w * b.p[0].P.h;
+    if (R == 9 && have_pc && pixels <= EPPM_SEARCH_PK9_MAX_PIXELS) hipLaunchKernelGGL((k_pm_random_search<9, true>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+    else if (R == 17 && have_pc && EPPM_SEARCH_PK17) hipLaunchKernelGGL((k_pm_random_search<17, true>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+    else if (R == 9) hipLaunchKernelGGL(k_pm_random_search<9>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else if (R == 17) hipLaunchKernelGGL(k_pm_random_search<17>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else hipLaunchKernelGGL(k_pm_random_search<0>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
 }

@@ -6,7 +6,7 @@
 #
 #   test        GPU suite (PYTEST_ARGS, default "-x -q")               bench       the default bench line -> gpurun_out/bench_latest.json
 #   quick       GPU suite + a short bench with stage times             stats       rocprofv3 --kernel-trace --stats of BENCH_ARGS -> gpurun_out/stats_$TAG
-#   ab          VARIANTS="a b": default bench per variant (BENCH_ARGS) abstage     VARIANTS: single-stream stage times (tools/stage_times.py; SIZE=WxH R=)
+#   ab          VARIANTS="a b": default bench per variant (BENCH_ARGS) abstage     VARIANTS: single-stream stage times (tools/stage_times.py; SIZE=WxH PATCH_R= BATCH=)
 #   abk         VARIANTS: per-kernel averages under rocprofv3 (BENCH_ARGS, FILTER=k_pm)
 #   pmc         PMC="counters.." in one pass of BENCH_ARGS -> gpurun_out/pmc_$TAG + per-kernel summary
 #   tcp         TA/TCP/TD counters per kernel (is a gather kernel L1 bound?)

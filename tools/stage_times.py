@@ -1,11 +1,11 @@
 """Single-stream per-stage device times of the library in eppm_amd/lib (A/B helper): stage_times.py LABEL ROUND
-env: SIZE=WxH (default 1024x436), R= patch radius (default 9), BATCH= pairs per launch (default 1: a single-pair context)"""
+env: SIZE=WxH (default 1024x436), PATCH_R= patch radius (default 9), BATCH= pairs per launch (default 1: a single-pair context)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, eppm_amd
 from eppm_amd import synth
 w, h = (int(x) for x in os.environ.get("SIZE", "1024x436").split("x"))
-R, NB = int(os.environ.get("R", "9")), int(os.environ.get("BATCH", "1"))
+R, NB = int(os.environ.get("PATCH_R", "9")), int(os.environ.get("BATCH", "1"))
 mf = 20.0 if w <= 1024 else (40.0 if w <= 1920 else 60.0)
 prm = eppm_amd.Params(patch_r=R)
 if NB == 1:

@@ -300,6 +300,11 @@ static void rng_free(eppm_pm_rng* r)
     delete r;
 }
 
+// Kernel-variant switches of the parity tests (eppm_test_set_option).  The values below are only the DEFAULTS a context copies when it
+// is created (eppm_ctx::opt_*) and what the context-less stage launchers read; a context in use is never affected by a later call.
+static std::atomic<int> g_sweep_spec{-1};      // "sweep_spec": -1 by iteration, 0 never, 1 always, 2 always and without the work list
+static std::atomic<int> g_no_split{0};         // "c2f_no_split"
+
 // ---------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------
@@ -314,7 +319,8 @@ struct eppm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipStream_t stream_pm = nullptr;    // experiment (EPPM_PM_LANE): the quarter-resolution stages on a stream of their own (priority / CU mask)
+    int opt_sweep_spec = -1, opt_no_split = 0;     // kernel-variant switches, copied from the process defaults at creation (test support)
+    hipStream_t stream_pm = nullptr;    // -DEPPM_EXPERIMENT_PM_LANE only: the quarter-resolution stages on a stream of their own (priority / CU mask)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     eppm_params prm;
     int h = 0, w = 0, nl = 0;
@@ -467,7 +473,7 @@ static int ctx_alloc(eppm_ctx* c)
         plane((void**)&c->cen2[i], c->cpitch[i] * c->H[i]);
         plane((void**)&c->flow[i], n * 8);
         plane((void**)&c->flow_tmp[i], n * 8);
-        if (i < c->nl - 1 && c2f_refine_wants_split(c->W[i], c->H[i], c->prm.patch_r, 1)) plane((void**)&c->c2f_cost9[i], n * 36 * 4);
+        if (i < c->nl - 1 && c2f_refine_wants_split(c->W[i], c->H[i], c->prm.patch_r, 1, c->opt_no_split != 0)) plane((void**)&c->c2f_cost9[i], n * 36 * 4);
     }
     const int L = c->nl - 1;
     const size_t n2 = (size_t)c->W[L] * c->H[L];
@@ -519,16 +525,24 @@ extern "C" int eppm_create_batch(eppm_ctx** out, int h, int w, int device, const
     HIPCHK(hipSetDevice(device));
     eppm_ctx* c = new eppm_ctx();
     c->device = device; c->prm = p; c->h = h; c->w = w; c->npairs = npairs; c->n_active = 1;
+    c->opt_sweep_spec = g_sweep_spec.load(); c->opt_no_split = g_no_split.load();
     c->nl = pyr_init_dim(c->H, c->W, h, w, p.levels, 0.5f);
     const int L = c->nl - 1;
     if (c->H[L] < 1 || c->W[L] < 1 || (c->W[L] + p.seg_len - 1) / p.seg_len > 1024 || (c->H[L] + p.seg_len - 1) / p.seg_len > 1024) {
         delete c;
         return set_err(EPPM_ERR_ARG, "eppm_create: unsupported size %dx%d", w, h);
     }
+    // Round 4 measured giving the quarter-resolution stages (PatchMatch + level-2 post-processing) a lane of their own -- a second
+    // stream per context, plain / high priority (hipStreamCreateWithPriority) / confined to K CUs per XCD (hipExtStreamCreateWithCUMask)
+    // with or without the complementary mask on this stream: every form LOSES (190.1 -> 182.5 plain, 179.3 high priority, 64-130 with
+    // CU masks; profiles/r04x_a_*).  Each kernel class is bound by the occupancy of the CUs it holds, so partitioning conserves
+    // CU-time, and co-residency on ONE CU is blocked by the refine's footprint (2 workgroups = all VGPRs and 157 of 160 KB LDS).
+    // The code is kept for reproduction behind -DEPPM_EXPERIMENT_PM_LANE (tools/build_variant.sh; EPPM_PM_LANE=plain|prio|mask:K,
+    // EPPM_MAIN_MASK=K in the environment) and is not part of the default build.
     hipError_t e = hipSuccess;
+#ifdef EPPM_EXPERIMENT_PM_LANE
     {
-        // EPPM_MAIN_MASK=K: the context's stream runs on all CUs but the first K of every XCD (bit i of a CU mask = CU i / 8 of XCD i % 8)
-        const char* mm = getenv("EPPM_MAIN_MASK");
+        const char* mm = getenv("EPPM_MAIN_MASK");         // bit i of a CU mask = CU i / 8 of XCD i % 8
         const int km = mm ? atoi(mm) : 0;
         if (km > 0 && km < 32) {
             uint32_t mask[8];
@@ -538,8 +552,12 @@ extern "C" int eppm_create_batch(eppm_ctx** out, int h, int w, int device, const
             e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         }
     }
+#else
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+#endif
     if (e != hipSuccess) { delete c; return set_err(EPPM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->own_stream = true;
+#ifdef EPPM_EXPERIMENT_PM_LANE
     if (const char* lane = getenv("EPPM_PM_LANE")) {
         hipError_t e2 = hipSuccess;
         if (!strncmp(lane, "prio", 4)) {
@@ -560,6 +578,7 @@ extern "C" int eppm_create_batch(eppm_ctx** out, int h, int w, int device, const
             (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
         }
     }
+#endif
     int r = ctx_alloc(c);
     if (r != EPPM_OK) { eppm_destroy(c); return r; }
     *out = c;
@@ -781,20 +800,18 @@ static void search(PmBatch& b, eppm_pm_rng* rng, const float* lut, const eppm_pa
 #ifndef EPPM_SPEC_FROM_ITER
 #define EPPM_SPEC_FROM_ITER 2
 #endif
-static std::atomic<int> g_sweep_spec{-1};      // test support ("sweep_spec"): -1 by iteration, 0 never, 1 always, 2 always and without the work list
 #ifndef EPPM_SWEEP_LIST
 #define EPPM_SWEEP_LIST 1          // work list of the speculative sweeps: phase B walks only the chains phase A found an accepted candidate on
 #endif
-static bool sweep_list_on() { return EPPM_SWEEP_LIST && g_sweep_spec.load() != 2; }
+static bool sweep_list_on(int mode) { return EPPM_SWEEP_LIST && mode != 2; }
 // A launch over one 1024x436 pair (two problems of 28 k pixels) is too small for the two-launch form to pay: phase A's evaluations
 // are one wave per SIMD, and the classic kernel at 32 lanes per chain finishes in 27 us where phase A + phase B take 19 + 16.  From
 // about a hundred thousand pixels per launch on (two such pairs; one 1920x1080 or 3840x2160 pair) the speculative form wins.
 #ifndef EPPM_SPEC_MIN_PIXELS
 #define EPPM_SPEC_MIN_PIXELS 100000
 #endif
-static bool sweep_speculative(int iteration, long long pixels)
+static bool sweep_speculative(int iteration, long long pixels, int m)
 {
-    const int m = g_sweep_spec.load();
     return m < 0 ? (iteration >= EPPM_SPEC_FROM_ITER && pixels >= EPPM_SPEC_MIN_PIXELS) : m != 0;
 }
 // one directional sweep on the batch; keeps the result in p[k].nnf (swaps the ping-pong pair when needed)
@@ -821,7 +838,7 @@ static void neighbor(PmBatch& b, const float* lut, const eppm_params& prm, int l
     }
 }
 // returns with the NNF of problem k in b.p[k].nnf (an even number of sweeps: the caller's buffer)
-static void run_patchmatch(PmBatch& b, eppm_pm_rng* rng, const float* lut, const eppm_params& prm, hipStream_t s)
+static void run_patchmatch(PmBatch& b, eppm_pm_rng* rng, const float* lut, const eppm_params& prm, hipStream_t s, int spec_mode)
 {
     b.sweep_seq = 0;
     launch_pm_init_field(b, rng->dev(), s);
@@ -829,7 +846,7 @@ static void run_patchmatch(PmBatch& b, eppm_pm_rng* rng, const float* lut, const
     for (int it = 0; it < prm.num_iter; it++) {
         if (prm.propagation == 1) jump(b, lut, prm, s);
         else if (prm.propagation == 2) neighbor(b, lut, prm, 10, s);
-        else for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s, sweep_speculative(it, (long long)b.n * b.npairs * b.p[0].P.w * b.p[0].P.h));
+        else for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s, sweep_speculative(it, (long long)b.n * b.npairs * b.p[0].P.w * b.p[0].P.h, spec_mode));
         search(b, rng, lut, prm, s);
     }
 }
@@ -859,9 +876,9 @@ static int compute_all(eppm_ctx* c)
 #ifndef EPPM_SWEEP_CACHE
 #define EPPM_SWEEP_CACHE 1
 #endif
-        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0, c->spec1, EPPM_SWEEP_CACHE ? c->scand1 : nullptr, sweep_list_on() ? c->wl1 : nullptr);     // driver :223
-        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1, c->spec2, EPPM_SWEEP_CACHE ? c->scand2 : nullptr, sweep_list_on() ? c->wl2 : nullptr);     // driver :224
-        run_patchmatch(b, c->rng, c->lut_pm, c->prm, s);
+        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0, c->spec1, EPPM_SWEEP_CACHE ? c->scand1 : nullptr, sweep_list_on(c->opt_sweep_spec) ? c->wl1 : nullptr);     // driver :223
+        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1, c->spec2, EPPM_SWEEP_CACHE ? c->scand2 : nullptr, sweep_list_on(c->opt_sweep_spec) ? c->wl2 : nullptr);     // driver :224
+        run_patchmatch(b, c->rng, c->lut_pm, c->prm, s, c->opt_sweep_spec);
     }
     stage_end(c, c->ev);
 
@@ -891,7 +908,7 @@ static int compute_all(eppm_ctx* c)
         launch_resize_flow(c->flow[l], c->H[l], c->W[l], c->flow[l + 1], c->H[l + 1], c->W[l + 1], 2.0f, 2.0f, s, bt);   // refine :1082-1083
         stage_end(c, c->ev);
         stage_begin(c, c->ev, rf_names[l], true);
-        launch_c2f_refine(planes(c, l, false), c->flow[l], c->lut_pm, c->prm.patch_r, c->c2f_cost9[l], s, bt);   // refine :1086
+        launch_c2f_refine(planes(c, l, false), c->flow[l], c->lut_pm, c->prm.patch_r, c->c2f_cost9[l], s, bt, c->opt_no_split != 0);   // refine :1086
         stage_end(c, c->ev, true);
         stage_begin(c, c->ev, bl_names[l]);
         launch_flow_blf(c->flow_tmp[l], c->flow[l], c->img1[l], (int)(c->ipitch[l] / 4), c->W[l], c->H[l], c->W[l], c->lut_blf, s, bt);  // driver :280
@@ -1262,7 +1279,7 @@ extern "C" int eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const ep
     HIPCHK(hipMemsetAsync((char*)spec + plane_bytes * 4, 0xff, plane_bytes * 4, g_stream));
     b.cache_plane = plane_bytes / 4;
     void* wl = nullptr;                                        // work list of the speculative form: lengths and stamps cleared per call
-    if (speculative && sweep_list_on()) {
+    if (speculative && sweep_list_on(g_sweep_spec.load())) {
         b.wl_units = pm_worklist_units(w, h, g_prm.seg_len);
         const size_t wl_bytes = pm_worklist_words(w, h, g_prm.seg_len) * 4;
         CHK(get_scratch(ds, wl_bytes, &wl, 5));
@@ -1356,7 +1373,7 @@ static int probe(const float* x, float* y, int n, int which)
 extern "C" int eppm_test_set_option(const char* name, int value)
 {
     if (!name) return set_err(EPPM_ERR_ARG, "eppm_test_set_option: NULL name");
-    if (!strcmp(name, "c2f_no_split")) { c2f_set_no_split(value); return EPPM_OK; }
+    if (!strcmp(name, "c2f_no_split")) { g_no_split.store(value); return EPPM_OK; }
     if (!strcmp(name, "sweep_spec")) { g_sweep_spec.store(value); return EPPM_OK; }
     return set_err(EPPM_ERR_ARG, "eppm_test_set_option: unknown option '%s'", name);
 }
@@ -1443,8 +1460,8 @@ extern "C" void baoCudaPatchMatch(eppm_short2* d_disp_vec, float* d_cost, eppm_u
     b.wl_units = pm_worklist_units(w, h, g_prm.seg_len);
     g_launch_status = get_scratch(ds, pm_worklist_words(w, h, g_prm.seg_len) * 4, &wl, 5);       // (k_pm_init_field clears it)
     if (g_launch_status != EPPM_OK) return;
-    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0, (float*)spec, (int32_t*)((char*)spec + plane_bytes * 4), sweep_list_on() ? (uint32_t*)wl : nullptr);
-    run_patchmatch(b, r, ds->lut_pm, g_prm, g_stream);
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0, (float*)spec, (int32_t*)((char*)spec + plane_bytes * 4), sweep_list_on(g_sweep_spec.load()) ? (uint32_t*)wl : nullptr);
+    run_patchmatch(b, r, ds->lut_pm, g_prm, g_stream, g_sweep_spec.load());
     if (b.p[0].nnf != (int16_t*)d_disp_vec && (g_launch_status = copy_d2d(d_disp_vec, b.p[0].nnf, disp_pitch * h)) != EPPM_OK) return;
     g_launch_status = finish();
 }
@@ -1513,7 +1530,7 @@ extern "C" void baoCudaBLFCostFilterRefine(eppm_float2* d_flow_vec, eppm_uchar4*
     PlanesH P;
     g_launch_status = mk_planes(ds, &P, d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch);
     if (g_launch_status != EPPM_OK) return;
-    launch_c2f_refine(P, (float*)d_flow_vec, ds->lut_pm, g_prm.patch_r, nullptr, g_stream);
+    launch_c2f_refine(P, (float*)d_flow_vec, ds->lut_pm, g_prm.patch_r, nullptr, g_stream, kOnePair, g_no_split.load() != 0);
     g_launch_status = finish();
 }
 
@@ -1529,7 +1546,7 @@ extern "C" void baoCudaBLF_C2F(eppm_float2** pFlowPyr, eppm_uchar4** pImgPyr1, e
     PlanesH P;
     g_launch_status = mk_planes(ds, &P, pImgPyr1[l], pImgPyr2[l], pCensusPyr1[l], pCensusPyr2[l], arrW[l], arrH[l], arrPitchUchar4[l], arrPitchUchar1[l]);
     if (g_launch_status != EPPM_OK) return;
-    launch_c2f_refine(P, (float*)pFlowPyr[l], ds->lut_pm, g_prm.patch_r, nullptr, g_stream);                                                          // refine :1086
+    launch_c2f_refine(P, (float*)pFlowPyr[l], ds->lut_pm, g_prm.patch_r, nullptr, g_stream, kOnePair, g_no_split.load() != 0);                       // refine :1086
     g_launch_status = finish();
 }
 

@@ -771,10 +771,6 @@ __global__ __launch_bounds__(256) void k_c2f_select(float* __restrict__ flow_, c
     flow[(y * w + x) * 2 + 1] = (float)(by - y);
 }
 
-// test support (eppm_test_set_option "c2f_no_split"): never split, so that small images go through the LDS-window kernels too
-static std::atomic<int> g_c2f_no_split{0};
-void c2f_set_no_split(int on) { g_c2f_no_split.store(on); }
-
 // admissible spread (max - min) of a tile's candidate centres in the LDS-window kernels, for the tests that probe the boundary
 bool c2f_window_span(int R, int* span_x, int* span_y)
 {
@@ -794,9 +790,10 @@ bool c2f_window_span(int R, int* span_x, int* span_y)
     return false;
 }
 
-bool c2f_refine_wants_split(int w, int h, int R, int npairs)
+// no_split (a context's "c2f_no_split" option): never split, so that small images go through the LDS-window kernels too
+bool c2f_refine_wants_split(int w, int h, int R, int npairs, bool no_split)
 {
-    if (g_c2f_no_split.load()) return false;
+    if (no_split) return false;
     const int tiles = ((w + kBlock - 1) / kBlock) * ((h + kBlock - 1) / kBlock) * npairs;
 #ifndef EPPM_C2F_SPLIT_BELOW_WAVES
 #define EPPM_C2F_SPLIT_BELOW_WAVES 1024              // fewer than 1 wave per SIMD on 256 CUs (at 256 threads per tile)
@@ -807,14 +804,14 @@ bool c2f_refine_wants_split(int w, int h, int R, int npairs)
 }
 
 // cost9: scratch of 36 floats per pixel, or NULL (never split)
-void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, float* cost9, hipStream_t s, Batch bt)
+void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, float* cost9, hipStream_t s, Batch bt, bool no_split)
 {
     dim3 grid((P.w + kBlock - 1) / kBlock, (P.h + kBlock - 1) / kBlock, bt.n), block(kBlock, kBlock);
     const int tiles = grid.x * grid.y;
     const int per_xcd = (tiles + 7) / 8;
     dim3 grid1(per_xcd * 8, bt.n);               // x: padded so every XCD gets the same number of slots; y: pair
     const bool table_ok = (P.w + R < 32764) && (P.h + R < 32764);     // range of the offset-table identity (c2f_pass)
-    if (cost9 && table_ok && c2f_refine_wants_split(P.w, P.h, R, bt.n)) {
+    if (cost9 && table_ok && c2f_refine_wants_split(P.w, P.h, R, bt.n, no_split)) {
         // 3 or 4 workgroups per tile: the factor whose workgroup count divides more evenly over the 256 CUs
         auto imbalance = [&](int f) { const int wgs = tiles * f * bt.n; return (float)((wgs + 255) / 256) * 256.0f / (float)wgs; };
         const int f = (imbalance(4) < imbalance(3)) ? 4 : 3;

@@ -610,8 +610,9 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
 #endif
     // Radius 17: one lane's evaluation is a serial chain of 324 samples (75 us), the 45 KB tile allows three workgroups per CU, and in
     // the converged iterations a block has a handful of evaluations left: then a whole wave takes one evaluation (6 samples per lane,
-    // ordered 54-hop sum), four at a time.  (At radius 9 the same with 16 lanes per evaluation was measured and lost: its registers
-    // cost the early iterations -- every block of the launch -- more than the late ones gain.)
+    // ordered 54-hop sum), four at a time.  (At radius 9 the same with 16 lanes per evaluation was measured and lost -- its registers cost the
+    // early iterations, every block of the launch, more than the late ones gain -- and as a separate instantiation for the late
+    // iterations only it changed nothing: profiles/r04x_c.)
     if (RT == 17 && total <= EPPM_SPEC_COOP17_MAX) {
         for (int slot = tid >> 6; slot < total; slot += 4) {
             const int pix = (int)s_list[slot], e = s_cand[slot];

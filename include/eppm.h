@@ -274,10 +274,13 @@ int  eppm_gauss_filter_rgba(eppm_uchar4* d_out, const eppm_uchar4* d_in, size_t 
 int  eppm_resize_rgba(eppm_uchar4* d_out, size_t out_pitch, int outH, int outW, const eppm_uchar4* d_in, size_t in_pitch,
         int h, int w, float ratio);
 int  eppm_resize_flow(eppm_float2* d_out, int outH, int outW, const eppm_float2* d_in, int h, int w, float ratio);
-/* test support: process-wide switches with which the parity tests steer launches onto a specific kernel variant (a host program
- * never needs them).  "c2f_no_split" = 1: the candidate refine is never split over several workgroups per tile, so that small
- * images run the LDS-window kernels too.  "sweep_spec": -1 (default) the sweeps of PatchMatch iterations >= 2 (the third on) run in the
- * speculative two-launch form when a launch covers at least 100 000 pixels (two 1024x436 pairs, one 1920x1080 pair), 0 never, 1 always (also in eppm_pm_seg_propagate, which otherwise runs the classic form). */
+/* test support: switches with which the parity tests steer launches onto a specific kernel variant (a host program never needs them;
+ * every variant computes the same bits).  A call sets the DEFAULT that contexts created afterwards copy, and what the context-less stage
+ * launchers below read; a context that exists already is not affected.  "c2f_no_split" = 1: the candidate refine is never split over
+ * several workgroups per tile, so that small images run the LDS-window kernels too.  "sweep_spec": -1 (default) the sweeps of PatchMatch
+ * iterations >= 2 (the third on) run in the speculative two-launch form when a launch covers at least 100 000 pixels (two 1024x436 pairs,
+ * one 1920x1080 pair), 0 never, 1 always (also in eppm_pm_seg_propagate, which otherwise runs the classic form), 2 always and without
+ * the work list (phase B walks every chain). */
 int  eppm_test_set_option(const char* name, int value);
 /* admissible spread (max - min, pixels) of a 16x16 tile's candidate centres for which the LDS-window refine kernels stage the
  * target window; wider tiles take the per-access path inside the same launch (patch_r 9 or 17) */

@@ -212,10 +212,19 @@ def worker(args):
 
         def probe_rccl():
             import datetime
-            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
-            probe = torch.ones(1, device=dev)
-            dist.all_reduce(probe, group=g)          # communicators are created lazily: fail here, not inside the timed region
-            torch.cuda.synchronize()
+            # RCCL prints its version banner on STDOUT when the first communicator comes up (or fails to): stdout carries the ONE JSON
+            # line and nothing else, so file descriptor 1 points at stderr while the communicator is created
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe, group=g)          # communicators are created lazily: fail here, not inside the timed region
+                torch.cuda.synchronize()
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
             if int(probe.item()) != world:
                 raise RuntimeError(f"all_reduce probe returned {probe.item()} for {world} ranks")
             return g

@@ -277,6 +277,31 @@ def test_class_pinned_blocks_shared_by_two_workers(tmp_path):
     assert outs[0] == outs[1] == outs[2] and len(outs[0]) == 12 + 320 * 200 * 8
 
 
+def test_unregister_under_a_pending_transfer_fails_instead_of_unpinning():
+    """eppm_compute_begin_into has the copy engine write registered planes until eppm_compute_end: unregistering them in between must
+    not unpin the pages under the transfer -- the call waits (bounded) and fails with EPPM_ERR_STATE, the registration stands, and after
+    eppm_compute_end it succeeds."""
+    import ctypes as C
+    import eppm_amd
+    from eppm_amd import synth
+    L = eppm_amd.lib()
+    h, w = 96, 128
+    a, b, _, _ = synth.make_pair(h, w, seed=4, max_flow=5.0)
+    uv = np.zeros((2, h, w), np.float32)
+    p = C.c_void_p(uv.ctypes.data)
+    assert L.eppm_host_register(p, C.c_size_t(uv.nbytes)) == 0
+    e = eppm_amd.EPPM()
+    e.init(a, b, h, w)
+    want = e.compute_flow()
+    e.compute_flow_begin(out=(uv[0], uv[1]))
+    assert L.eppm_host_unregister(p) == 3 and b"in flight" in L.eppm_last_error()          # EPPM_ERR_STATE
+    assert L.eppm_host_is_registered(p, C.c_size_t(uv.nbytes)) == 1
+    u, v = e.compute_flow_end(out=(uv[0], uv[1]))
+    assert L.eppm_host_unregister(p) == 0 and L.eppm_host_is_registered(p, C.c_size_t(uv.nbytes)) == 0
+    e.close()
+    assert np.array_equal(u, want[0]) and np.array_equal(v, want[1])
+
+
 def test_host_registration_is_counted():
     """eppm_host_register twice on one block (and once on a range inside it) = three owners: the block stays registered until the
     third eppm_host_unregister; a context computing into it in between is unaffected."""

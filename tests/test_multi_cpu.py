@@ -198,3 +198,42 @@ def test_ranks_agree_on_the_backend_when_the_probe_fails_on_one_rank(tmp_path):
         d = json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1])
         assert d == {"good": False, "none": True, "partial": True}, (r, d)
     assert "simulated RCCL failure" in outs[1][1] and "barrier and MAX go over gloo" in outs[0][1]
+
+
+def test_bench_input_plan_keeps_every_rank_inside_the_64_goldens():
+    """bench.InputPlan: the pairs a rank times are pairs (rank * P + j) mod 64 of BASELINE configs[2]'s 64 pairs, so that every flow of the
+    timed region has a committed oracle hash at any number of ranks (with 24 pairs in flight per rank, rank 3 of 8 would otherwise start
+    at pair 72); its config-3 share is pair i -> rank i mod N; another size or radius has no goldens and says so."""
+    import argparse
+    import bench
+    mk = lambda **kw: argparse.Namespace(**dict(dict(width=1024, height=436, patch_r=9, propagation=0), **kw))   # noqa: E731
+    seen = set()
+    for rank in range(8):
+        p = bench.InputPlan(mk(), rank, 8, 24, True, False)
+        assert p.man3 is not None and len(p.timed_idx) == 24 and all(0 <= i < 64 for i in p.timed_idx)
+        assert p.timed_idx[0] == (rank * 24) % 64
+        assert p.share3 == list(range(rank, 64, 8))
+        seen |= set(p.share3)
+        jobs = p._jobs()
+        assert len(jobs) == len(set(jobs)) and all(j[:2] == (436, 1024) and 1234 <= j[2] < 1298 for j in jobs)
+    assert seen == set(range(64))
+    p = bench.InputPlan(mk(), 0, 1, 24, False, True)
+    assert p.other == ["hd_1234", "uhd_r17_1234"] and (1080, 1920, 1234, 40.0) in p._jobs() and (2160, 3840, 1234, 60.0) in p._jobs()
+    for odd in (dict(width=640, height=480), dict(patch_r=17), dict(propagation=1)):
+        q = bench.InputPlan(mk(**odd), 0, 1, 24, True, False)
+        assert q.man3 is None and q.why_unverifiable and q.share3 == [] and q.verify_timed([], []) == [0, 0, 0]
+
+
+def test_synth_cache_and_worker_processes_reproduce_the_generator(tmp_path, monkeypatch):
+    """eppm_amd.synth.make_pairs_parallel (worker processes filling a file cache) returns exactly what make_pair generates, from a cold and
+    from a warm cache; the goldens are tied to the generator's exact output."""
+    import numpy as np
+    from eppm_amd import synth
+    monkeypatch.setenv("EPPM_SYNTH_CACHE", str(tmp_path / "cache"))
+    jobs = [(48, 64, 5, 6.0), (40, 72, 6, 4.0), (48, 64, 5, 6.0)]
+    want = [synth.make_pair(*j[:2], seed=j[2], max_flow=j[3]) for j in jobs]
+    for attempt in range(2):
+        got = synth.make_pairs_parallel(jobs, workers=2)
+        for g, w_ in zip(got, want):
+            assert all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(g, w_)), attempt
+    assert len(list((tmp_path / "cache").iterdir())) == 2

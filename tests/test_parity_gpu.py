@@ -96,7 +96,7 @@ def test_patchmatch_substages(S, O, L1):
     for it in range(3):
         for d in range(4):
             # both forms of the sweep on the same state: classic, and speculative (phase A + phase B; the context path uses it
-            # from the fourth iteration on, here it also meets the first iterations' many accepted candidates)
+            # from the third iteration on (EPPM_SPEC_FROM_ITER = 2), here it also meets the first iterations' many accepted candidates)
             spec = {}
             for mode in (1, 2):         # 1: phase B walks the chains phase A listed (work list); 2: phase B walks every chain
                 try:

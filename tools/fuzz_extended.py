@@ -30,7 +30,7 @@ def main():
             h, w, _ = a.shape
             want = O.compute_flow(a, b, O.default_params(**params))
             rev = O.compute_flow(b, a, O.default_params(**params))
-            for mode in (-1, 1):
+            for mode in (-1, 1, 2):          # library default, speculative with the work list, speculative without it
                 L.eppm_test_set_option(b"sweep_spec", mode)
                 try:
                     e = eppm_amd.EPPM(params=eppm_amd.Params(**params))

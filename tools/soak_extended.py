@@ -22,7 +22,7 @@ def main():
     NP, NB, K = 16, 8, 3
     pairs, want = [], []
     for i in range(NP):
-        a, b, _, _ = synth.make_pair(h, w, seed=man["seed0"] + i)
+        a, b, _, _ = synth.make_pair_cached(h, w, seed=man["seed0"] + i)
         pa, pb = eppm_amd.pinned_empty((h, w, 3)), eppm_amd.pinned_empty((h, w, 3))
         pa[:], pb[:] = a, b
         pairs.append((pa, pb))

@@ -187,6 +187,11 @@ def worker(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the HIP runtime starts: RCCL needs dmabuf IPC on this pool
+    # stdout carries the ONE JSON line and nothing else: gloo and RCCL print connection banners on stdout (every rank's, merged under
+    # torch.distributed.run), so file descriptor 1 points at stderr for the life of the rank and the line is written to the saved one
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     verify3 = (world > 1) if args.verify_config3 is None else bool(args.verify_config3)
     other_cfgs = world == 1 and not args.no_extras and not args.no_other_configs and (args.width, args.height, args.patch_r, args.propagation) == (W, H, 9, 0)
     S = max(1, args.inflight)
@@ -212,19 +217,10 @@ def worker(args):
 
         def probe_rccl():
             import datetime
-            # RCCL prints its version banner on STDOUT when the first communicator comes up (or fails to): stdout carries the ONE JSON
-            # line and nothing else, so file descriptor 1 points at stderr while the communicator is created
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
-                probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe, group=g)          # communicators are created lazily: fail here, not inside the timed region
-                torch.cuda.synchronize()
-            finally:
-                os.dup2(saved, 1)
-                os.close(saved)
+            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe, group=g)          # communicators are created lazily: fail here, not inside the timed region
+            torch.cuda.synchronize()
             if int(probe.item()) != world:
                 raise RuntimeError(f"all_reduce probe returned {probe.item()} for {world} ranks")
             return g
@@ -455,7 +451,7 @@ def worker(args):
                 out["other_configs"] = other_configs(plan, local_rank, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

@@ -184,7 +184,12 @@ extern "C" int eppm_host_unregister(void* p)
     auto al = g_reg_alias.find(base);
     auto it = g_reg.find(base);
     if (al != g_reg_alias.end()) { it = g_reg.find(al->second); g_reg_alias.erase(al); }
-    if (it == g_reg.end() || it->second.owned) return set_err(EPPM_ERR_ARG, "eppm_host_unregister: not a block registered with eppm_host_register");
+    if (it == g_reg.end()) return set_err(EPPM_ERR_ARG, "eppm_host_unregister: not a block registered with eppm_host_register");
+    if (it->second.owned) {          // a range inside eppm_host_alloc memory was registered on top: drop that owner; the block itself goes with eppm_host_free
+        if (it->second.refs <= 1) return set_err(EPPM_ERR_ARG, "eppm_host_unregister: a block from eppm_host_alloc is released with eppm_host_free");
+        it->second.refs--;
+        return EPPM_OK;
+    }
     if (--it->second.refs > 0) return EPPM_OK;          // another owner still holds the registration
     // last owner: wait for the transfers in flight on the block (a context of another thread between its look-up and the end of its
     // copy); bounded, so that unregistering under one's own pending eppm_compute_begin_into is an error and not a deadlock

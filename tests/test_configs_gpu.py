@@ -328,6 +328,10 @@ def test_host_registration_is_counted():
     u1, v1 = e.compute_flow()
     assert L.eppm_host_unregister(p) == 0 and L.eppm_host_is_registered(p, C.c_size_t(blk.nbytes)) == 0
     assert L.eppm_host_unregister(p) != 0                       # no owner left
+    q = eppm_amd.pinned_empty((64,), np.uint8)                  # eppm_host_alloc memory counts as registered; a registration on top is one more owner
+    qp = C.c_void_p(q.ctypes.data)
+    assert L.eppm_host_register(qp, C.c_size_t(64)) == 0 and L.eppm_host_unregister(qp) == 0
+    assert L.eppm_host_unregister(qp) != 0 and L.eppm_host_is_registered(qp, C.c_size_t(64)) == 1      # the allocation itself goes with eppm_host_free
     e.set_data(blk[0], blk[1])                                  # through the staging buffers now
     u2, v2 = e.compute_flow()
     e.close()

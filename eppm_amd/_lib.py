@@ -35,6 +35,7 @@ SYMBOLS = [
     "eppm_host_register", "eppm_host_unregister", "eppm_host_is_registered", "eppm_host_alloc", "eppm_host_free",
     "eppm_compute_begin_into", "eppm_batch_compute_begin_into",
     "eppm_load_ppm", "eppm_ppm_size", "eppm_save_flo", "eppm_load_flo", "eppm_flo_size", "eppm_flow_error",
+    "eppm_flow_error_border", "eppm_flow_error_percentage", "eppm_flow_cutoff", "eppm_flow_to_color_host",
 ]
 
 

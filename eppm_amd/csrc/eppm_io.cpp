@@ -110,13 +110,15 @@ extern "C" int eppm_load_flo(const char* filename, float* u, float* v, int h, in
     return EPPM_OK;
 }
 
-// basic/bao_flow_tools.cpp:64-111 (border = 0): a pixel counts when the ground truth is non-zero and known
-extern "C" int eppm_flow_error(const float* u, const float* v, const float* gu, const float* gv, int h, int w, float* epe, float* aae)
+// basic/bao_flow_tools.cpp:64-111: a pixel counts when the ground truth is non-zero and known; `border` pixels on every side are left out
+extern "C" int eppm_flow_error_border(const float* u, const float* v, const float* gu, const float* gv, int h, int w, int border, float* epe, float* aae)
 {
-    if (!u || !v || !gu || !gv || h <= 0 || w <= 0) return EPPM_ERR_ARG;
+    if (!u || !v || !gu || !gv || h <= 0 || w <= 0 || border < 0) return EPPM_ERR_ARG;
     int num_valid = 0;
     float total_angle = 0, total_epe = 0;
-    for (size_t i = 0; i < (size_t)h * w; i++) {
+    for (int y = border; y < h - border; y++)
+      for (int x = border; x < w - border; x++) {
+        const size_t i = (size_t)y * w + x;
         const float gtuu = gu[i], gtvv = gv[i];
         if ((fabs(gtuu) > 0 && fabs(gtuu) <= 1e9) || (fabs(gtvv) > 0 && fabs(gtvv) <= 1e9)) {
             num_valid++;
@@ -134,6 +136,98 @@ extern "C" int eppm_flow_error(const float* u, const float* v, const float* gu, 
     } else {
         if (aae) *aae = 0;
         if (epe) *epe = 0;
+    }
+    return EPPM_OK;
+}
+extern "C" int eppm_flow_error(const float* u, const float* v, const float* gu, const float* gv, int h, int w, float* epe, float* aae)
+{
+    return eppm_flow_error_border(u, v, gu, gv, h, w, 0, epe, aae);
+}
+
+// basic/bao_flow_tools.cpp:114-141: fraction of the pixels with a known ground truth whose end-point error exceeds error_thresh;
+// error_map (h*w bytes, or NULL): 255 where it does, 0 elsewhere
+extern "C" int eppm_flow_error_percentage(const float* u, const float* v, const float* gu, const float* gv, int h, int w, int error_thresh,
+                                          uint8_t* error_map, float* fraction)
+{
+    if (!u || !v || !gu || !gv || !fraction || h <= 0 || w <= 0) return EPPM_ERR_ARG;
+    if (error_map) memset(error_map, 0, (size_t)h * w);
+    int num_valid = 0, num_correct = 0;
+    for (size_t i = 0; i < (size_t)h * w; i++) {
+        const float gtuu = gu[i], gtvv = gv[i];
+        if (fabs(gtuu) <= 1e9 || fabs(gtvv) <= 1e9) {
+            num_valid++;
+            const float uu = u[i], vv = v[i];
+            const float epe_val = sqrt((uu - gtuu) * (uu - gtuu) + (vv - gtvv) * (vv - gtvv));
+            if (epe_val <= error_thresh) num_correct++;
+            else if (error_map) error_map[i] = 255;
+        }
+    }
+    *fraction = num_valid > 0 ? 1.0f - float(num_correct) / float(num_valid) : 0.0f;
+    return EPPM_OK;
+}
+
+// basic/bao_flow_tools.cpp:166-197: both components clamped to [-|cutoff|, |cutoff|]; unknown vectors (a component above 1e9 in
+// magnitude, flowIO.cpp:37-41) pass through unless cut_invalid is set
+extern "C" int eppm_flow_cutoff(float* u_out, float* v_out, const float* u, const float* v, int h, int w, int cutoff, int cut_invalid)
+{
+    if (!u_out || !v_out || !u || !v || h <= 0 || w <= 0) return EPPM_ERR_ARG;
+    const int c = (int)fabs((double)cutoff);
+    for (size_t i = 0; i < (size_t)h * w; i++) {
+        const float x = u[i], y = v[i];
+        if (!cut_invalid && (fabs(x) > 1e9 || fabs(y) > 1e9)) { u_out[i] = x; v_out[i] = y; continue; }
+        const float lx = (x < c) ? x : (float)c, ly = (y < c) ? y : (float)c;           // __min(val, cutoff), then __max(., -cutoff)
+        u_out[i] = (lx > -c) ? lx : (float)-c;
+        v_out[i] = (ly > -c) ? ly : (float)-c;
+    }
+    return EPPM_OK;
+}
+
+// Host colour coding of a flow field (basic/bao_flow_tools.cpp:200-231 on Middlebury's computeColor, colorcode.cpp:30-85): vectors are
+// scaled by the largest known radius of the field, unknown vectors are black; rgb: h*w*3 bytes, R,G,B.  (The device routine of the
+// optional color_flow output, k_color.hip, is the reference's CUDA port of the same wheel with a fixed scale.)
+namespace {
+struct Wheel {
+    int n = 0, c[60][3];
+    Wheel()
+    {
+        const int RY = 15, YG = 6, GC = 4, CB = 11, BM = 13, MR = 6;
+        auto put = [&](int r, int g, int b) { c[n][0] = r; c[n][1] = g; c[n][2] = b; n++; };
+        for (int i = 0; i < RY; i++) put(255, 255 * i / RY, 0);
+        for (int i = 0; i < YG; i++) put(255 - 255 * i / YG, 255, 0);
+        for (int i = 0; i < GC; i++) put(0, 255, 255 * i / GC);
+        for (int i = 0; i < CB; i++) put(0, 255 - 255 * i / CB, 255);
+        for (int i = 0; i < BM; i++) put(255 * i / BM, 0, 255);
+        for (int i = 0; i < MR; i++) put(255, 0, 255 - 255 * i / MR);
+    }
+};
+}  // namespace
+extern "C" int eppm_flow_to_color_host(uint8_t* rgb, const float* u, const float* v, int h, int w)
+{
+    if (!rgb || !u || !v || h <= 0 || w <= 0) return EPPM_ERR_ARG;
+    static const Wheel W;
+    float maxrad = -1;
+    for (size_t i = 0; i < (size_t)h * w; i++) {
+        const float fx = u[i], fy = v[i];
+        if (fabs(fx) > 1e9 || fabs(fy) > 1e9) continue;
+        const float rad = sqrt(fx * fx + fy * fy);
+        maxrad = (maxrad > rad) ? maxrad : rad;
+    }
+    for (size_t i = 0; i < (size_t)h * w; i++) {
+        uint8_t* o = rgb + i * 3;
+        if (fabs(u[i]) > 1e9 || fabs(v[i]) > 1e9) { o[0] = o[1] = o[2] = 0; continue; }
+        const float fx = u[i] / maxrad, fy = v[i] / maxrad;
+        const float rad = sqrt(fx * fx + fy * fy);
+        const float a = atan2(-fy, -fx) / M_PI;
+        const float fk = (a + 1.0f) / 2.0f * (W.n - 1);
+        const int k0 = (int)fk, k1 = (k0 + 1) % W.n;
+        const float f = fk - k0;
+        for (int b = 0; b < 3; b++) {
+            const float col0 = W.c[k0][b] / 255.0f, col1 = W.c[k1][b] / 255.0f;
+            float col = (1 - f) * col0 + f * col1;
+            if (rad <= 1) col = 1 - rad * (1 - col);
+            else col *= .75;
+            o[b] = (uint8_t)(int)(255.0 * col);            // computeColor writes B,G,R; bao_convert_flow_to_colorshow swaps to R,G,B
+        }
     }
     return EPPM_OK;
 }

@@ -299,8 +299,18 @@ int  eppm_ppm_size(const char* filename, int* h, int* w);
 int  eppm_save_flo(const char* filename, const float* u, const float* v, int h, int w);
 int  eppm_load_flo(const char* filename, float* u, float* v, int h, int w);
 int  eppm_flo_size(const char* filename, int* h, int* w);
-/* EPE / AAE with the reference's validity rule (basic/bao_flow_tools.cpp:64-111). */
+/* EPE / AAE with the reference's validity rule (basic/bao_flow_tools.cpp:64-111); _border: `border` pixels on every side left out. */
 int  eppm_flow_error(const float* u, const float* v, const float* gt_u, const float* gt_v, int h, int w, float* epe, float* aae);
+int  eppm_flow_error_border(const float* u, const float* v, const float* gt_u, const float* gt_v, int h, int w, int border, float* epe, float* aae);
+/* Fraction of the pixels with known ground truth whose end-point error exceeds error_thresh; error_map: h*w bytes (255 there) or
+ * NULL (bao_calc_flow_error_percentage, basic/bao_flow_tools.cpp:114-141). */
+int  eppm_flow_error_percentage(const float* u, const float* v, const float* gt_u, const float* gt_v, int h, int w, int error_thresh,
+                                uint8_t* error_map, float* fraction);
+/* Both components clamped to [-|cutoff|, |cutoff|]; unknown vectors pass through unless cut_invalid (bao_flow_cutoff, :166-197). */
+int  eppm_flow_cutoff(float* u_out, float* v_out, const float* u, const float* v, int h, int w, int cutoff, int cut_invalid);
+/* Host colour coding scaled by the field's largest known radius, unknown vectors black; rgb: h*w*3 bytes R,G,B
+ * (bao_convert_flow_to_colorshow, :200-231, on Middlebury's computeColor, 3rdparty/middlebury/colorcode.cpp:30-85). */
+int  eppm_flow_to_color_host(uint8_t* rgb, const float* u, const float* v, int h, int w);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,55 @@ void refio_flow_error(const float* u, const float* v, const float* gu, const flo
     bao_free(a); bao_free(b); bao_free(c); bao_free(d);
 }
 
+// bao_flow_tools.cpp:64-111 with a border
+void refio_flow_error_border(const float* u, const float* v, const float* gu, const float* gv, int h, int w, int border, float* epe, float* aae)
+{
+    float** a = bao_alloc<float>(h, w); float** b = bao_alloc<float>(h, w);
+    float** c = bao_alloc<float>(h, w); float** d = bao_alloc<float>(h, w);
+    memcpy(a[0], u, sizeof(float) * h * w); memcpy(b[0], v, sizeof(float) * h * w);
+    memcpy(c[0], gu, sizeof(float) * h * w); memcpy(d[0], gv, sizeof(float) * h * w);
+    float e = 0, g = 0;
+    bao_calc_flow_error(a, b, c, d, h, w, e, g, border, false);
+    *epe = e; *aae = g;
+    bao_free(a); bao_free(b); bao_free(c); bao_free(d);
+}
+
+// bao_flow_tools.cpp:114-141
+float refio_flow_error_percentage(const float* u, const float* v, const float* gu, const float* gv, int h, int w, int thresh, unsigned char* emap)
+{
+    float** a = bao_alloc<float>(h, w); float** b = bao_alloc<float>(h, w);
+    float** c = bao_alloc<float>(h, w); float** d = bao_alloc<float>(h, w);
+    unsigned char** m = emap ? bao_alloc<unsigned char>(h, w) : 0;
+    memcpy(a[0], u, sizeof(float) * h * w); memcpy(b[0], v, sizeof(float) * h * w);
+    memcpy(c[0], gu, sizeof(float) * h * w); memcpy(d[0], gv, sizeof(float) * h * w);
+    const float r = bao_calc_flow_error_percentage(a, b, c, d, h, w, thresh, m);
+    if (m) { memcpy(emap, m[0], (size_t)h * w); bao_free(m); }
+    bao_free(a); bao_free(b); bao_free(c); bao_free(d);
+    return r;
+}
+
+// bao_flow_tools.cpp:166-197
+void refio_flow_cutoff(float* uo, float* vo, const float* u, const float* v, int h, int w, int cutoff, int cut_invalid)
+{
+    float** a = bao_alloc<float>(h, w); float** b = bao_alloc<float>(h, w);
+    float** c = bao_alloc<float>(h, w); float** d = bao_alloc<float>(h, w);
+    memcpy(a[0], u, sizeof(float) * h * w); memcpy(b[0], v, sizeof(float) * h * w);
+    bao_flow_cutoff(c, d, a, b, h, w, cutoff, cut_invalid != 0);
+    memcpy(uo, c[0], sizeof(float) * h * w); memcpy(vo, d[0], sizeof(float) * h * w);
+    bao_free(a); bao_free(b); bao_free(c); bao_free(d);
+}
+
+// bao_flow_tools.cpp:200-231
+void refio_flow_to_color(unsigned char* rgb, const float* u, const float* v, int h, int w)
+{
+    float** a = bao_alloc<float>(h, w); float** b = bao_alloc<float>(h, w);
+    unsigned char*** c = bao_alloc<unsigned char>(h, w, 3);
+    memcpy(a[0], u, sizeof(float) * h * w); memcpy(b[0], v, sizeof(float) * h * w);
+    bao_convert_flow_to_colorshow(c, a, b, h, w);
+    memcpy(rgb, c[0][0], (size_t)h * w * 3);
+    bao_free(a); bao_free(b); bao_free(c);
+}
+
 // 3rdparty/middlebury/colorcode.cpp:61-85 -- the CPU routine the reference's device colour coding (basic/bao_basic_cuda.cuh:776-807)
 // is a port of; pix is B,G,R.  fx, fy already divided by the maximum radius.
 void refio_compute_color(float fx, float fy, unsigned char* pix) { computeColor(fx, fy, pix); }

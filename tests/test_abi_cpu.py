@@ -119,6 +119,82 @@ def test_epe_aae_equal_reference():
     assert e2 == epe.value and a2 == aae.value
 
 
+def _flow_fields(seed, shp=(37, 53)):
+    rng = np.random.default_rng(seed)
+    u, v, gu, gv = [(rng.standard_normal(shp) * 6).astype(np.float32) for _ in range(4)]
+    gu[0, :5] = 0; gv[0, :5] = 0                 # zero ground truth
+    gu[3, 7] = 1e10; gv[5, 9] = -1e10            # unknown ground truth in one component
+    gu[8, 8] = 1e10; gv[8, 8] = 1e10             # ... in both
+    u[10, 10] = 1e10; v[11, 11] = 2e9            # unknown estimated vectors
+    return u, v, gu, gv
+
+
+@needs_ref
+@pytest.mark.parametrize("border", [0, 1, 5, 18, 30])
+def test_flow_error_with_border_equals_reference(border):
+    """eppm_flow_error_border vs the reference's compiled bao_calc_flow_error (basic/bao_flow_tools.cpp:64-111), bit for bit, including
+    a border wider than half the image (no pixel counted: the outputs stay as passed in the reference, 0 here)."""
+    R = O.refio()
+    u, v, gu, gv = _flow_fields(11)
+    h, w = u.shape
+    epe, aae = C.c_float(0), C.c_float(0)
+    R.refio_flow_error_border(*[a.ctypes.data_as(C.c_void_p) for a in (u, v, gu, gv)], h, w, border, C.byref(epe), C.byref(aae))
+    assert eppm_amd.io.flow_error(u, v, gu, gv, border=border) == (epe.value, aae.value)
+
+
+@needs_ref
+@pytest.mark.parametrize("thresh", [0, 1, 3, 10])
+def test_flow_error_percentage_equals_reference(thresh):
+    """eppm_flow_error_percentage vs bao_calc_flow_error_percentage (:114-141): the fraction bit for bit, the error map byte for byte."""
+    R = O.refio()
+    R.refio_flow_error_percentage.restype = C.c_float
+    u, v, gu, gv = _flow_fields(12)
+    h, w = u.shape
+    m = np.full((h, w), 7, np.uint8)
+    want = R.refio_flow_error_percentage(*[a.ctypes.data_as(C.c_void_p) for a in (u, v, gu, gv)], h, w, thresh, m.ctypes.data_as(C.c_void_p))
+    got, gm = eppm_amd.io.flow_error_percentage(u, v, gu, gv, thresh, want_map=True)
+    assert got == want and np.array_equal(gm, m)
+    assert eppm_amd.io.flow_error_percentage(u, v, gu, gv, thresh) == want
+    allunk = np.full((h, w), 1e10, np.float32)
+    assert eppm_amd.io.flow_error_percentage(u, v, allunk, allunk, thresh) == 0.0
+
+
+@needs_ref
+@pytest.mark.parametrize("cutoff,cut_invalid", [(4, False), (4, True), (-7, False), (0, True), (1000, False)])
+def test_flow_cutoff_equals_reference(cutoff, cut_invalid):
+    """eppm_flow_cutoff vs bao_flow_cutoff (:166-197), bit for bit (negative cut-off values, unknown vectors kept or cut)."""
+    R = O.refio()
+    u, v, _, _ = _flow_fields(13)
+    h, w = u.shape
+    wu, wv = np.empty_like(u), np.empty_like(v)
+    R.refio_flow_cutoff(wu.ctypes.data_as(C.c_void_p), wv.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
+                        h, w, cutoff, int(cut_invalid))
+    gu_, gv_ = eppm_amd.io.flow_cutoff(u, v, cutoff, cut_invalid)
+    assert np.array_equal(gu_.view(np.uint32), wu.view(np.uint32)) and np.array_equal(gv_.view(np.uint32), wv.view(np.uint32))
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,scale", [(1, 6.0), (2, 0.01), (3, 300.0)])
+def test_host_flow_colour_coding_equals_reference(seed, scale):
+    """eppm_flow_to_color_host vs the reference's compiled bao_convert_flow_to_colorshow (:200-231) on Middlebury's computeColor
+    (3rdparty/middlebury/colorcode.cpp): byte for byte, unknown vectors black, scaled by the largest known radius."""
+    R = O.refio()
+    rng = np.random.default_rng(seed)
+    h, w = 61, 83
+    u = (rng.standard_normal((h, w)) * scale).astype(np.float32)
+    v = (rng.standard_normal((h, w)) * scale).astype(np.float32)
+    u[0, :] = 0; v[0, :] = np.linspace(-scale, scale, w, dtype=np.float32)       # axis-aligned vectors
+    v[1, :] = 0; u[1, :] = np.linspace(-scale, scale, w, dtype=np.float32)
+    u[2, 2] = v[2, 2] = 0
+    u[5, 5] = 1e10; v[6, 6] = -3e9
+    want = np.empty((h, w, 3), np.uint8)
+    R.refio_flow_to_color(want.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), h, w)
+    got = eppm_amd.io.flow_to_color(u, v)
+    bad = np.argwhere((got != want).any(axis=2))
+    assert len(bad) == 0, (len(bad), bad[:5], got[tuple(bad[0])] if len(bad) else None, want[tuple(bad[0])] if len(bad) else None)
+    assert (got[5, 5] == 0).all() and (got[6, 6] == 0).all()
+
+
 def test_reference_main_cpp_builds_unmodified_on_the_drop_in():
     """oracle/_ref/runeppm_ref = the reference's own main.cpp (+ its host-only I/O sources), compiled unmodified against
     include/ and linked with libeppm_hip.so (oracle/Makefile, target runeppm_ref).  Here: it was built and it resolves the

@@ -25,7 +25,7 @@ SYMBOLS = [
     "eppm_stage_times", "eppm_clear_stage_times", "eppm_enable_stage_timing", "eppm_last_error", "eppm_version",
     "eppm_device_count", "eppm_set_device", "eppm_malloc_device", "eppm_malloc_pitched", "eppm_free_device",
     "eppm_memcpy_h2d", "eppm_memcpy_d2h", "eppm_memcpy2d_h2d", "eppm_memcpy2d_d2h", "eppm_memset_device",
-    "eppm_device_synchronize", "eppm_device_mem_info", "eppm_set_launcher_stream", "eppm_set_launcher_params", "eppm_launcher_status",
+    "eppm_device_synchronize", "eppm_device_mem_info", "eppm_release_cached_memory", "eppm_set_launcher_stream", "eppm_set_launcher_params", "eppm_launcher_status",
     "baoCudaPatchMatchMultiscalePrepare", "baoCudaCensusTransform", "baoCudaPatchMatch", "baoCudaLeftRightCheck",
     "baoCudaOutlierRemoval", "baoCudaWeightedMedianFilter", "baoCudaFillHole", "baoCudaNNF2Flow", "baoCudaBLF_C2F",
     "baoCudaBLFCostFilterRefine", "baoCudaFlowSmoothing", "eppm_flow_to_color", "eppm_compute_color",

@@ -229,7 +229,9 @@ extern "C" int eppm_host_free(void* p)
 // ---------------------------------------------------------------------------------------------------
 // PatchMatch RNG object
 // ---------------------------------------------------------------------------------------------------
+namespace { struct RngTables; }
 struct eppm_pm_rng {
+    RngTables* tables = nullptr;       // shared, read-only (rngtab_acquire): init_tab, iter_tab, skip_mat point into it
     int device = 0, w = 0, h = 0, gx = 0, gy = 0, G = 0, per_lane = 0;
     unsigned long long seed = 0;
     uint32_t* init_tab = nullptr;
@@ -248,14 +250,38 @@ struct eppm_pm_rng {
     }
 };
 
-static int rng_create(eppm_pm_rng** out, int w, int h, const eppm_params& p, bool alloc_work = true)
+// The read-only tables of a generator -- every block's start states for the init draw and the first search, and the GF(2) skip matrix --
+// depend only on (device, w, h, num_guess, seed): building them walks every block's stream on the host (0.4 M draws at 1024x436) and
+// raises a 160x160 bit matrix to a power, 1.5 ms of the 3.3 ms a context takes to create.  Contexts of one geometry share one copy;
+// an entry nobody uses stays cached (a fresh object per pair is the window the reference's own demo times) until eight such pile up.
+namespace {
+struct RngTables {
+    int device, w, h, G;
+    unsigned long long seed;
+    uint32_t *init_tab = nullptr, *iter_tab = nullptr, *skip_mat = nullptr;
+    uint32_t skip_weyl = 0;
+    int per_lane = 0, refs = 0;
+    unsigned long long last_use = 0;
+};
+std::mutex g_rngtab_mu;
+std::vector<RngTables*> g_rngtab;
+unsigned long long g_rngtab_clock = 0;
+void rngtab_free(RngTables* t) { (void)hipFree(t->init_tab); (void)hipFree(t->iter_tab); (void)hipFree(t->skip_mat); delete t; }
+}  // namespace
+
+static int rngtab_acquire(RngTables** out, int device, int w, int h, const eppm_params& p)
 {
-    eppm_pm_rng* r = new eppm_pm_rng();
-    HIPCHK(hipGetDevice(&r->device));
-    r->w = w; r->h = h; r->G = p.num_guess; r->seed = p.seed;
-    r->gx = (w + kBlock - 1) / kBlock; r->gy = (h + kBlock - 1) / kBlock;
-    r->per_lane = 512 * r->G / 64;
-    const int nb = r->gx * r->gy;
+    std::lock_guard<std::mutex> lk(g_rngtab_mu);
+    for (RngTables* t : g_rngtab)
+        if (t->device == device && t->w == w && t->h == h && t->G == p.num_guess && t->seed == p.seed) {
+            t->refs++; t->last_use = ++g_rngtab_clock;
+            *out = t;
+            return EPPM_OK;
+        }
+    RngTables* t = new RngTables();
+    t->device = device; t->w = w; t->h = h; t->G = p.num_guess; t->seed = p.seed;
+    const int gx = (w + kBlock - 1) / kBlock, gy = (h + kBlock - 1) / kBlock, nb = gx * gy;
+    t->per_lane = 512 * t->G / 64;
     const size_t words = (size_t)nb * 64 * 6;
     std::vector<uint32_t> it(words), st(words);
     // walk every block's stream once: lane l of the init draw starts at draw 8*l, lane l of a search at
@@ -267,29 +293,66 @@ static int rng_create(eppm_pm_rng** out, int w, int h, const eppm_params& p, boo
             if ((q & 7) == 0) memcpy(&it[((size_t)b * 64 + (q >> 3)) * 6], &s, 24);
             xorwow_next(&s);
         }
-        for (int q = 0; q < 512 * r->G; q++) {
-            if (q % r->per_lane == 0) memcpy(&st[((size_t)b * 64 + q / r->per_lane) * 6], &s, 24);
+        for (int q = 0; q < 512 * t->G; q++) {
+            if (q % t->per_lane == 0) memcpy(&st[((size_t)b * 64 + q / t->per_lane) * 6], &s, 24);
             xorwow_next(&s);
         }
     }
-    const unsigned long long skip = (unsigned long long)(512 * r->G - r->per_lane);
+    const unsigned long long skip = (unsigned long long)(512 * t->G - t->per_lane);
     std::vector<uint32_t> mat(160 * 5);
     xorwow_skip_matrix(skip, mat.data());
-    r->skip_weyl = 362437u * (uint32_t)skip;
-    HIPCHK(hipMalloc(&r->init_tab, words * 4));
-    HIPCHK(hipMalloc(&r->iter_tab, words * 4));
+    t->skip_weyl = 362437u * (uint32_t)skip;
+    hipError_t e = hipMalloc(&t->init_tab, words * 4);
+    if (e == hipSuccess) e = hipMalloc(&t->iter_tab, words * 4);
+    if (e == hipSuccess) e = hipMalloc(&t->skip_mat, mat.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(t->init_tab, it.data(), words * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->iter_tab, st.data(), words * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->skip_mat, mat.data(), mat.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rngtab_free(t);
+        return set_err(EPPM_ERR_HIP, "generator tables: %s", hipGetErrorString(e));
+    }
+    t->refs = 1; t->last_use = ++g_rngtab_clock;
+    g_rngtab.push_back(t);
+    *out = t;
+    return EPPM_OK;
+}
+static void rngtab_release(RngTables* t)
+{
+    if (!t) return;
+    std::lock_guard<std::mutex> lk(g_rngtab_mu);
+    t->refs--;
+    // keep at most eight unused entries: drop the least recently used ones beyond that
+    for (;;) {
+        int idle = 0, oldest = -1;
+        for (int i = 0; i < (int)g_rngtab.size(); i++)
+            if (g_rngtab[i]->refs == 0) { idle++; if (oldest < 0 || g_rngtab[i]->last_use < g_rngtab[oldest]->last_use) oldest = i; }
+        if (idle <= 8) break;
+        rngtab_free(g_rngtab[oldest]);
+        g_rngtab.erase(g_rngtab.begin() + oldest);
+    }
+}
+
+static int rng_create(eppm_pm_rng** out, int w, int h, const eppm_params& p, bool alloc_work = true)
+{
+    eppm_pm_rng* r = new eppm_pm_rng();
+    HIPCHK(hipGetDevice(&r->device));
+    r->w = w; r->h = h; r->G = p.num_guess; r->seed = p.seed;
+    r->gx = (w + kBlock - 1) / kBlock; r->gy = (h + kBlock - 1) / kBlock;
+    const int tr = rngtab_acquire(&r->tables, r->device, w, h, p);
+    if (tr != EPPM_OK) { delete r; return tr; }
+    r->per_lane = r->tables->per_lane;
+    r->init_tab = r->tables->init_tab; r->iter_tab = r->tables->iter_tab; r->skip_mat = r->tables->skip_mat;
+    r->skip_weyl = r->tables->skip_weyl;
+    const size_t words = (size_t)r->gx * r->gy * 64 * 6;
     r->own_work = alloc_work;
-    if (alloc_work)
+    if (alloc_work) {       // (a context's states live in its slab and are set by k_pm_init_field at the start of every PatchMatch run)
         for (int k = 0; k < 2; k++)
             for (int q = 0; q < 2; q++) HIPCHK(hipMalloc(&r->work[k][q], words * 4));
-    HIPCHK(hipMalloc(&r->skip_mat, mat.size() * 4));
-    HIPCHK(hipMemcpy(r->init_tab, it.data(), words * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(r->iter_tab, st.data(), words * 4, hipMemcpyHostToDevice));
-    if (alloc_work) {       // (a context's states are set by k_pm_init_field at the start of every PatchMatch run)
-        HIPCHK(hipMemcpy(r->work[0][0], st.data(), words * 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(r->work[1][0], st.data(), words * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(r->work[0][0], r->iter_tab, words * 4, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(r->work[1][0], r->iter_tab, words * 4, hipMemcpyDeviceToDevice));
     }
-    HIPCHK(hipMemcpy(r->skip_mat, mat.data(), mat.size() * 4, hipMemcpyHostToDevice));
     *out = r;
     return EPPM_OK;
 }
@@ -297,12 +360,102 @@ static int rng_create(eppm_pm_rng** out, int w, int h, const eppm_params& p, boo
 static void rng_free(eppm_pm_rng* r)
 {
     if (!r) return;
-    (void)hipFree(r->init_tab); (void)hipFree(r->iter_tab);
     if (r->own_work)
         for (int k = 0; k < 2; k++)
             for (int q = 0; q < 2; q++) (void)hipFree(r->work[k][q]);
-    (void)hipFree(r->skip_mat);
+    rngtab_release(r->tables);
     delete r;
+}
+
+// A program in the reference's demo style makes a fresh object per pair: allocation is inside the window main.cpp times (:63-66).
+// hipMalloc of a 95 MB slab costs ~1 ms, hipFree ~3 ms (it drains the device), a pinned staging buffer ~0.3 ms.  Blocks a destroyed
+// context gives back are therefore kept -- a few, bounded in bytes -- and handed to the next context that asks for exactly that size.
+// Nothing depends on a block's contents: every plane is written before it is read (a fresh hipMalloc block is not zeroed either).
+#ifndef EPPM_MEM_CACHE
+#define EPPM_MEM_CACHE 1
+#endif
+namespace {
+struct CachedBlock { int device; bool pinned; size_t bytes; void* p; };
+std::mutex g_memcache_mu;
+std::vector<CachedBlock> g_memcache;
+constexpr size_t kMemCacheDeviceBytes = (size_t)3 << 30, kMemCachePinnedBytes = (size_t)512 << 20;
+constexpr int kMemCacheBlocks = 12;
+
+hipError_t cache_alloc(void** p, size_t bytes, bool pinned, int device)
+{
+    if (EPPM_MEM_CACHE) {
+        std::lock_guard<std::mutex> lk(g_memcache_mu);
+        for (size_t i = 0; i < g_memcache.size(); i++)
+            if (g_memcache[i].pinned == pinned && g_memcache[i].bytes == bytes && g_memcache[i].device == device) {
+                *p = g_memcache[i].p;
+                g_memcache.erase(g_memcache.begin() + i);
+                return hipSuccess;
+            }
+    }
+    hipError_t e = pinned ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes);
+    if (e != hipSuccess && EPPM_MEM_CACHE) {           // never let kept blocks cause a failure that would not happen without them
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lk(g_memcache_mu);
+            for (const CachedBlock& b : g_memcache) { if (b.pinned) (void)hipHostFree(b.p); else (void)hipFree(b.p); }
+            g_memcache.clear();
+        }
+        e = pinned ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes);
+    }
+    return e;
+}
+// the block must be idle (the caller has synchronised the stream that used it)
+void cache_free(void* p, size_t bytes, bool pinned, int device)
+{
+    if (!p) return;
+    if (EPPM_MEM_CACHE) {
+        std::lock_guard<std::mutex> lk(g_memcache_mu);
+        size_t held = 0;
+        int n = 0;
+        for (const CachedBlock& b : g_memcache) if (b.pinned == pinned) { held += b.bytes; n++; }
+        if (n < kMemCacheBlocks && held + bytes <= (pinned ? kMemCachePinnedBytes : kMemCacheDeviceBytes)) {
+            g_memcache.push_back(CachedBlock{device, pinned, bytes, p});
+            return;
+        }
+    }
+    if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
+}
+}  // namespace
+// Streams likewise: creating one costs about a millisecond (a hardware queue behind it), destroying one as much.  A destroyed context's
+// own stream -- idle: eppm_destroy synchronises it first -- goes to a small per-device pool.
+namespace {
+struct PooledStream { int device; hipStream_t s; };
+std::vector<PooledStream> g_streams;          // g_memcache_mu
+}
+static hipError_t pooled_stream_create(hipStream_t* out, int device)
+{
+    if (EPPM_MEM_CACHE) {
+        std::lock_guard<std::mutex> lk(g_memcache_mu);
+        for (size_t i = 0; i < g_streams.size(); i++)
+            if (g_streams[i].device == device) { *out = g_streams[i].s; g_streams.erase(g_streams.begin() + i); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+static void pooled_stream_destroy(hipStream_t s, int device)
+{
+    if (!s) return;
+#ifndef EPPM_EXPERIMENT_PM_LANE          // (that build's streams may carry CU masks: never pooled)
+    if (EPPM_MEM_CACHE) {
+        std::lock_guard<std::mutex> lk(g_memcache_mu);
+        if (g_streams.size() < 16) { g_streams.push_back(PooledStream{device, s}); return; }
+    }
+#endif
+    (void)hipStreamDestroy(s);
+}
+// gives every cached block back to the runtime (memory accounting, tests)
+extern "C" int eppm_release_cached_memory(void)
+{
+    std::lock_guard<std::mutex> lk(g_memcache_mu);
+    for (const CachedBlock& b : g_memcache) { if (b.pinned) (void)hipHostFree(b.p); else (void)hipFree(b.p); }
+    g_memcache.clear();
+    for (const PooledStream& p : g_streams) (void)hipStreamDestroy(p.s);
+    g_streams.clear();
+    return EPPM_OK;
 }
 
 // Kernel-variant switches of the parity tests (eppm_test_set_option).  The values below are only the DEFAULTS a context copies when it
@@ -358,6 +511,7 @@ struct eppm_ctx {
     // pinned staging for images / flows in memory the caller did NOT register (eppm_host_register), allocated on the first such
     // call; the image staging is double-buffered (an event per buffer marks its H2D done), so staging pair i+1 never waits for
     // the stream to drain
+    size_t slab_bytes = 0, h_rgb_bytes = 0, h_flow_bytes = 0;      // sizes of the cacheable blocks (cache_alloc / cache_free)
     uint8_t* h_rgb[2] = {nullptr, nullptr};   // each npairs x both frames
     hipEvent_t ev_rgb[2] = {nullptr, nullptr};
     hipEvent_t ev_h2d = nullptr;        // marks the DMA reads of registered caller images
@@ -424,20 +578,19 @@ extern "C" int eppm_destroy(eppm_ctx* c)
     clear_events(c, c->ev);
     clear_events(c, c->ev_prep);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-    (void)hipFree(c->slab);
-    (void)hipFree(c->lut_pm); (void)hipFree(c->lut_wmf); (void)hipFree(c->lut_blf);
+    cache_free(c->slab, c->slab_bytes, false, c->device);
     if (c->h_color) (void)hipHostFree(c->h_color);
     for (int q = 0; q < 2; q++) {
-        if (c->h_rgb[q]) (void)hipHostFree(c->h_rgb[q]);
+        cache_free(c->h_rgb[q], c->h_rgb_bytes, true, c->device);
         if (c->ev_rgb[q]) (void)hipEventDestroy(c->ev_rgb[q]);
     }
     if (c->ev_h2d) (void)hipEventDestroy(c->ev_h2d);
-    if (c->h_flow) (void)hipHostFree(c->h_flow);
+    cache_free(c->h_flow, c->h_flow_bytes, true, c->device);
     rng_free(c->rng);
     if (c->stream_pm) { (void)hipStreamSynchronize(c->stream_pm); (void)hipStreamDestroy(c->stream_pm); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream && c->stream) pooled_stream_destroy(c->stream, c->device);
     delete c;
     return EPPM_OK;
 }
@@ -446,6 +599,26 @@ static int upload_lut(float** dst, const std::vector<float>& v)
 {
     HIPCHK(hipMalloc(dst, v.size() * sizeof(float)));
     HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return EPPM_OK;
+}
+
+// The three look-up tables (a few hundred bytes, functions of the patch radius only) are uploaded once per (device, radius) and shared by
+// every context: three hipMalloc + three synchronous copies + three hipFree per context were a millisecond of the create / destroy pair.
+static int shared_luts(int device, int R, float** pm, float** wmf, float** blf)
+{
+    struct Entry { int device, R; float *pm, *wmf, *blf; };
+    static std::mutex mu;
+    static std::vector<Entry> tab;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Entry& e : tab)
+        if (e.device == device && e.R == R) { *pm = e.pm; *wmf = e.wmf; *blf = e.blf; return EPPM_OK; }
+    Entry e{device, R, nullptr, nullptr, nullptr};
+    std::vector<float> v;
+    host_pm_lut(R, v);  CHK(upload_lut(&e.pm, v));
+    host_wmf_lut(v);    CHK(upload_lut(&e.wmf, v));
+    host_blf_lut(v);    CHK(upload_lut(&e.blf, v));
+    tab.push_back(e);
+    *pm = e.pm; *wmf = e.wmf; *blf = e.blf;
     return EPPM_OK;
 }
 
@@ -504,12 +677,13 @@ static int ctx_alloc(eppm_ctx* c)
         for (int q = 0; q < 2; q++) plane((void**)&c->rng->work[k][q], rng_bytes);
     c->stride = (off + 4095) & ~(size_t)4095;
     // every texel plane is addressed with 32-bit byte offsets from ITS OWN base; the slab stride itself is 64-bit
-    HIPCHK(hipMalloc((void**)&c->slab, c->stride * c->npairs));
+    c->slab_bytes = c->stride * c->npairs;
+    {
+        const hipError_t e = cache_alloc((void**)&c->slab, c->slab_bytes, false, c->device);
+        if (e != hipSuccess) { (void)hipGetLastError(); return set_err(EPPM_ERR_HIP, "hipMalloc of %zu bytes (%d slab(s)) failed: %s", c->slab_bytes, c->npairs, hipGetErrorString(e)); }
+    }
     for (const Fix& f : fix) *f.dst = c->slab + f.off;
-    std::vector<float> v;
-    host_pm_lut(c->prm.patch_r, v);  CHK(upload_lut(&c->lut_pm, v));
-    host_wmf_lut(v);                 CHK(upload_lut(&c->lut_wmf, v));
-    host_blf_lut(v);                 CHK(upload_lut(&c->lut_blf, v));
+    CHK(shared_luts(c->device, c->prm.patch_r, &c->lut_pm, &c->lut_wmf, &c->lut_blf));
     c->out_u.assign(c->npairs, nullptr);
     c->out_v.assign(c->npairs, nullptr);
     return EPPM_OK;
@@ -558,7 +732,7 @@ extern "C" int eppm_create_batch(eppm_ctx** out, int h, int w, int device, const
         }
     }
 #else
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    e = pooled_stream_create(&c->stream, c->device);
 #endif
     if (e != hipSuccess) { delete c; return set_err(EPPM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->own_stream = true;
@@ -600,7 +774,7 @@ extern "C" int eppm_batch_size(const eppm_ctx* c) { return c ? c->npairs : 0; }
 extern "C" int eppm_set_stream(eppm_ctx* c, void* s)
 {
     if (!c) return set_err(EPPM_ERR_ARG, "NULL ctx");
-    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); pooled_stream_destroy(c->stream, c->device); }
     c->stream = (hipStream_t)s;
     c->own_stream = false;
     return EPPM_OK;
@@ -698,7 +872,8 @@ static int set_images_host_impl(eppm_ctx* c, int n, const uint8_t* const* rgb1, 
             if (!stage) {
                 const int q = c->rgb_cur;
                 if (!c->h_rgb[q]) {
-                    HIPCHK(hipHostMalloc((void**)&c->h_rgb[q], img * 2 * c->npairs, hipHostMallocDefault));
+                    c->h_rgb_bytes = img * 2 * c->npairs;
+                    HIPCHK(cache_alloc((void**)&c->h_rgb[q], c->h_rgb_bytes, true, c->device));
                     HIPCHK(hipEventCreateWithFlags(&c->ev_rgb[q], hipEventDisableTiming));
                 } else {
                     HIPCHK(hipEventSynchronize(c->ev_rgb[q]));      // the H2D that last read this buffer (two set_images ago)
@@ -966,7 +1141,10 @@ static int compute_begin(eppm_ctx* c, int n_out, float* const* u, float* const* 
             c->out_u[k] = du; c->out_v[k] = dv;
             continue;
         }
-        if (!c->h_flow) HIPCHK(hipHostMalloc((void**)&c->h_flow, n * 8 * c->npairs, hipHostMallocDefault));
+        if (!c->h_flow) {
+            c->h_flow_bytes = n * 8 * c->npairs;
+            HIPCHK(cache_alloc((void**)&c->h_flow, c->h_flow_bytes, true, c->device));
+        }
         HIPCHK(hipMemcpyAsync(c->h_flow + (size_t)k * n * 2, src, n * 8, hipMemcpyDeviceToHost, c->stream));
         c->out_u[k] = c->out_v[k] = nullptr;
     }

@@ -180,6 +180,9 @@ int  eppm_memset_device(void* p, int value, size_t bytes);
 int  eppm_device_synchronize(void);
 /* free / total memory of the current device (sizing the number of contexts in flight; leak checks) */
 int  eppm_device_mem_info(size_t* free_bytes, size_t* total_bytes);
+/* A destroyed context's slab and pinned staging buffers are kept (a few blocks, bounded in bytes) for the next context of the same size:
+ * allocation is inside the window the reference's demo times.  This gives them back to the runtime. */
+int  eppm_release_cached_memory(void);
 /* Stream used by the reference-signature launchers below (default: the null stream). */
 int  eppm_set_launcher_stream(void* hip_stream);
 /* Parameters used by the reference-signature launchers (default: defs.h values). */

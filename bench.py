@@ -451,7 +451,9 @@ def worker(args):
                 out["other_configs"] = other_configs(plan, local_rank, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h)
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        data = (json.dumps(out) + "\n").encode()
+        while data:
+            data = data[os.write(json_fd, data):]
     if world > 1:
         dist.destroy_process_group()
 

@@ -65,26 +65,32 @@ __device__ __forceinline__ float fast_exp(float x)
     return __builtin_ldexpf(p, (int)n);
 }
 
-// ---- x / c for a compile-time constant c, correctly rounded in 3 operations --------------------
-// q0 = x*rc; r = fma(-c,q0,x); q = fma(r,rc,q0).  Equal to the IEEE quotient for every x this path
-// produces; verified exhaustively on the CPU by tests/csrc/verify_divconst.c.
-__device__ __forceinline__ float div_const(float x, float c, float rc)
+// ---- x / c for a compile-time constant c, correctly rounded in 2 operations ---------------------
+// With zh = fl(1/c) and zl = fl(1/c - zh) (1/c in double):  q = fma(x, zh, fl(x*zl)).  Equal to the IEEE quotient x / c, which is what
+// the oracle computes, for EVERY float in [2^-30, 4] (and 0, and the negatives by symmetry) for c = .1f*.1f and c = .02f*.02f, and for
+// the integers 0..255 for c = 255: verified exhaustively on the CPU by tests/csrc/verify_divconst.c, sampled on the GPU
+// (test_div_const_bits).  Rounds 1-3 used a 3-operation form (q0 = x*rc; r = fma(-c,q0,x); q = fma(r,rc,q0)); the patch term has two of
+// these divisions, so this form takes it from 44 to 42 instructions.  The operand order matters: fma(x, zl, fl(x*zh)) is wrong for 7 %
+// of the inputs.
+struct DivConst { float zh, zl; };
+constexpr DivConst make_div_const(float c)
 {
-    const float q0 = x * rc;
-    const float r = __builtin_fmaf(-c, q0, x);
-    return __builtin_fmaf(r, rc, q0);
+    const double rc = 1.0 / (double)c;
+    const float zh = (float)rc;
+    return DivConst{zh, (float)(rc - (double)zh)};
 }
+__device__ __forceinline__ float div_const(float x, const DivConst d) { return __builtin_fmaf(x, d.zh, x * d.zl); }
 static_assert(kPmSigR2 == kLambdaAd2 && kBlfSigR2 == kWmfSigR2, "one helper per distinct constant");
 #ifdef EPPM_APPROX_EXP       // the opt-in tolerance build: the argument of the hardware exp needs no correctly rounded quotient either
 __device__ __forceinline__ float div_ad2(float x) { return x * (1.0f / kLambdaAd2); }
 __device__ __forceinline__ float div_wmf2(float x) { return x * (1.0f / kWmfSigR2); }
 #else
-__device__ __forceinline__ float div_ad2(float x) { return div_const(x, kLambdaAd2, 1.0f / kLambdaAd2); }   // also PM_SIG_R^2
-__device__ __forceinline__ float div_wmf2(float x) { return div_const(x, kWmfSigR2, 1.0f / kWmfSigR2); }    // also POSTPROC_BLF_SIG_R^2
+__device__ __forceinline__ float div_ad2(float x) { constexpr DivConst d = make_div_const(kLambdaAd2); return div_const(x, d); }   // also PM_SIG_R^2
+__device__ __forceinline__ float div_wmf2(float x) { constexpr DivConst d = make_div_const(kWmfSigR2); return div_const(x, d); }    // also POSTPROC_BLF_SIG_R^2
 #endif
 
 // unorm8 -> float exactly as c/255.0f (cudaReadModeNormalizedFloat)
-__device__ __forceinline__ float unorm8(float c) { return div_const(c, 255.0f, 1.0f / 255.0f); }
+__device__ __forceinline__ float unorm8(float c) { constexpr DivConst d = make_div_const(255.0f); return div_const(c, d); }
 
 struct rgbf { float x, y, z; };
 

@@ -104,7 +104,14 @@ struct PmRngDev {
     uint32_t skip_weyl;          // 362437 * (512*G - per_lane)
     int per_lane;                // draws per lane per search = 512*G/64
     int gx, gy;
+    // The numbers of search launch `it` of a run, drawn ahead: [block][G][512] int16 (the shorts the search stores in LDS); NULL: the
+    // search draws them itself from rng_work.  The block streams depend on (seed, geometry, num_guess) only -- the reference re-seeds on
+    // every call (kernel.cu:68, :160) -- so the numbers every PatchMatch run of a geometry draws are the same constants.
+    const int16_t* rand_tab = nullptr;
 };
+// fills tab[block][512*G] with the draws of ONE search launch from the lane states in `work` and advances `work` (in place) to the
+// next launch's position: exactly what wave G of k_pm_random_search does
+void launch_pm_rand_table(const PmRngDev& rng, uint32_t* work, int16_t* tab, int G, hipStream_t s);
 void launch_pm_init_field(const PmBatch& b, const PmRngDev& rng, hipStream_t s);
 void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t s);
 // one directional sweep; returns true when the result is in nnf_alt (caller swaps nnf/nnf_alt)

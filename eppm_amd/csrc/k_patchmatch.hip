@@ -910,7 +910,46 @@ void launch_pm_neighbor(const PmBatch& b, const float* lut, int R, hipStream_t s
 // pixels, the costs meet in LDS and wave 0 replays the reference's in-order strict-< selection.  The four
 // quarter-workgroups of a block draw the same numbers (cheap); only quarter 0 advances the stored state.
 // ---------------------------------------------------------------------------------------------------
-template <int RT, bool PK = false>
+// jump over the other 63 lanes' draws: v <- v * skip_mat over GF(2); Weyl counter by multiplication
+__device__ __forceinline__ void xorwow_skip(Xorwow& st, const uint32_t* __restrict__ skip_mat, uint32_t skip_weyl)
+{
+    const uint32_t v[5] = {st.v0, st.v1, st.v2, st.v3, st.v4};
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma unroll
+    for (int wd = 0; wd < 5; wd++) {
+        const uint32_t vw = v[wd];
+#pragma unroll 8
+        for (int b = 0; b < 32; b++) {
+            const uint32_t* row = skip_mat + (wd * 32 + b) * 5;
+            const uint32_t m = 0u - ((vw >> b) & 1u);
+            a0 ^= m & row[0]; a1 ^= m & row[1]; a2 ^= m & row[2]; a3 ^= m & row[3]; a4 ^= m & row[4];
+        }
+    }
+    st.v0 = a0; st.v1 = a1; st.v2 = a2; st.v3 = a3; st.v4 = a4;
+    st.d += skip_weyl;
+}
+
+// The draws of one search launch for every block, ahead of time (PmRngDev::rand_tab): one wave per 16x16 block does what wave G of
+// the search does -- lane l draws numbers [per_lane*l, per_lane*(l+1)) of the block's stream as shorts, then jumps its state over the
+// other lanes' draws -- and the states stay in `work` for the next launch's table.
+__global__ __launch_bounds__(64) void k_pm_rand_table(PmRngDev rng, uint32_t* __restrict__ work, int16_t* __restrict__ tab, int G)
+{
+    const int block_id = blockIdx.x, lane = threadIdx.x;
+    const size_t so = ((size_t)block_id * 64 + lane) * 6;
+    Xorwow st = load_state(work + so);
+    int16_t* __restrict__ out = tab + (size_t)block_id * 512 * G + rng.per_lane * lane;
+    for (int q = 0; q < rng.per_lane; q++) out[q] = (int16_t)xorwow_next(st);
+    xorwow_skip(st, rng.skip_mat, rng.skip_weyl);
+    store_state(work + so, st);
+}
+void launch_pm_rand_table(const PmRngDev& rng, uint32_t* work, int16_t* tab, int G, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pm_rand_table, dim3(rng.gx * rng.gy), dim3(64), 0, s, rng, work, tab, G);
+}
+
+// TAB: the launch's random numbers come from PmRngDev::rand_tab (drawn ahead, see above): no drawing wave, no state, no LDS copy of the
+// numbers -- a lane loads the two shorts of its pixel and guess -- and the workgroup is G waves instead of G + 1.
+template <int RT, bool PK = false, bool TAB = false>
 __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
                                                           int search_range, int G)
 {
@@ -918,10 +957,10 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT, TH = (RT == 0) ? 1 : 4 + 2 * RT;
     __shared__ float4 s_src[TW * TH];
     __shared__ LUT L;
-    __shared__ int16_t s_rand[8 * 512];
+    __shared__ int16_t s_rand[TAB ? 2 : 8 * 512];
     __shared__ float s_cost[8][64];
     __shared__ int s_guess[8][64];
-    __shared__ uint32_t s_state[64 * 6];
+    __shared__ uint32_t s_state[TAB ? 2 : 64 * 6];
     // problem = id mod nprob (one problem per XCD L2, see k_pm_sweep); the rest of the id walks the quarter-blocks row by row
     const unsigned nprob = B.n * B.npairs, bq = blockIdx.x % nprob, brest = blockIdx.x / nprob;
     const int bxx = brest % rng.gx, byy = brest / rng.gx;
@@ -930,7 +969,7 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     const int tile_y = byy >> 2, quarter = byy & 3;
     const int block_id = tile_y * rng.gx + bxx;
     load_patch_lut(L, lut, R, tid, blockDim.x);
-    if (tid < 64) {
+    if (!TAB && tid < 64) {
         const size_t so = ((size_t)block_id * 64 + tid) * 6;
         Xorwow st = load_state(pr.rng_work + so);
         const int base = rng.per_lane * tid;
@@ -947,28 +986,14 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     }
     __syncthreads();
     const int lane = tid & 63, k = tid >> 6;                     // wave k = guess k; wave G advances the RNG states
-    if (k == G) {
+    if (!TAB && k == G) {
         if (quarter == 0) {
-            // jump over the other 63 lanes' draws: v <- v * skip_mat over GF(2); Weyl counter by multiplication.
             // Off the critical path: this wave has nothing else to do, the other G waves are evaluating guesses.  (Round 3 tried
             // giving the jump to the last guess's wave after its evaluation -- six waves per workgroup, four workgroups per CU
             // instead of three: slower, 1.40 -> 1.46 ms PatchMatch for one pair, -0.4 % batched: the jump then ends the workgroup.)
             const size_t so = ((size_t)block_id * 64 + lane) * 6;
             Xorwow st = load_state(s_state + lane * 6);
-            const uint32_t v[5] = {st.v0, st.v1, st.v2, st.v3, st.v4};
-            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-#pragma unroll
-            for (int wd = 0; wd < 5; wd++) {
-                const uint32_t vw = v[wd];
-#pragma unroll 8
-                for (int b = 0; b < 32; b++) {
-                    const uint32_t* row = rng.skip_mat + (wd * 32 + b) * 5;
-                    const uint32_t m = 0u - ((vw >> b) & 1u);
-                    a0 ^= m & row[0]; a1 ^= m & row[1]; a2 ^= m & row[2]; a3 ^= m & row[3]; a4 ^= m & row[4];
-                }
-            }
-            st.v0 = a0; st.v1 = a1; st.v2 = a2; st.v3 = a3; st.v4 = a4;
-            st.d += rng.skip_weyl;
+            xorwow_skip(st, rng.skip_mat, rng.skip_weyl);
             store_state(pr.rng_work_next + so, st);
         }
     }
@@ -984,8 +1009,15 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     int gx = 0, gy = 0;
     bool evaluate = false;
     if (inimg) {
-        const uint32_t rdn1 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix];       // short -> unsigned int, :1558-1559
-        const uint32_t rdn2 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix + 1];
+        uint32_t rdn1, rdn2;                                                     // short -> unsigned int, :1558-1559
+        if (TAB) {
+            const uint32_t two = *reinterpret_cast<const uint32_t*>(rng.rand_tab + ((size_t)block_id * G + k) * 512 + 2 * pix);
+            rdn1 = (uint32_t)(int32_t)(int16_t)(two & 0xffffu);
+            rdn2 = (uint32_t)(int32_t)(int16_t)(two >> 16);
+        } else {
+            rdn1 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix];
+            rdn2 = (uint32_t)(int32_t)s_rand[512 * k + 2 * pix + 1];
+        }
         const int xmin = max(bx - mag, 0), xmax = min(bx + mag + 1, P.w + 1);
         const int ymin = max(by - mag, 0), ymax = min(by + mag + 1, P.h + 1);
         gx = (int)(int16_t)((uint32_t)xmin + rdn1 % (uint32_t)(xmax - xmin));
@@ -1025,6 +1057,14 @@ void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float*
                              hipStream_t s)
 {
     dim3 grid(rng.gx * rng.gy * 4 * b.n * b.npairs), block(64 * (num_guess + 1));      // + the wave that advances the RNG states
+    if (rng.rand_tab && (R == 9 || R == 17)) {                                         // numbers drawn ahead: G waves per workgroup
+        dim3 blockt(64 * num_guess);
+        const bool have_pc_t = b.p[0].P.pc2 && (b.n < 2 || b.p[1].P.pc2);
+        if (R == 9) hipLaunchKernelGGL((k_pm_random_search<9, false, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
+        else if (have_pc_t) hipLaunchKernelGGL((k_pm_random_search<17, true, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
+        else hipLaunchKernelGGL((k_pm_random_search<17, false, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
+        return;
+    }
 #ifndef EPPM_SEARCH_PK9_MAX_PIXELS
 #define EPPM_SEARCH_PK9_MAX_PIXELS 0           // radius 9: launches up to this many pixels gather the 4-byte target plane (measured: slower at every size)
 #endif

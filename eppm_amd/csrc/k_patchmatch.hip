@@ -122,12 +122,6 @@ __global__ __launch_bounds__(256) void k_pm_cost_field(PmBatch B, const float* _
     pr.cost[y * B.cpitch + x] = patch_dist(P, L, R, x, y, dx, dy);
 }
 
-void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t s)
-{
-    const int w = b.p[0].P.w, h = b.p[0].P.h;
-    dim3 grid((w + kBlock - 1) / kBlock, (h + kBlock - 1) / kBlock, b.n * b.npairs), block(kBlock, kBlock);
-    hipLaunchKernelGGL(k_pm_cost_field, grid, block, 0, s, b, lut, R);
-}
 
 // RT = 9 / 17: the source samples of the workgroup's 16x4 pixels come from an LDS tile (16+2R)x(4+2R), loaded once,
 // clamped at load -- one LDS read per sample instead of a clamped address and a gather; RT = 0: any radius, source
@@ -180,6 +174,42 @@ __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L
         }
     }
     return cost_sum / weight_sum;
+}
+
+// the cost field with the source samples of the 16x16 block from an LDS tile, as in the search and in phase A of the sweeps (radius 9 / 17)
+template <int RT>
+__global__ __launch_bounds__(256) void k_pm_cost_field_tile(PmBatch B, const float* __restrict__ lut, int R)
+{
+    using LUT = typename SearchLut<RT>::type;
+    constexpr int TW = kBlock + 2 * RT;
+    __shared__ float4 s_src[TW * TW];
+    __shared__ LUT L;
+    const int tid = threadIdx.y * kBlock + threadIdx.x;
+    load_patch_lut(L, lut, R, tid, 256);
+    const PmProblem pr = pm_problem(B, blockIdx.z);
+    const Planes P = to_dev(pr.P);
+    const int x0 = blockIdx.x * kBlock - RT, y0 = blockIdx.y * kBlock - RT;
+    for (int t = tid; t < TW * TW; t += 256) {
+        const int sy = iclamp(y0 + t / TW, 0, P.h - 1), sx = iclamp(x0 + t % TW, 0, P.w - 1);
+        s_src[t] = P.pk1[(unsigned)(sy * P.pitch + sx)];
+    }
+    __syncthreads();
+    const int x = blockIdx.x * kBlock + threadIdx.x, y = blockIdx.y * kBlock + threadIdx.y;
+    if (x >= P.w || y >= P.h) return;
+    const int dx = pr.nnf[(y * B.npitch + x) * 2], dy = pr.nnf[(y * B.npitch + x) * 2 + 1];
+    pr.cost[y * B.cpitch + x] = search_patch_dist<RT>(P, L, R, s_src, TW, threadIdx.x, threadIdx.y, x, y, dx, dy);
+}
+
+void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t s)
+{
+    const int w = b.p[0].P.w, h = b.p[0].P.h;
+    dim3 grid((w + kBlock - 1) / kBlock, (h + kBlock - 1) / kBlock, b.n * b.npairs), block(kBlock, kBlock);
+#ifndef EPPM_COST_FIELD_TILE
+#define EPPM_COST_FIELD_TILE 1
+#endif
+    if (EPPM_COST_FIELD_TILE && R == 9) hipLaunchKernelGGL(k_pm_cost_field_tile<9>, grid, block, 0, s, b, lut, R);
+    else if (EPPM_COST_FIELD_TILE && R == 17) hipLaunchKernelGGL(k_pm_cost_field_tile<17>, grid, block, 0, s, b, lut, R);
+    else hipLaunchKernelGGL(k_pm_cost_field, grid, block, 0, s, b, lut, R);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 // eppm_io.cpp -- file formats and error metrics of the reference's CLI path (main.cpp:56-69):
 // PPM reader (basic/bao_basic.cpp:137-218), Middlebury .flo (3rdparty/middlebury/flowIO.cpp:5-20,
 // :48-163), EPE/AAE (basic/bao_flow_tools.cpp:64-111).  No GPU code here.
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -171,7 +172,7 @@ extern "C" int eppm_flow_error_percentage(const float* u, const float* v, const 
 extern "C" int eppm_flow_cutoff(float* u_out, float* v_out, const float* u, const float* v, int h, int w, int cutoff, int cut_invalid)
 {
     if (!u_out || !v_out || !u || !v || h <= 0 || w <= 0) return EPPM_ERR_ARG;
-    const int c = (int)fabs((double)cutoff);
+    const int c = (cutoff == INT_MIN) ? INT_MAX : abs(cutoff);      // fabs(INT_MIN) does not fit an int: undefined in the reference, the largest cutoff here
     for (size_t i = 0; i < (size_t)h * w; i++) {
         const float x = u[i], y = v[i];
         if (!cut_invalid && (fabs(x) > 1e9 || fabs(y) > 1e9)) { u_out[i] = x; v_out[i] = y; continue; }
@@ -208,13 +209,17 @@ extern "C" int eppm_flow_to_color_host(uint8_t* rgb, const float* u, const float
     float maxrad = -1;
     for (size_t i = 0; i < (size_t)h * w; i++) {
         const float fx = u[i], fy = v[i];
-        if (fabs(fx) > 1e9 || fabs(fy) > 1e9) continue;
+        if (!(fabs(fx) <= 1e9) || !(fabs(fy) <= 1e9)) continue;
         const float rad = sqrt(fx * fx + fy * fy);
         maxrad = (maxrad > rad) ? maxrad : rad;
     }
+    // A field with no motion (maxrad 0) or no known vector (-1) divides 0 by 0 in the reference and indexes the wheel with (int)NaN --
+    // undefined there (a crash on x86); here the scale is 1 (Middlebury's own color_flow tool: "if (maxrad == 0) maxrad = 1"), and a
+    // vector with a NaN component is drawn black like an unknown one.
+    if (!(maxrad > 0)) maxrad = 1;
     for (size_t i = 0; i < (size_t)h * w; i++) {
         uint8_t* o = rgb + i * 3;
-        if (fabs(u[i]) > 1e9 || fabs(v[i]) > 1e9) { o[0] = o[1] = o[2] = 0; continue; }
+        if (!(fabs(u[i]) <= 1e9) || !(fabs(v[i]) <= 1e9)) { o[0] = o[1] = o[2] = 0; continue; }
         const float fx = u[i] / maxrad, fy = v[i] / maxrad;
         const float rad = sqrt(fx * fx + fy * fy);
         const float a = atan2(-fy, -fx) / M_PI;

@@ -312,7 +312,9 @@ int  eppm_flow_error_percentage(const float* u, const float* v, const float* gt_
 /* Both components clamped to [-|cutoff|, |cutoff|]; unknown vectors pass through unless cut_invalid (bao_flow_cutoff, :166-197). */
 int  eppm_flow_cutoff(float* u_out, float* v_out, const float* u, const float* v, int h, int w, int cutoff, int cut_invalid);
 /* Host colour coding scaled by the field's largest known radius, unknown vectors black; rgb: h*w*3 bytes R,G,B
- * (bao_convert_flow_to_colorshow, :200-231, on Middlebury's computeColor, 3rdparty/middlebury/colorcode.cpp:30-85). */
+ * (bao_convert_flow_to_colorshow, :200-231, on Middlebury's computeColor, 3rdparty/middlebury/colorcode.cpp:30-85).  Where the
+ * reference is undefined this is defined: a field with no motion or no known vector (largest radius 0: 0/0 there, then
+ * colorwheel[(int)NaN]) is scaled by 1 -- a static scene is white --, and a vector with a NaN component is black. */
 int  eppm_flow_to_color_host(uint8_t* rgb, const float* u, const float* v, int h, int w);
 
 #ifdef __cplusplus

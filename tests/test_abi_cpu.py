@@ -195,6 +195,27 @@ def test_host_flow_colour_coding_equals_reference(seed, scale):
     assert (got[5, 5] == 0).all() and (got[6, 6] == 0).all()
 
 
+def test_host_io_under_sanitizers(tmp_path):
+    """eppm_io.cpp (PPM / .flo readers, flow tools: no GPU code) under ASan + UBSan + float-cast checks: malformed and truncated
+    files, absurd header sizes, static / all-unknown / NaN flow fields, INT_MIN cutoff (tests/csrc/io_sanitize_driver.cpp)."""
+    exe = str(tmp_path / "io_san")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=all",
+                           os.path.join(ROOT, "tests", "csrc", "io_sanitize_driver.cpp"), os.path.join(ROOT, "eppm_amd", "csrc", "eppm_io.cpp"), "-o", exe])
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+def test_colour_coding_of_a_static_scene_is_white_not_a_crash():
+    """maxrad == 0 divides 0 by 0 in the reference (bao_flow_tools.cpp:229, then colorwheel[(int)NaN]): undefined there; here the
+    scale falls back to 1 as in Middlebury's color_flow tool, and NaN vectors are drawn black like unknown ones."""
+    from eppm_amd import io
+    z = np.zeros((6, 9), np.float32)
+    assert (io.flow_to_color(z, z) == 255).all()
+    u = z.copy(); u[2, 3] = np.nan; u[4, 4] = 3.0
+    rgb = io.flow_to_color(u, z)
+    assert (rgb[2, 3] == 0).all() and (rgb[0, 0] == 255).all() and not (rgb[4, 4] == 255).all()
+
+
 def test_reference_main_cpp_builds_unmodified_on_the_drop_in():
     """oracle/_ref/runeppm_ref = the reference's own main.cpp (+ its host-only I/O sources), compiled unmodified against
     include/ and linked with libeppm_hip.so (oracle/Makefile, target runeppm_ref).  Here: it was built and it resolves the

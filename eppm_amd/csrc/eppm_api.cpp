@@ -337,11 +337,12 @@ static int rngtab_acquire(RngTables** out, int device, int w, int h, const eppm_
 #ifndef EPPM_RAND_TABLE
 #define EPPM_RAND_TABLE 1
 #endif
+static std::atomic<int> g_rand_table{1};       // test switch "rand_table": 0 = contexts created afterwards draw while they search (the form above 512 MB)
 static const int16_t* rngtab_rand_table(RngTables* t, int iters, size_t* stride)
 {
     const int gx = (t->w + kBlock - 1) / kBlock, gy = (t->h + kBlock - 1) / kBlock, nb = gx * gy;
     *stride = (size_t)nb * 512 * t->G;
-    if (!EPPM_RAND_TABLE || iters < 1) return nullptr;
+    if (!EPPM_RAND_TABLE || iters < 1 || !g_rand_table.load()) return nullptr;
     std::lock_guard<std::mutex> lk(g_rngtab_mu);
     if (t->rand_iters >= iters) return t->rand_tab;
     const size_t bytes = *stride * 2 * (size_t)iters;
@@ -1608,6 +1609,7 @@ extern "C" int eppm_test_set_option(const char* name, int value)
     if (!name) return set_err(EPPM_ERR_ARG, "eppm_test_set_option: NULL name");
     if (!strcmp(name, "c2f_no_split")) { g_no_split.store(value); return EPPM_OK; }
     if (!strcmp(name, "sweep_spec")) { g_sweep_spec.store(value); return EPPM_OK; }
+    if (!strcmp(name, "rand_table")) { g_rand_table.store(value); return EPPM_OK; }
     return set_err(EPPM_ERR_ARG, "eppm_test_set_option: unknown option '%s'", name);
 }
 extern "C" int eppm_probe_c2f_window(int patch_r, int* span_x, int* span_y)

@@ -721,3 +721,28 @@ def test_no_device_memory_leak_over_create_destroy(crop):
     e = eppm_amd.EPPM(); e.init(a, b, 120, 160); u1, v1 = e.compute_flow(); e.close()       # and everything still works afterwards
     e = eppm_amd.EPPM(); e.init(a, b, 120, 160); u2, v2 = e.compute_flow(); e.close()
     assert np.array_equal(u1, u2) and np.array_equal(v1, v2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 3])
+def test_search_draws_in_context_when_no_table(frames, batch):
+    """A context whose geometry would need more than 512 MB of numbers drawn ahead searches with the drawing wave and per-pair generator
+    states instead (k_pm_random_search<.., TAB = false>, the default of rounds 1-3): forced here with the "rand_table" switch, single
+    and batch context, == the oracle bit for bit, and == a context with the table."""
+    import eppm_amd
+    from oracle import oracle as O
+    a, b = frames
+    region = (slice(60, 300), slice(100, 500))
+    a, b = np.ascontiguousarray(a[region]), np.ascontiguousarray(b[region])
+    L = eppm_amd.lib()
+    ou, ov = O.compute_flow(a, b)
+    try:
+        assert L.eppm_test_set_option(b"rand_table", 0) == 0
+        if batch == 1:
+            e = eppm_amd.EPPM(); e.init(*a.shape[:2]); e.set_data(a, b); flows = [e.compute_flow()]; e.close()
+        else:
+            e = eppm_amd.EPPMBatch(a.shape[0], a.shape[1], batch); e.set_data([(a, b)] * batch); flows = e.compute_flow(); e.close()
+    finally:
+        L.eppm_test_set_option(b"rand_table", 1)
+    for u, v in flows:
+        eq(u, ou, "u, streaming search"); eq(v, ov, "v, streaming search")

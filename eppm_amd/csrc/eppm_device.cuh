@@ -51,7 +51,7 @@ __device__ __forceinline__ float fast_exp(float x)
     // v_mul, v_rndne, v_sub, 5 x v_fma, v_cvt, v_ldexp.  (Forming rint(y) with the 1.5*2^23 constant and reading the
     // exponent from the mantissa bits trades the half-rate v_rndne/v_cvt for three full-rate instructions; measured
     // 2.5 % slower in the refine kernel: the instruction count is what costs, tools/microbench/valu_rate.hip.)
-#ifdef EPPM_APPROX_EXP       // measurement-only build (tools/gpu_approx_exp.sh): the hardware v_exp_f32, NOT the shared formula
+#ifdef EPPM_APPROX_EXP       // the opt-in tolerance build (make approx): the hardware v_exp_f32, NOT the shared formula
     return __builtin_amdgcn_exp2f(x * 0x1.715476p+0f);
 #endif
     const float y = x * 0x1.715476p+0f;

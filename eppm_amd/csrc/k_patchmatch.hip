@@ -1095,16 +1095,12 @@ void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float*
         else hipLaunchKernelGGL((k_pm_random_search<17, false, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
         return;
     }
-#ifndef EPPM_SEARCH_PK9_MAX_PIXELS
-#define EPPM_SEARCH_PK9_MAX_PIXELS 0           // radius 9: launches up to this many pixels gather the 4-byte target plane (measured: slower at every size)
-#endif
+    // (radius 9 gathers the float4 plane: the 4-byte plane's conversions cost it more than the narrower gathers save, at every size)
 #ifndef EPPM_SEARCH_PK17
 #define EPPM_SEARCH_PK17 1
 #endif
     const bool have_pc = b.p[0].P.pc2 && (b.n < 2 || b.p[1].P.pc2);
-    const long long pixels = (long long)b.n * b.npairs * b.p[0].P.w * b.p[0].P.h;
-    if (R == 9 && have_pc && pixels <= EPPM_SEARCH_PK9_MAX_PIXELS) hipLaunchKernelGGL((k_pm_random_search<9, true>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
-    else if (R == 17 && have_pc && EPPM_SEARCH_PK17) hipLaunchKernelGGL((k_pm_random_search<17, true>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+    if (R == 17 && have_pc && EPPM_SEARCH_PK17) hipLaunchKernelGGL((k_pm_random_search<17, true>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else if (R == 9) hipLaunchKernelGGL(k_pm_random_search<9>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else if (R == 17) hipLaunchKernelGGL(k_pm_random_search<17>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else hipLaunchKernelGGL(k_pm_random_search<0>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);

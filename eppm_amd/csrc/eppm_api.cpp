@@ -509,7 +509,7 @@ extern "C" int eppm_release_cached_memory(void)
 
 // Kernel-variant switches of the parity tests (eppm_test_set_option).  The values below are only the DEFAULTS a context copies when it
 // is created (eppm_ctx::opt_*) and what the context-less stage launchers read; a context in use is never affected by a later call.
-static std::atomic<int> g_sweep_spec{-1};      // "sweep_spec": -1 by iteration, 0 never, 1 always, 2 always and without the work list
+static std::atomic<int> g_sweep_spec{-1};      // "sweep_spec": -1 by iteration, 0 never, 1 always, 2 always and without the work list, 3 always in the merged form
 static std::atomic<int> g_no_split{0};         // "c2f_no_split"
 
 // ---------------------------------------------------------------------------------------------------
@@ -547,6 +547,7 @@ struct eppm_ctx {
     float *spec1 = nullptr, *spec2 = nullptr;   // evaluation cache of the sweeps (PmProblem::spec / scand): four direction planes each
     int32_t *scand1 = nullptr, *scand2 = nullptr;
     uint32_t *wl1 = nullptr, *wl2 = nullptr;    // work lists of the speculative sweeps (PmProblem::wl)
+    int16_t *seed1 = nullptr, *seed2 = nullptr; // merged form: the field before each direction's sweep (PmProblem::seed), four planes each
     uint32_t* wmf_ws = nullptr;        // work lists + counters of the weighted median
     bool flow_pending = false;         // eppm_compute_begin issued, eppm_compute_end not yet
     float *flow[kMaxLevels] = {}, *flow_tmp[kMaxLevels] = {};
@@ -716,6 +717,8 @@ static int ctx_alloc(eppm_ctx* c)
     plane((void**)&c->scand2, n2 * 4 * 4);
     plane((void**)&c->wl1, pm_worklist_words(c->W[L], c->H[L], c->prm.seg_len) * 4);
     plane((void**)&c->wl2, pm_worklist_words(c->W[L], c->H[L], c->prm.seg_len) * 4);
+    plane((void**)&c->seed1, n2 * 4 * 4);
+    plane((void**)&c->seed2, n2 * 4 * 4);
     plane((void**)&c->wmf_ws, wmf_workspace_words(c->W[L], c->H[L], c->prm.wmf_iters) * 4);
     plane((void**)&c->d_rgb, (size_t)h * w * 3 * 2);
     plane((void**)&c->d_color, (size_t)h * w * 4);
@@ -1005,10 +1008,10 @@ extern "C" int eppm_batch_set_images_device(eppm_ctx* c, int n, const void* cons
 
 // ---- baoCudaPatchMatch (kernel.cu:1760-1826) for one problem or for the forward+backward pair at once ----
 static PmProblem mk_problem(const PlanesH& P, float* cost, int16_t* nnf, int16_t* nnf_alt, eppm_pm_rng* rng, int k, float* spec = nullptr,
-                            int32_t* scand = nullptr, uint32_t* wl = nullptr)
+                            int32_t* scand = nullptr, uint32_t* wl = nullptr, int16_t* seed = nullptr)
 {
     PmProblem p;
-    p.P = P; p.cost = cost; p.nnf = nnf; p.nnf_alt = nnf_alt; p.spec = spec; p.scand = scand; p.wl = wl;
+    p.P = P; p.cost = cost; p.nnf = nnf; p.nnf_alt = nnf_alt; p.spec = spec; p.scand = scand; p.wl = wl; p.seed = seed;
     p.rng_work = rng ? rng->work[k][rng->cur[k]] : nullptr;
     p.rng_work_next = rng ? rng->work[k][rng->cur[k] ^ 1] : nullptr;
     return p;
@@ -1045,6 +1048,16 @@ static bool sweep_speculative(int iteration, long long pixels, int m)
 {
     return m < 0 ? (iteration >= EPPM_SPEC_FROM_ITER && pixels >= EPPM_SPEC_MIN_PIXELS) : m != 0;
 }
+// From this iteration on the four speculative sweeps share ONE phase A (k_patchmatch.hip, k_pm_spec_all: the merged form): the field has
+// converged far enough that a phase-A launch costs its launch, and four of them per iteration are three too many.  Mode 3 of the test
+// switch forces the merged form from the first iteration.
+#ifndef EPPM_MERGED_FROM_ITER
+#define EPPM_MERGED_FROM_ITER 5
+#endif
+static bool sweeps_merged(int iteration, long long pixels, int m)
+{
+    return m == 3 || (m < 0 && EPPM_MERGED_FROM_ITER >= 0 && iteration >= EPPM_MERGED_FROM_ITER && sweep_speculative(iteration, pixels, m));
+}
 // one directional sweep on the batch; keeps the result in p[k].nnf (swaps the ping-pong pair when needed)
 static void sweep(PmBatch& b, const float* lut, const eppm_params& prm, int dir, hipStream_t s, bool speculative = false)
 {
@@ -1077,7 +1090,11 @@ static void run_patchmatch(PmBatch& b, eppm_pm_rng* rng, const float* lut, const
     for (int it = 0; it < prm.num_iter; it++) {
         if (prm.propagation == 1) jump(b, lut, prm, s);
         else if (prm.propagation == 2) neighbor(b, lut, prm, 10, s);
-        else for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s, sweep_speculative(it, (long long)b.n * b.npairs * b.p[0].P.w * b.p[0].P.h, spec_mode));
+        else {
+            const long long pixels = (long long)b.n * b.npairs * b.p[0].P.w * b.p[0].P.h;
+            if (sweeps_merged(it, pixels, spec_mode) && launch_pm_sweeps_merged(b, lut, prm.patch_r, prm.seg_len, it, s)) { /* in place */ }
+            else for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s, sweep_speculative(it, pixels, spec_mode));
+        }
         search(b, rng, lut, prm, s, it);
     }
 }
@@ -1103,12 +1120,13 @@ static int compute_all(eppm_ctx* c)
         PmBatch b;
         b.n = 2; b.cpitch = lw; b.npitch = lw; b.npairs = bt.n; b.stride = bt.stride;
         b.cache_plane = (size_t)lw * lh;
+        b.seed_plane = (size_t)lw * lh * 2;
         b.wl_units = pm_worklist_units(lw, lh, c->prm.seg_len);
 #ifndef EPPM_SWEEP_CACHE
 #define EPPM_SWEEP_CACHE 1
 #endif
-        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0, c->spec1, EPPM_SWEEP_CACHE ? c->scand1 : nullptr, sweep_list_on(c->opt_sweep_spec) ? c->wl1 : nullptr);     // driver :223
-        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1, c->spec2, EPPM_SWEEP_CACHE ? c->scand2 : nullptr, sweep_list_on(c->opt_sweep_spec) ? c->wl2 : nullptr);     // driver :224
+        b.p[0] = mk_problem(planes(c, L, false), c->cost1, c->nnf1, c->nnf_tmp, c->rng, 0, c->spec1, EPPM_SWEEP_CACHE ? c->scand1 : nullptr, sweep_list_on(c->opt_sweep_spec) ? c->wl1 : nullptr, c->seed1);     // driver :223
+        b.p[1] = mk_problem(planes(c, L, true), c->cost2, c->nnf2, c->nnf_tmp2, c->rng, 1, c->spec2, EPPM_SWEEP_CACHE ? c->scand2 : nullptr, sweep_list_on(c->opt_sweep_spec) ? c->wl2 : nullptr, c->seed2);     // driver :224
         run_patchmatch(b, c->rng, c->lut_pm, c->prm, s, c->opt_sweep_spec);
     }
     stage_end(c, c->ev);

@@ -79,6 +79,9 @@ struct PmProblem {
     // [16, 16 + units): stamp per unit (two adjacent segments of a line) = 1 + number of the last sweep that listed it;
     // [16 + units, 16 + 2 * units): the list.  NULL: phase B walks every chain.
     uint32_t* wl = nullptr;
+    // Merged form of the speculative sweeps (k_patchmatch.hip, k_pm_spec_all): the field as it stood before each direction's sweep of the
+    // current iteration, four short2 planes (direction d at int16 offset d * PmBatch::seed_plane) -- where the in-place sweeps read their seeds.
+    int16_t* seed = nullptr;
     uint32_t* rng_work;       // [nblocks][64][6] XORWOW lane states read by the random search
     uint32_t* rng_work_next;  // ... written by it (ping-pong: four workgroups read each block's state, one advances it)
 };
@@ -91,10 +94,14 @@ struct PmBatch {
     size_t cache_plane = 0;   // elements per direction plane of PmProblem::spec / scand
     int wl_units = 0;         // capacity of PmProblem::wl (pm_worklist_units)
     int sweep_seq = 0;        // number of the next sweep of this PatchMatch run (0, 1, ..): launch_pm_sweep counts
+    size_t seed_plane = 0;    // int16 elements per direction plane of PmProblem::seed
+    int merged_it = 0;        // merged form: number of the iteration (list parity, stamps)
+    int seg_len = 0, nseg_row = 0, nseg_col = 0;   // merged form: the sweeps' geometry (every kernel lists for every direction)
 };
 // units (pairs of adjacent segments of a line) of the larger of the row and column sweeps; words of PmProblem::wl
 int pm_worklist_units(int w, int h, int seg_len);
-inline size_t pm_worklist_words(int w, int h, int seg_len) { return 16 + 2 * (size_t)pm_worklist_units(w, h, seg_len); }
+// words of PmProblem::wl: 16 counters | stamps, list of the two-launch form (units each) | stamps, lists of the merged form (4 x units each)
+inline size_t pm_worklist_words(int w, int h, int seg_len) { return 16 + 10 * (size_t)pm_worklist_units(w, h, seg_len); }
 // RNG tables shared by both problems (same seed, same block ids: the reference re-initialises the states on
 // every baoCudaPatchMatch call, kernel.cu:160); see xorwow_host.cpp
 struct PmRngDev {
@@ -117,6 +124,9 @@ void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t
 // one directional sweep; returns true when the result is in nnf_alt (caller swaps nnf/nnf_alt)
 // speculative: the two-launch form for iterations in which few candidates are accepted (k_patchmatch.hip, k_pm_sweep_spec); same results
 bool launch_pm_sweep(PmBatch& b, const float* lut, int R, int seg_len, int dir, hipStream_t s, bool speculative = false);
+// The four sweeps of one iteration in the merged speculative form (k_pm_spec_all + four in-place launches over the listed chains): same
+// results, in place in nnf.  Returns false (nothing launched) when the problems lack the planes or the radius has no instantiation.
+bool launch_pm_sweeps_merged(PmBatch& b, const float* lut, int R, int seg_len, int iteration, hipStream_t s);
 // one jump-flood launch (step = neighbour distance); reads nnf, writes nnf_alt (caller swaps)
 void launch_pm_jump(const PmBatch& b, const float* lut, int R, int step, hipStream_t s);
 // one 4-neighbour propagation launch (d_neighbor_propagate); reads nnf, writes nnf_alt (caller swaps)

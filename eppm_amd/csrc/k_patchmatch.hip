@@ -47,6 +47,7 @@ __device__ __forceinline__ PmProblem pm_problem(const PmBatch& B, unsigned q)
     p.spec = pair_ptr_opt(p.spec, B.stride, pair);
     p.scand = pair_ptr_opt(p.scand, B.stride, pair);
     p.wl = pair_ptr_opt(p.wl, B.stride, pair);
+    p.seed = pair_ptr_opt(p.seed, B.stride, pair);
     p.rng_work = pair_ptr_opt(p.rng_work, B.stride, pair);
     p.rng_work_next = pair_ptr_opt(p.rng_work_next, B.stride, pair);
     return p;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(64) void k_pm_init_field(PmBatch B, PmRngDev rng)
     for (int k = 0; k < 6; k++) pr.rng_work[so + k] = rng.iter_tab[so + k];
     // a new run: sweep numbers start at 0 again, so the work list's lengths and stamps do
     if (pr.wl)
-        for (int wi = block_id * 64 + lane; wi < 16 + B.wl_units; wi += rng.gx * rng.gy * 64) pr.wl[wi] = 0u;
+        for (int wi = block_id * 64 + lane; wi < 16 + 6 * B.wl_units; wi += rng.gx * rng.gy * 64) pr.wl[wi] = 0u;
 }
 
 void launch_pm_init_field(const PmBatch& b, const PmRngDev& rng, hipStream_t s)
@@ -290,6 +291,20 @@ __device__ __forceinline__ float coop_patch_dist(const Planes& P, const LUT& L, 
 // lines themselves (patch centres), hold every source texel the workgroup's patches can touch.  They are staged in LDS once,
 // clamped at load; the source half of the sample gathers then never reaches the L1 (which these launches load to 60 % at one
 // 16-byte lane-fetch per clock, tools/ubench/gather_rate.hip).  TW = tile row length (odd: spreads a chain's ds_read_b128 over the banks).
+// ---- merged form of the speculative sweeps: lists and stamps of all four directions live side by side --------------------------
+// PmProblem::wl beyond the two-launch form's words: counters wl[8 + 4 * (iteration & 1) + d]; stamps [16 + 2U + d U, ..) = 1 + the
+// iteration that listed the unit last; lists [16 + 6U + d U, ..).  d: 0 row forward, 1 column forward, 2 row reverse, 3 column reverse.
+// Lists the unit (segments 2u, 2u + 1 of its line) whose chains visit pixel (px, py) in direction d, once per iteration.
+__device__ __forceinline__ void merged_list_unit(uint32_t* __restrict__ wl, const PmBatch& B, int d, int px, int py)
+{
+    const bool row = (d & 1) == 0;
+    const int along = row ? px : py, ln = row ? py : px, nseg = row ? B.nseg_row : B.nseg_col;
+    const unsigned seg = (d < 2 && along < B.seg_len) ? 0u : (unsigned)(along / B.seg_len);
+    const unsigned unit = (unsigned)ln * ((unsigned)(nseg + 1) >> 1) + (seg >> 1), U = (unsigned)B.wl_units, seq1 = (unsigned)B.merged_it + 1u;
+    if (atomicMax(&wl[16 + 2 * U + d * U + unit], seq1) < seq1)
+        wl[16 + 6 * U + d * U + atomicAdd(&wl[8 + 4 * (B.merged_it & 1) + d], 1u)] = unit;
+}
+
 template <int LPC> struct SweepTile { static constexpr int CPB = 256 / LPC, SEGS = (CPB >= 16) ? 4 : 2, LINES = CPB / SEGS; };
 
 // SPEC: phase B of the speculative form (see k_pm_sweep_spec below): a step that follows a rejection takes its cost from
@@ -299,10 +314,16 @@ template <int LPC> struct SweepTile { static constexpr int CPB = 256 / LPC, SEGS
 // fill the chip (one 1024x436 pair): once the field has converged nearly every step is answered by the evaluation cache, and what a
 // step then waits for is the round trip of its own loads -- 1.3 us per step, ten steps deep; fetched up front they cost one round trip.
 constexpr int kSpecMaxSteps = 16;
-template <int R, int LPC, bool IS_ROW, bool REVERSE, bool TILE, bool SPEC = false, bool PRE = SPEC>
+// MERGED (classic form, PRE, no tile): one of the four in-place launches of the merged speculative form (k_pm_spec_all below): the
+// workgroup's chains are listed units of this direction, seeds come from PmProblem::seed (the field as it stood before this sweep), a
+// step's cost comes from the evaluation cache when the cache holds its candidate and is evaluated otherwise, only accepted candidates are
+// written (in place: a pixel is written by its own visitors only), and an accepted candidate is passed on to the later directions of the
+// iteration: their seed planes, and the unit of the pixel whose candidate it changes.
+template <int R, int LPC, bool IS_ROW, bool REVERSE, bool TILE, bool SPEC = false, bool PRE = SPEC, bool MERGED = false>
 __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, const float* __restrict__ lut, int L_, int nseg, int nseg_pad, int TW)
 {
     static_assert(PRE || !SPEC, "phase B fetches its chains' pixels up front");
+    static_assert(!MERGED || (PRE && !SPEC && !TILE), "the merged form's sweeps are the classic form with up-front fetches, without a tile");
     // SPEC with a work list (pr.wl): the workgroup's CPB chains are CPB / 2 listed units (a unit = segments 2u, 2u + 1 of a line, so
     // that segments 0 and 1 -- the two visitors of pixel L -- always sit in one workgroup); a workgroup past the end of the list
     // returns at once.  Chains that are not listed keep their pixels: phase A has copied the whole field to the output plane.
@@ -321,11 +342,13 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
     const unsigned nprob = B.n * B.npairs, bq = blockIdx.x % nprob, bxx = blockIdx.x / nprob;
     const PmProblem pr = pm_problem(B, bq);
     const Planes P = to_dev(pr.P);
-    const int16_t* __restrict__ nin = pr.nnf;
-    int16_t* __restrict__ nout = pr.nnf_alt;
+    // (MERGED reads and writes one plane: no __restrict__ on either pointer then)
+    typename std::conditional<MERGED, const int16_t*, const int16_t* __restrict__>::type nin = pr.nnf;
+    typename std::conditional<MERGED, int16_t*, int16_t* __restrict__>::type nout = MERGED ? pr.nnf : pr.nnf_alt;
     float* __restrict__ cost = pr.cost;
     // this direction's planes of the evaluation cache (eppm_internal.h: PmProblem::spec / scand)
     constexpr int DIR = IS_ROW ? (REVERSE ? 2 : 0) : (REVERSE ? 3 : 1);
+    const int16_t* __restrict__ seeds = MERGED ? pr.seed + DIR * B.seed_plane : nullptr;
     float* __restrict__ cval = pr.spec ? pr.spec + DIR * B.cache_plane : nullptr;
     int32_t* __restrict__ ccand = pr.scand ? pr.scand + DIR * B.cache_plane : nullptr;
     const int len = IS_ROW ? P.w : P.h, lines = IS_ROW ? P.h : P.w;
@@ -345,12 +368,12 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
         seg = chain % nseg_pad;
     }
     bool listed = true;
-    if (SPEC && pr.wl) {
-        const uint32_t nlist = pr.wl[B.sweep_seq & 1];
+    if ((SPEC && pr.wl) || MERGED) {
+        const uint32_t nlist = MERGED ? pr.wl[8 + 4 * (B.merged_it & 1) + DIR] : pr.wl[B.sweep_seq & 1];
         if (bxx * (CPB / 2) >= nlist) return;                         // (uniform over the workgroup, before any barrier)
         const unsigned slot = bxx * CPB + grp, upl = (unsigned)(nseg + 1) >> 1;
         listed = (slot >> 1) < nlist;
-        const unsigned unit = listed ? pr.wl[16 + B.wl_units + (slot >> 1)] : 0u;
+        const unsigned unit = listed ? pr.wl[(MERGED ? 16 + (6 + DIR) * B.wl_units : 16 + B.wl_units) + (slot >> 1)] : 0u;
         line = (int)(unit / upl);
         seg = (int)(unit % upl) * 2 + (int)(slot & 1);
     }
@@ -382,10 +405,10 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
     int px = 0, py = 0;
     if (active) {
         const int sidx = IS_ROW ? (line * B.npitch + start) : (start * B.npitch + line);
-        px = nin[sidx * 2];
-        py = nin[sidx * 2 + 1];
+        px = MERGED ? seeds[sidx * 2] : nin[sidx * 2];
+        py = MERGED ? seeds[sidx * 2 + 1] : nin[sidx * 2 + 1];
         // the one pixel of the line no chain visits keeps its value
-        const bool copier = (REVERSE ? (seg == nseg - 1) : (seg == 0)) && !(SPEC && pr.wl);     // (work list: phase A copied every pixel)
+        const bool copier = (REVERSE ? (seg == nseg - 1) : (seg == 0)) && !(SPEC && pr.wl) && !MERGED;     // (work list: phase A copied every pixel; merged: in place)
         if (copier && r == 0) {
             const int u = REVERSE ? len - 1 : 0;
             const int uidx = IS_ROW ? (line * B.npitch + u) : (u * B.npitch + line);
@@ -519,10 +542,21 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
                     nout[nidx * 2] = (int16_t)px;
                     nout[nidx * 2 + 1] = (int16_t)py;
                     cost[cidx] = cv;
+                    if (MERGED) {
+                        // the later sweeps of this iteration start from the field this sweep leaves: their seeds, and the chain whose
+                        // candidate at the next pixel in THEIR direction has just changed
+#pragma unroll
+                        for (int d2 = DIR + 1; d2 < 4; d2++) {
+                            int16_t* sd = pr.seed + d2 * B.seed_plane;
+                            sd[nidx * 2] = (int16_t)px; sd[nidx * 2 + 1] = (int16_t)py;
+                            const int qx = (d2 == 2) ? x - 1 : x, qy = (d2 == 1) ? y + 1 : (d2 == 3) ? y - 1 : y;
+                            if (qx >= 0 && qy >= 0 && qx < P.w && qy < P.h) merged_list_unit(pr.wl, B, d2, qx, qy);
+                        }
+                    }
                 }
                 from_nin = false;
             } else {
-                if (r == 0 && !second_visit) {
+                if (r == 0 && !second_visit && !MERGED) {
                     nout[nidx * 2] = (int16_t)ox;
                     nout[nidx * 2 + 1] = (int16_t)oy;
                 }
@@ -665,6 +699,121 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
     cval[py * B.cpitch + px] = cv;
     if (ccand) ccand[py * B.cpitch + px] = e;
     if (wl && cv < pr.cost[py * B.cpitch + px]) list_unit(px, py);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Merged form: ONE phase A for the four sweeps of an iteration (late iterations: nearly every candidate is answered by the cache, and
+// what a phase-A launch then costs is the launch).  From the field F0 the iteration starts with, for every pixel and every direction d the
+// rejection-path candidate shift_d(F0[i - 1_d]) is tested exactly as k_pm_sweep_spec tests it (skip rule, cache, evaluation) and the unit
+// is listed when the candidate would be accepted against the pixel's cost.  The four sweeps then run as in-place launches over their lists
+// (k_pm_sweep<.., MERGED>).  Why the lists stay complete although sweeps 1..3 see a field the earlier sweeps have changed:
+//  * a chain leaves the rejection path first at a pixel i whose candidate shift_d(F[i - 1_d]) is accepted.  If pixel i - 1_d still holds its
+//    F0 match, that candidate is the one tested here, against a cost that can only have fallen since: listed.  If an earlier sweep of the
+//    iteration changed pixel i - 1_d, that sweep listed the unit of pixel i for direction d when it accepted (k_pm_sweep, MERGED);
+//  * the cache answers by candidate, so an entry written here for a candidate the field no longer proposes is simply not used;
+//  * seeds: PmProblem::seed[d] = F0 here, kept current by the earlier sweeps' accepted candidates, never by sweep d itself.
+// ---------------------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(256) void k_pm_spec_all(PmBatch B, const float* __restrict__ lut, int R, int gx)
+{
+    using LUT = typename SearchLut<RT>::type;
+    constexpr int TW = kBlock + 2 * RT;
+    __shared__ float4 s_src[TW * TW];
+    __shared__ LUT L;
+    __shared__ uint16_t s_list[1024];      // compacted work: pixel index inside the block | direction << 8
+    __shared__ int s_cand[1024];           // its candidate, x | y << 16
+    __shared__ int s_wcount[16];           // [direction][wave]
+    const unsigned nprob = B.n * B.npairs, bq = blockIdx.x % nprob, brest = blockIdx.x / nprob;
+    const int bxx = brest % gx, byy = brest / gx;
+    const PmProblem pr = pm_problem(B, bq);
+    const Planes P = to_dev(pr.P);
+    uint32_t* __restrict__ wl = pr.wl;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x = bxx * kBlock + (tid & 15), y = byy * kBlock + (tid >> 4);
+    if (blockIdx.x < nprob && tid < 4) wl[8 + 4 * ((B.merged_it + 1) & 1) + tid] = 0u;      // the next iteration's list lengths
+    unsigned needmask = 0;
+    int cpack[4] = {0, 0, 0, 0};
+    if (x < P.w && y < P.h) {
+        const int ni = (y * B.npitch + x) * 2, ci = y * B.cpitch + x;
+        const uint32_t* __restrict__ nnf32 = reinterpret_cast<const uint32_t*>(pr.nnf);       // a match as one word: x | y << 16
+        const uint32_t own = nnf32[ni >> 1];
+        const int ox = (int)(int16_t)(own & 0xffffu), oy = (int)(int16_t)(own >> 16);
+        const float c0 = pr.cost[ci];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            reinterpret_cast<uint32_t*>(pr.seed + d * B.seed_plane)[ni >> 1] = own;
+            const int qx = (d == 0) ? x - 1 : (d == 2) ? x + 1 : x, qy = (d == 1) ? y - 1 : (d == 3) ? y + 1 : y;
+            if (qx >= 0 && qy >= 0 && qx < P.w && qy < P.h) {
+                const uint32_t qm = nnf32[qy * B.npitch + qx];
+                int cx = (int)(int16_t)(qm & 0xffffu), cy = (int)(int16_t)(qm >> 16);
+                if (d == 0) cx = min(cx + 1, P.w - 1);
+                else if (d == 1) cy = min(cy + 1, P.h - 1);
+                else if (d == 2) cx = max(cx - 1, 0);
+                else cy = max(cy - 1, 0);
+                const int cp = (cx & 0xffff) | (cy << 16);
+                bool need = !(cx == ox && cy == oy);                             // equal to the pixel's own match: rejected unevaluated
+                if (need && pr.scand[d * B.cache_plane + ci] == cp) {            // evaluated before: the cost stands
+                    need = false;
+                    if (pr.spec[d * B.cache_plane + ci] < c0) merged_list_unit(wl, B, d, x, y);
+                }
+                if (need) { needmask |= 1u << d; cpack[d] = cp; }
+            }
+        }
+    }
+    unsigned long long bal[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        bal[d] = __ballot((needmask >> d) & 1u);
+        if (lane == 0) s_wcount[d * 4 + wv] = __popcll(bal[d]);
+    }
+    __syncthreads();
+    int total = 0, base[4];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if ((k & 3) == 0) base[k >> 2] = total;              // start of direction k/4 ...
+        const int c = s_wcount[k];
+        if ((k & 3) < wv) base[k >> 2] += c;                 // ... plus the lower waves of that direction
+        total += c;
+    }
+    if (total == 0) return;
+    load_patch_lut(L, lut, R, tid, 256);
+    {
+        const int x0 = bxx * kBlock - RT, y0 = byy * kBlock - RT;
+        for (int t = tid; t < TW * TW; t += 256) {
+            const int sy = iclamp(y0 + t / TW, 0, P.h - 1), sx = iclamp(x0 + t % TW, 0, P.w - 1);
+            s_src[t] = P.pk1[(unsigned)(sy * P.pitch + sx)];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; d++)
+        if ((needmask >> d) & 1u) {
+            const int slot = base[d] + __popcll(bal[d] & ((1ull << lane) - 1ull));
+            s_list[slot] = (uint16_t)(tid | (d << 8));
+            s_cand[slot] = cpack[d];
+        }
+    __syncthreads();                          // table, tile, list
+    if (RT == 17 && total <= EPPM_SPEC_COOP17_MAX) {          // few evaluations: a wave each (see k_pm_sweep_spec)
+        for (int slot = tid >> 6; slot < total; slot += 4) {
+            const int pix = (int)s_list[slot] & 255, d = (int)s_list[slot] >> 8, e = s_cand[slot];
+            const int px = bxx * kBlock + (pix & 15), py = byy * kBlock + (pix >> 4), ci = py * B.cpitch + px;
+            const float cv = coop_patch_dist<(RT == 17 ? 17 : 1), 64>(P, L, s_src, TW, pix & 15, pix >> 4, (int)(int16_t)(e & 0xffff), e >> 16, tid & 63);
+            if ((tid & 63) == 0) {
+                pr.spec[d * B.cache_plane + ci] = cv;
+                pr.scand[d * B.cache_plane + ci] = e;
+                if (cv < pr.cost[ci]) merged_list_unit(wl, B, d, px, py);
+            }
+        }
+        return;
+    }
+    for (int slot = tid; slot < total; slot += 256) {
+        const int pix = (int)s_list[slot] & 255, d = (int)s_list[slot] >> 8, e = s_cand[slot];
+        const int tx = pix & 15, ty = pix >> 4;
+        const int px = bxx * kBlock + tx, py = byy * kBlock + ty, ci = py * B.cpitch + px;
+        const float cv = search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16);
+        pr.spec[d * B.cache_plane + ci] = cv;
+        pr.scand[d * B.cache_plane + ci] = e;
+        if (cv < pr.cost[ci]) merged_list_unit(wl, B, d, px, py);
+    }
 }
 
 // Fallback for patch radii without a cooperative instantiation: the reference's one-thread-per-chain form,
@@ -840,6 +989,44 @@ bool launch_pm_sweep(PmBatch& b, const float* lut, int R, int seg_len, int dir, 
         default: hipLaunchKernelGGL((k_pm_seg_propagate<false, true>), grid, block, 0, s, b, lut, R, seg_len, nseg, lpb); break;
     }
     return false;
+}
+
+template <int R, int LPC>
+static void launch_sweep_merged(const PmBatch& b, const float* lut, int seg_len, int dir, hipStream_t s)
+{
+    const PlanesH& P = b.p[0].P;
+    const bool is_row = (dir == 0 || dir == 2);
+    const int len = is_row ? P.w : P.h, lines = is_row ? P.h : P.w;
+    const int nseg = (len + seg_len - 1) / seg_len, nseg_pad = (nseg + 1) & ~1;
+    constexpr int CPB = 256 / LPC;
+    const int wgs = (lines * nseg_pad + CPB - 1) / CPB;
+    dim3 grid(wgs * (b.n * b.npairs)), block(256);
+    switch (dir) {
+        case 0: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, false, false, false, true, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad, 0); break;
+        case 1: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, false, false, false, true, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad, 0); break;
+        case 2: hipLaunchKernelGGL((k_pm_sweep<R, LPC, true, true, false, false, true, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad, 0); break;
+        default: hipLaunchKernelGGL((k_pm_sweep<R, LPC, false, true, false, false, true, true>), grid, block, 0, s, b, lut, seg_len, nseg, nseg_pad, 0); break;
+    }
+}
+bool launch_pm_sweeps_merged(PmBatch& b, const float* lut, int R, int seg_len, int iteration, hipStream_t s)
+{
+    for (int k = 0; k < b.n; k++)
+        if (!b.p[k].seed || !b.p[k].wl || !b.p[k].spec || !b.p[k].scand) return false;
+    if (!(R == 9 || R == 17) || seg_len > kSpecMaxSteps || seg_len < 1) return false;
+    const int w = b.p[0].P.w, h = b.p[0].P.h, gx = (w + kBlock - 1) / kBlock, gy = (h + kBlock - 1) / kBlock;
+    b.merged_it = iteration;
+    b.seg_len = seg_len;
+    b.nseg_row = (w + seg_len - 1) / seg_len;
+    b.nseg_col = (h + seg_len - 1) / seg_len;
+    dim3 grid(gx * gy * (b.n * b.npairs)), block(256);
+    if (R == 9) hipLaunchKernelGGL(k_pm_spec_all<9>, grid, block, 0, s, b, lut, R, gx);
+    else hipLaunchKernelGGL(k_pm_spec_all<17>, grid, block, 0, s, b, lut, R, gx);
+    for (int dir = 0; dir < 4; dir++) {
+        if (R == 9) launch_sweep_merged<9, EPPM_LPC9_SPEC>(b, lut, seg_len, dir, s);
+        else launch_sweep_merged<17, EPPM_LPC17_SPEC>(b, lut, seg_len, dir, s);
+        b.sweep_seq++;
+    }
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -418,7 +418,7 @@ def test_sweep_and_search_parameter_extremes(frames, params):
     eq(u, ou, f"u {params}"); eq(v, ov, f"v {params}")
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("params,region", [
     (dict(), (slice(40, 231), slice(100, 421))),
     (dict(seg_len=16, num_iter=5), (slice(40, 231), slice(100, 421))),        # the longest segments phase B takes (16 lanes per chain)
@@ -432,7 +432,9 @@ def test_speculative_sweeps_forced_on_and_off(frames, params, region, mode):
     """The speculative two-launch sweeps (phase A evaluates every pixel's rejection-path candidate in parallel, phase B walks
     the chains) against the classic dependent-step kernel: forced for EVERY iteration (mode 1: also the first ones, where most
     steps follow an accepted candidate and phase B evaluates; with the work list -- phase B walks only the chains on which phase A
-    found a candidate that would be accepted -- and, mode 2, without it) and forced off (mode 0), all == the oracle bit for bit."""
+    found a candidate that would be accepted -- and, mode 2, without it; mode 3: the merged form, ONE phase A for the four sweeps of an
+    iteration and four in-place launches over their lists, also from the first iteration, where nearly every chain is listed and the
+    later sweeps' lists come mostly from the earlier sweeps' accepted candidates) and forced off (mode 0), all == the oracle bit for bit."""
     import eppm_amd
     a, b = frames
     L = eppm_amd.lib()

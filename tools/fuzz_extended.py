@@ -1,7 +1,7 @@
 """Extended fixed-seed fuzz of the whole path against the live CPU oracle (GPU box; not part of the suite: ~10 minutes): the cases of
 tests/test_configs_gpu.py::_fuzz_case for seeds 100 .. 100+N-1, each through a single-pair context with the sweeps' form left to the
-library (classic + evaluation cache at these sizes) and forced speculative, and through a 3-pair batch context (pair, reversed pair,
-pair) forced speculative.  Prints one line per failure and a summary; exit code 1 on any mismatch.
+library (classic + evaluation cache at these sizes) and forced speculative (two-launch form with and without the work list, merged form), and through a 3-pair batch context (pair,
+reversed pair, pair) forced speculative in both forms.  Prints one line per failure and a summary; exit code 1 on any mismatch.
 usage: fuzz_extended.py [N]"""
 import os
 import sys
@@ -30,7 +30,7 @@ def main():
             h, w, _ = a.shape
             want = O.compute_flow(a, b, O.default_params(**params))
             rev = O.compute_flow(b, a, O.default_params(**params))
-            for mode in (-1, 1, 2):          # library default, speculative with the work list, speculative without it
+            for mode in (-1, 1, 2, 3):       # library default, speculative with the work list, without it, merged form from the first iteration
                 L.eppm_test_set_option(b"sweep_spec", mode)
                 try:
                     e = eppm_amd.EPPM(params=eppm_amd.Params(**params))
@@ -45,18 +45,19 @@ def main():
                 if not same(got, want) or not same(got_rev, rev):
                     bad += 1
                     print(f"MISMATCH seed {seed} case {t} sweep_spec {mode}: {w}x{h} {params}", flush=True)
-            L.eppm_test_set_option(b"sweep_spec", 1)
-            try:
-                B = eppm_amd.EPPMBatch(h, w, 3, params=eppm_amd.Params(**params))
-                B.set_data([(a, b), (b, a), (a, b)])
-                out = B.compute_flow()
-                B.close()
-            finally:
-                L.eppm_test_set_option(b"sweep_spec", -1)
-            runs += 3
-            if not (same(out[0], want) and same(out[1], rev) and same(out[2], want)):
-                bad += 1
-                print(f"MISMATCH seed {seed} case {t} batch: {w}x{h} {params}", flush=True)
+            for mode in (1, 3):
+                L.eppm_test_set_option(b"sweep_spec", mode)
+                try:
+                    B = eppm_amd.EPPMBatch(h, w, 3, params=eppm_amd.Params(**params))
+                    B.set_data([(a, b), (b, a), (a, b)])
+                    out = B.compute_flow()
+                    B.close()
+                finally:
+                    L.eppm_test_set_option(b"sweep_spec", -1)
+                runs += 3
+                if not (same(out[0], want) and same(out[1], rev) and same(out[2], want)):
+                    bad += 1
+                    print(f"MISMATCH seed {seed} case {t} batch sweep_spec {mode}: {w}x{h} {params}", flush=True)
     print(f"fuzz_extended: {runs} flows checked against the oracle, {bad} mismatching cases")
     sys.exit(1 if bad else 0)
 

@@ -257,7 +257,7 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
 
 // Waves per SIMD the register allocator plans for.  LDS would allow 5 (29 KB per workgroup), but at 4 the 116-VGPR
 // schedule keeps more gathers in flight per wave and is 1.5 % faster than the 92-VGPR one (A/B on one box,
-// tools/gpu_ab.sh); unroll 1 / 5 of the sample loop and 3 waves are slower, and so is a software-pipelined loop
+// tools/gpu.sh ab); unroll 1 / 5 of the sample loop and 3 waves are slower, and so is a software-pipelined loop
 // that issues the gathers of the next sample pair before computing the current one (161 VGPRs, +6 % instructions,
 // +3.5 % time: the kernel waits on VALU issue, not on memory).
 #ifndef EPPM_C2F_WAVES

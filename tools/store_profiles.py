@@ -24,7 +24,7 @@ for d in sorted(os.listdir(src)):
         summ[d] = list(csv.DictReader(out.splitlines()))
 
 VALU_PEAK = 256 * 4 * 2.4e9 / 2
-GROUPS = (("refine", ("k_c2f_refine", "k_c2f_select")), ("sweeps", ("k_pm_sweep", "k_pm_seg_propagate")), ("search", ("k_pm_random_search",)),
+GROUPS = (("refine", ("k_c2f_refine", "k_c2f_select")), ("sweeps", ("k_pm_sweep", "k_pm_spec_all", "k_pm_seg_propagate")), ("search", ("k_pm_random_search",)),
           ("smoothing", ("k_flow_blf",)), ("weighted_median", ("k_wmf",)))
 
 

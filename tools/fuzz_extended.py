@@ -1,8 +1,8 @@
 """Extended fixed-seed fuzz of the whole path against the live CPU oracle (GPU box; not part of the suite: ~10 minutes): the cases of
-tests/test_configs_gpu.py::_fuzz_case for seeds 100 .. 100+N-1, each through a single-pair context with the sweeps' form left to the
+tests/test_configs_gpu.py::_fuzz_case for seeds first .. first+N-1 (default 100), each through a single-pair context with the sweeps' form left to the
 library (classic + evaluation cache at these sizes) and forced speculative (two-launch form with and without the work list, merged form), and through a 3-pair batch context (pair,
 reversed pair, pair) forced speculative in both forms.  Prints one line per failure and a summary; exit code 1 on any mismatch.
-usage: fuzz_extended.py [N]"""
+usage: fuzz_extended.py [N [first_seed]]"""
 import os
 import sys
 
@@ -22,9 +22,10 @@ def same(got, want):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     L = eppm_amd.lib()
     bad = runs = 0
-    for seed in range(100, 100 + n):
+    for seed in range(first, first + n):
         for t in range(8):
             a, b, params = T._fuzz_case(seed, t)
             h, w, _ = a.shape

@@ -78,6 +78,8 @@ struct PmProblem {
     // word 0, 1: list lengths of the even / odd sweeps of a run (ping-pong: a sweep's phase A clears the other one);
     // [16, 16 + units): stamp per unit (two adjacent segments of a line) = 1 + number of the last sweep that listed it;
     // [16 + units, 16 + 2 * units): the list.  NULL: phase B walks every chain.
+    // Merged form (one phase A for the four sweeps of an iteration): words 8 + 4 * (iteration & 1) + d: list length of direction d;
+    // [16 + (2 + d) * units, ..): stamps of direction d = 1 + the iteration that listed the unit last; [16 + (6 + d) * units, ..): its list.
     uint32_t* wl = nullptr;
     // Merged form of the speculative sweeps (k_patchmatch.hip, k_pm_spec_all): the field as it stood before each direction's sweep of the
     // current iteration, four short2 planes (direction d at int16 offset d * PmBatch::seed_plane) -- where the in-place sweeps read their seeds.

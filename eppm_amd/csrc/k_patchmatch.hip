@@ -805,6 +805,26 @@ __global__ __launch_bounds__(256) void k_pm_spec_all(PmBatch B, const float* __r
         }
         return;
     }
+#ifndef EPPM_MERGED_COOP9_MAX
+#define EPPM_MERGED_COOP9_MAX 16
+#endif
+    // Radius 9, a block with at most 16 evaluations (the usual case in the iterations this kernel runs in): 16 lanes each, all at once --
+    // the launch then waits for a 7-sample chain and 16 hops instead of one lane's 100 samples.  (In k_pm_sweep_spec the same lost: its
+    // registers cost the early iterations, which every block of that kernel also serves; this kernel only runs late.)  PatchMatch
+    // 0.747 -> 0.741 ms per pair in 8-pair launches, default bench +0.4 % (two interleaved rounds each), 1920x1080 unchanged.
+    if (RT == 9 && total <= EPPM_MERGED_COOP9_MAX) {
+        for (int slot = tid >> 4; slot < total; slot += 16) {
+            const int pix = (int)s_list[slot] & 255, d = (int)s_list[slot] >> 8, e = s_cand[slot];
+            const int px = bxx * kBlock + (pix & 15), py = byy * kBlock + (pix >> 4), ci = py * B.cpitch + px;
+            const float cv = coop_patch_dist<(RT == 9 ? 9 : 1), 16>(P, L, s_src, TW, pix & 15, pix >> 4, (int)(int16_t)(e & 0xffff), e >> 16, tid & 15);
+            if ((tid & 15) == 0) {
+                pr.spec[d * B.cache_plane + ci] = cv;
+                pr.scand[d * B.cache_plane + ci] = e;
+                if (cv < pr.cost[ci]) merged_list_unit(wl, B, d, px, py);
+            }
+        }
+        return;
+    }
     for (int slot = tid; slot < total; slot += 256) {
         const int pix = (int)s_list[slot] & 255, d = (int)s_list[slot] >> 8, e = s_cand[slot];
         const int tx = pix & 15, ty = pix >> 4;

@@ -363,7 +363,17 @@ def test_patch_radius_17_and_other_parameters(crop):
     eq(u, ou, "u R=5 generic"); eq(v, ov, "v R=5 generic")
 
 
-def test_tiny_and_degenerate_inputs():
+@pytest.fixture(params=[-1, 3], ids=["sweeps_default", "sweeps_merged"])
+def sweep_mode(request):
+    """The library's own choice of the sweeps' form, and the merged speculative form forced from the first iteration (sweep_spec 3)."""
+    import eppm_amd
+    L = eppm_amd.lib()
+    assert L.eppm_test_set_option(b"sweep_spec", request.param) == 0
+    yield request.param
+    L.eppm_test_set_option(b"sweep_spec", -1)
+
+
+def test_tiny_and_degenerate_inputs(sweep_mode):
     """Smallest supported size, constant images (every patch cost ties at 0), and identical images."""
     rng = np.random.default_rng(5)
     a = rng.integers(0, 256, (16, 20, 3), dtype=np.uint8); b = rng.integers(0, 256, (16, 20, 3), dtype=np.uint8)
@@ -385,9 +395,9 @@ def test_tiny_and_degenerate_inputs():
     (64, 3000, dict(patch_r=17, num_iter=2)),        # radius 17 on a strip: the patch is taller than the image at every level
     (33, 1500, dict(propagation=1, num_iter=2)),     # jump flood on a strip
 ])
-def test_extreme_aspect_ratios(h, w, params):
-    """Strips: many segments per line and few lines (and the transpose) -- grid and tile-mapping edge cases of the sweeps, the
-    search and the refine; patches larger than the image."""
+def test_extreme_aspect_ratios(h, w, params, sweep_mode):
+    """Strips: many segments per line and few lines (and the transpose) -- grid and tile-mapping edge cases of the sweeps (in the
+    library's own form and in the merged speculative form), the search and the refine; patches larger than the image."""
     import eppm_amd
     from oracle import oracle as O
     rng = np.random.default_rng([h, w])

@@ -1186,12 +1186,17 @@ void launch_pm_rand_table(const PmRngDev& rng, uint32_t* work, int16_t* tab, int
 
 // TAB: the launch's random numbers come from PmRngDev::rand_tab (drawn ahead, see above): no drawing wave, no state, no LDS copy of the
 // numbers -- a lane loads the two shorts of its pixel and guess -- and the workgroup is G waves instead of G + 1.
-template <int RT, bool PK = false, bool TAB = false>
+// ROWS = 2 (numbers drawn ahead only): a workgroup covers an EIGHTH of the block (2 rows, 32 pixels; a wave = two guesses of them) -- for
+// launches of so few workgroups that their count per CU quantises badly (one 1024x436 pair: 872 quarter-workgroups on 256 CUs run as 4
+// per CU where 3.4 are needed; the kernel runs at its CU's L1 rate, so the launch lasts as long as the fullest CU).
+template <int RT, bool PK = false, bool TAB = false, int ROWS = 4>
 __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
                                                           int search_range, int G)
 {
+    static_assert(ROWS == 4 || (ROWS == 2 && TAB && RT != 0), "eighth-block workgroups read their numbers from the table");
     using LUT = typename SearchLut<RT>::type;
-    constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT, TH = (RT == 0) ? 1 : 4 + 2 * RT;
+    constexpr int PIXW = 16 * ROWS, NSUB = kBlock / ROWS;        // pixels per workgroup, workgroups per 16x16 block
+    constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT, TH = (RT == 0) ? 1 : ROWS + 2 * RT;
     __shared__ float4 s_src[TW * TH];
     __shared__ LUT L;
     __shared__ int16_t s_rand[TAB ? 2 : 8 * 512];
@@ -1203,7 +1208,7 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     const int bxx = brest % rng.gx, byy = brest / rng.gx;
     const PmProblem pr = pm_problem(B, bq);
     const int tid = threadIdx.x;
-    const int tile_y = byy >> 2, quarter = byy & 3;
+    const int tile_y = byy / NSUB, quarter = byy % NSUB;
     const int block_id = tile_y * rng.gx + bxx;
     load_patch_lut(L, lut, R, tid, blockDim.x);
     if (!TAB && tid < 64) {
@@ -1215,14 +1220,14 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     }
     const Planes P = to_dev(pr.P);
     if (RT != 0) {
-        const int x0 = bxx * kBlock - RT, y0 = tile_y * kBlock + quarter * 4 - RT;
+        const int x0 = bxx * kBlock - RT, y0 = tile_y * kBlock + quarter * ROWS - RT;
         for (int t = tid; t < TW * TH; t += blockDim.x) {
             const int sy = iclamp(y0 + t / TW, 0, P.h - 1), sx = iclamp(x0 + t % TW, 0, P.w - 1);
             s_src[t] = P.pk1[(unsigned)(sy * P.pitch + sx)];
         }
     }
     __syncthreads();
-    const int lane = tid & 63, k = tid >> 6;                     // wave k = guess k; wave G advances the RNG states
+    const int lane = tid % PIXW, k = tid / PIXW;                 // ROWS = 4: wave k = guess k; wave G advances the RNG states
     if (!TAB && k == G) {
         if (quarter == 0) {
             // Off the critical path: this wave has nothing else to do, the other G waves are evaluating guesses.  (Round 3 tried
@@ -1234,7 +1239,7 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
             store_state(pr.rng_work_next + so, st);
         }
     }
-    const int pix = quarter * 64 + lane;                         // row-major index inside the 16x16 block
+    const int pix = quarter * PIXW + lane;                       // row-major index inside the 16x16 block
     const int x = bxx * kBlock + (pix & 15), y = tile_y * kBlock + (pix >> 4);
     const bool inimg = (k < G) && (x < P.w && y < P.h);
     const int nidx = y * B.npitch + x, cidx = y * B.cpitch + x;
@@ -1297,6 +1302,13 @@ void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float*
     if (rng.rand_tab && (R == 9 || R == 17)) {                                         // numbers drawn ahead: G waves per workgroup
         dim3 blockt(64 * num_guess);
         const bool have_pc_t = b.p[0].P.pc2 && (b.n < 2 || b.p[1].P.pc2);
+#ifndef EPPM_SEARCH_HALF_BELOW_WGS
+#define EPPM_SEARCH_HALF_BELOW_WGS 1024       // under four quarter-workgroups per CU: eighth-block workgroups (PatchMatch of one 1024x436 pair 1.362 -> 1.330 ms;
+#endif                                        // at 4080 workgroups, one 1920x1080 pair, they lose: 4.49 -> 4.57 ms)
+        if (R == 9 && (int)grid.x < EPPM_SEARCH_HALF_BELOW_WGS) {
+            hipLaunchKernelGGL((k_pm_random_search<9, false, true, 2>), dim3(grid.x * 2), dim3(32 * num_guess), 0, s, b, rng, lut, R, search_range, num_guess);
+            return;
+        }
         if (R == 9) hipLaunchKernelGGL((k_pm_random_search<9, false, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
         else if (have_pc_t) hipLaunchKernelGGL((k_pm_random_search<17, true, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
         else hipLaunchKernelGGL((k_pm_random_search<17, false, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);

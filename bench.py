@@ -209,6 +209,8 @@ def worker(args):
         local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    host_cpus = os.sched_getaffinity(0)            # restored before the CPU baseline
+    numa = bind_to_gpu_numa(local_rank)            # this rank's host thread(s) next to its GPU
     ctl = None                      # gloo group: control plane (backend agreement); `grp` carries the barrier and the MAX of the wall time
     grp = None
     if world > 1:
@@ -302,6 +304,10 @@ def worker(args):
         e.stage_times(clear=True)
     dts = []
     for _ in range(max(1, args.repeats)):
+        # outside the timed window: every output buffer is poisoned, so that the hashes below can only match flows THIS repeat wrote
+        # (the warm-up and the earlier repeats wrote the same flows into the same buffers)
+        for x in inputs:
+            x[2].fill_(float("nan"))
         barrier()
         t0 = time.perf_counter()
         run_steps(0, args.steps, S * NB)
@@ -315,6 +321,10 @@ def worker(args):
         t = torch.tensor(tv, dtype=torch.int64)
         dist.all_reduce(t, group=ctl)
         tv = [int(x) for x in t]
+    bindings = [numa]
+    if world > 1:
+        bindings = [None] * world
+        dist.all_gather_object(bindings, numa, group=ctl)
     dom_timed = []
     for e in tengs:
         dom_timed += e.stage_times(clear=True)
@@ -430,7 +440,9 @@ def worker(args):
                                    "RGB in, host u/v out -- is `host_boundary`)",
                        "inputs": "device-resident RGBA", "outputs": "device-resident float2 flow",
                        "pairs_per_step_per_gpu": 1, "pairs_in_flight_per_gpu": S * NB, "pairs_per_launch": NB, "contexts_in_flight": S,
-                       "width": w, "height": h},
+                       "width": w, "height": h,
+                       "host_binding": {"what": "each rank's host threads bound to the CPUs of its GPU's NUMA node (eppm_bind_thread_to_device; "
+                                                "numa_node -1 = topology not visible, unbound)", "ranks": bindings}},
             "timed_region_verified": {"ok": tv[0], "of": tv[1], "inputs_differ_on_this_host": tv[2], "all_ok": tv[0] == tv[1] and tv[1] > 0,
                                       "what": "sha256 of every flow the last repeat of the timed region left in HBM (all ranks) == the CPU oracle's flow of that "
                                               "pair, tests/golden/MANIFEST_config3.json" if plan.man3 else plan.why_unverifiable},
@@ -450,12 +462,33 @@ def worker(args):
                     e.synchronize()
                 out["other_configs"] = other_configs(plan, local_rank, dev)
         if world == 1 and not args.no_cpu_baseline:
+            os.sched_setaffinity(0, host_cpus)     # the CPU baseline gets the whole host, not the GPU's NUMA node
             out["cpu_baseline"] = cpu_baseline(w, h)
         data = (json.dumps(out) + "\n").encode()
         while data:
             data = data[os.write(json_fd, data):]
     if world > 1:
         dist.destroy_process_group()
+
+
+def bind_to_gpu_numa(device):
+    """One process per GPU: bind this rank's host threads to the CPUs of the NUMA node its GPU's PCIe slot belongs to
+    (eppm_bind_thread_to_device: hipDeviceGetPCIBusId + sysfs).  Recorded in config.host_binding; a host that does not expose the
+    topology is left unbound."""
+    import ctypes as C
+    import eppm_amd
+    info = {"pci": None, "numa_node": -1, "cpus_bound": 0}
+    try:
+        L = eppm_amd.lib()
+        buf = C.create_string_buffer(32)
+        if L.eppm_device_pci_bus_id(device, buf, C.c_size_t(32)) == 0:
+            info["pci"] = buf.value.decode()
+        node, n = C.c_int(-1), C.c_int(0)
+        if L.eppm_bind_thread_to_device(device, C.byref(node), C.byref(n)) == 0:
+            info["numa_node"], info["cpus_bound"] = node.value, n.value
+    except Exception as ex:
+        info["error"] = str(ex)[:120]
+    return info
 
 
 def verify_config3(args, rank, world, local_rank, params, dist, ctl, plan):
@@ -701,20 +734,25 @@ def cold_window(args, device, params, pair):
 
 
 def cpu_baseline(w, h):
-    """The CPU oracle (oracle/, a port of the reference's kernel semantics: the reference has no CPU path) timed on this host on a
-    bounded sample: the workload's own pair (seed 1234), whole path, five runs on 16 OpenMP threads (the lockstep sweeps synchronise
-    every step: 16-32 threads are fastest on the GPU box's 256-thread host, 128 take twice and 256 nine times as long,
-    tools/orc_threads.py), median reported; and ONE thread on the pair's centre 256x128 crop."""
+    """The CPU oracle (oracle/, a port of the reference's kernel semantics: the reference has no CPU path) timed on this host's cores,
+    on a bounded sample of the workload:
+      * `value` = `whole_host`: what the BOX computes -- floor(hardware threads / 16) oracle processes side by side, each on 16 OpenMP
+        threads bound to 16 hardware threads of its own, each computing a DISTINCT pair of the workload (seeds 1234 + i), all started
+        together; three such rounds, the median round reported; `cores` = the threads actually busy.  (One process cannot use the box:
+        the oracle's lockstep sweeps synchronise every step, 16-32 threads are fastest, 128 take twice and 256 nine times as long,
+        tools/orc_threads.py.)
+      * `single_pair_16_threads`: the latency of ONE pair on 16 threads, median of 3 runs (the figure of rounds 1-4);
+      * `single_thread`: one thread on the pair's centre 256x128 crop."""
     from oracle import oracle as O
     from eppm_amd import synth
     a, b, _, _ = synth.make_pair_cached(h, w, seed=1234)
     O.compute_flow(a[:32, :32].copy(), b[:32, :32].copy())      # build + warm
     n_all = O.num_threads()
-    ncpu = os.cpu_count() or 1
+    ncpu = len(os.sched_getaffinity(0))
     n = min(16, ncpu)
     O.set_num_threads(n)
     runs = []
-    for _ in range(5):                       # median of 5 runs (SURVEY 8d)
+    for _ in range(3):
         t0 = time.perf_counter()
         O.compute_flow(a, b)
         runs.append(time.perf_counter() - t0)
@@ -727,14 +765,93 @@ def cpu_baseline(w, h):
     O.compute_flow(qa, qb)
     dt1 = time.perf_counter() - t0
     O.set_num_threads(n_all)
-    return {"value": w * h / dt / 1e6, "unit": "Mflow-vectors/s", "cores": n, "kind": "port",
-            "sample": f"1 pair {w}x{h} (the workload's own pair, seed 1234), whole path, median of {len(runs)} runs = {dt:.2f} s (min {min(runs):.2f}, max "
-                      f"{max(runs):.2f}), OpenMP oracle on {n} of {ncpu} hardware threads",
-            "single_thread": {"value": qw * qh / dt1 / 1e6, "unit": "Mflow-vectors/s", "cores": 1,
-                              "sample": f"centre {qw}x{qh} crop of the same pair, whole path once, {dt1:.1f} s, one thread"}}
+    single = {"value": w * h / dt / 1e6, "unit": "Mflow-vectors/s", "cores": n, "ms_per_pair": dt * 1e3,
+              "sample": f"1 pair {w}x{h} (the workload's own pair, seed 1234), whole path, median of {len(runs)} runs = {dt:.2f} s (min {min(runs):.2f}, max "
+                        f"{max(runs):.2f}), OpenMP oracle on {n} of {ncpu} hardware threads"}
+    out = dict(single, kind="port")
+    out["single_pair_16_threads"] = single
+    out["single_thread"] = {"value": qw * qh / dt1 / 1e6, "unit": "Mflow-vectors/s", "cores": 1,
+                            "sample": f"centre {qw}x{qh} crop of the same pair, whole path once, {dt1:.1f} s, one thread"}
+    wh = cpu_whole_host(w, h, n)
+    out["whole_host"] = wh
+    if "value" in wh:          # the throughput figure of the box is the baseline of a throughput metric
+        out.update({"value": wh["value"], "cores": wh["cores"], "sample": wh["sample"]})
+    return out
+
+
+def cpu_whole_host(w, h, threads_per_proc, rounds=3):
+    """floor(CPUs / threads_per_proc) worker processes (this file, --cpu-worker), each bound to its own CPUs, each holding its own
+    pair; a round = every worker computes its pair once, all started by one "go"; the round's wall time runs from the go to the last
+    answer.  Bounded: rounds x one pair per worker (~4 s per round on the GPU box)."""
+    cpus = sorted(os.sched_getaffinity(0))
+    nproc = max(1, len(cpus) // threads_per_proc)
+    procs = []
+    try:
+        from oracle import oracle as O
+        O.lib()                              # built here, once: the workers only load it
+        for i in range(nproc):
+            mine = cpus[i * threads_per_proc:(i + 1) * threads_per_proc]
+            env = dict(os.environ, OMP_NUM_THREADS=str(len(mine)), OMP_PROC_BIND="false")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(h), str(w), str(1234 + i),
+                                           ",".join(map(str, mine))], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("a CPU-baseline worker did not start")
+        walls, per_pair = [], []
+        for _ in range(rounds):
+            t0 = time.perf_counter()
+            for p in procs:
+                p.stdin.write("go\n")
+                p.stdin.flush()
+            per_pair += [float(p.stdout.readline()) for p in procs]
+            walls.append(time.perf_counter() - t0)
+        for p in procs:
+            p.stdin.write("quit\n")
+            p.stdin.flush()
+        wall = float(sorted(walls)[len(walls) // 2])
+        return {"value": nproc * w * h / wall / 1e6, "unit": "Mflow-vectors/s", "cores": nproc * threads_per_proc, "kind": "port",
+                "processes": nproc, "threads_per_process": threads_per_proc, "round_s": walls, "pair_s_min_max": [min(per_pair), max(per_pair)],
+                "sample": f"{nproc} oracle process(es) x {threads_per_proc} OpenMP threads = {nproc * threads_per_proc} of {len(cpus)} hardware threads busy, each "
+                          f"process bound to its own CPUs and computing a distinct {w}x{h} pair (seeds 1234..{1233 + nproc}), whole path; {rounds} rounds "
+                          f"of one pair per process, started together; median round {wall:.2f} s"}
+    except Exception as ex:                  # a reported extra, never a reason to lose the line
+        return {"error": str(ex)[:300]}
+    finally:
+        for p in procs:
+            try:
+                p.stdin.close()
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+
+
+def cpu_worker(argv):
+    """--cpu-worker H W SEED CPULIST: one process of cpu_whole_host.  Binds itself, loads its pair and the oracle, says "ready", then
+    computes the pair once per "go" line and answers with the seconds it took."""
+    h, w, seed = int(argv[0]), int(argv[1]), int(argv[2])
+    cpus = [int(c) for c in argv[3].split(",") if c]
+    if cpus:
+        os.sched_setaffinity(0, cpus)
+    from oracle import oracle as O
+    from eppm_amd import synth
+    a, b, _, _ = synth.make_pair_cached(h, w, seed=seed)
+    O.set_num_threads(max(1, len(cpus)))
+    O.compute_flow(a[:32, :32].copy(), b[:32, :32].copy())
+    print("ready", flush=True)
+    for line in sys.stdin:
+        if line.strip() != "go":
+            break
+        t0 = time.perf_counter()
+        O.compute_flow(a, b)
+        print(time.perf_counter() - t0, flush=True)
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(sys.argv[2:])
+        return
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         spawn_ranks(args)

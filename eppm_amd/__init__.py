@@ -10,6 +10,6 @@ which are the public methods of ``class bao_flow_patchmatch_multiscale_cuda``
 when the library is missing.
 """
 from .build import build, lib_path  # noqa: F401
-from ._lib import EppmError, lib  # noqa: F401
+from ._lib import EppmError, lib, select_library  # noqa: F401
 from .api import EPPM, EPPMBatch, Params, host_register, host_unregister, pinned_empty  # noqa: F401
 from . import io, stages  # noqa: F401

@@ -25,13 +25,13 @@ SYMBOLS = [
     "eppm_stage_times", "eppm_clear_stage_times", "eppm_enable_stage_timing", "eppm_last_error", "eppm_version",
     "eppm_device_count", "eppm_set_device", "eppm_malloc_device", "eppm_malloc_pitched", "eppm_free_device",
     "eppm_memcpy_h2d", "eppm_memcpy_d2h", "eppm_memcpy2d_h2d", "eppm_memcpy2d_d2h", "eppm_memset_device",
-    "eppm_device_synchronize", "eppm_device_mem_info", "eppm_release_cached_memory", "eppm_set_launcher_stream", "eppm_set_launcher_params", "eppm_launcher_status",
+    "eppm_device_synchronize", "eppm_device_mem_info", "eppm_device_pci_bus_id", "eppm_bind_thread_to_device", "eppm_release_cached_memory", "eppm_set_launcher_stream", "eppm_set_launcher_params", "eppm_launcher_status",
     "baoCudaPatchMatchMultiscalePrepare", "baoCudaCensusTransform", "baoCudaPatchMatch", "baoCudaLeftRightCheck",
     "baoCudaOutlierRemoval", "baoCudaWeightedMedianFilter", "baoCudaFillHole", "baoCudaNNF2Flow", "baoCudaBLF_C2F",
     "baoCudaBLFCostFilterRefine", "baoCudaFlowSmoothing", "eppm_flow_to_color", "eppm_compute_color",
     "eppm_pm_rng_create", "eppm_pm_rng_reset", "eppm_pm_rng_destroy", "eppm_pm_rng_block_states", "eppm_pm_gen_rand_field",
     "eppm_pm_cost_field", "eppm_pm_seg_propagate", "eppm_pm_jump_propagate", "eppm_pm_parallel_propagate", "eppm_pm_random_search", "eppm_gauss_filter_rgba", "eppm_resize_rgba",
-    "eppm_resize_flow", "eppm_probe_fast_exp", "eppm_probe_div_const", "eppm_test_set_option", "eppm_probe_c2f_window",
+    "eppm_resize_flow",
     "eppm_host_register", "eppm_host_unregister", "eppm_host_is_registered", "eppm_host_alloc", "eppm_host_free",
     "eppm_compute_begin_into", "eppm_batch_compute_begin_into",
     "eppm_load_ppm", "eppm_ppm_size", "eppm_save_flo", "eppm_load_flo", "eppm_flo_size", "eppm_flow_error",
@@ -39,11 +39,27 @@ SYMBOLS = [
 ]
 
 
+# what include/eppm_test.h adds, exported by libeppm_hip_test.so only (the parity tests' switches and arithmetic probes)
+TEST_SYMBOLS = ["eppm_test_set_option", "eppm_probe_c2f_window", "eppm_probe_fast_exp", "eppm_probe_div_const"]
+
+_variant = None
+
+
+def select_library(variant):
+    """Which build this PROCESS loads: "" the product library (default), "test" libeppm_hip_test.so (the same objects plus the test
+    hooks of include/eppm_test.h: tests/conftest.py selects it for the pytest process; child processes -- bench.py, the CLI, smoke() --
+    are not affected), "approx" the opt-in approx-exp build.  Must be called before the first lib()."""
+    global _variant
+    if _lib is not None and variant != _variant:
+        raise EppmError("select_library: a library is loaded already")
+    _variant = variant
+
+
 def lib():
     """Load libeppm_hip.so.  No fallback: a missing library is an error."""
     global _lib
     if _lib is None:
-        path = lib_path()
+        path = lib_path(_variant)
         if not os.path.exists(path):
             raise EppmError(f"{path} is missing: run eppm_amd.build() (hipcc --offload-arch=gfx950); there is no CPU fallback")
         L = C.CDLL(path)

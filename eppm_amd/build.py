@@ -7,26 +7,28 @@ _CSRC = os.path.join(_HERE, "csrc")
 
 
 def lib_path(variant=None):
-    """Default library, or the opt-in approx-exp build (variant="approx", or EPPM_HIP_VARIANT=approx in the environment)."""
+    """The product library; variant="test": the parity tests' library (libeppm_hip_test.so: the same objects + include/eppm_test.h);
+    variant="approx": the opt-in approx-exp build.  variant=None reads EPPM_HIP_VARIANT from the environment."""
     variant = variant if variant is not None else os.environ.get("EPPM_HIP_VARIANT", "")
-    if variant not in ("", "exact", "approx"):
+    if variant not in ("", "exact", "approx", "test"):
         raise ValueError(f"unknown library variant {variant!r}")
-    return os.path.join(_HERE, "lib", "libeppm_hip_approx.so" if variant == "approx" else "libeppm_hip.so")
+    name = {"approx": "libeppm_hip_approx.so", "test": "libeppm_hip_test.so"}.get(variant, "libeppm_hip.so")
+    return os.path.join(_HERE, "lib", name)
 
 
 def _stale():
-    outs = [lib_path("")]
+    outs = [lib_path(""), lib_path("test")]
     if not all(os.path.exists(o) for o in outs):
         return True
     t = min(os.path.getmtime(o) for o in outs)
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)]
-    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("eppm.h", "bao_flow_patchmatch_multiscale_cuda.h", "bao_basic_cuda.h")]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("eppm.h", "eppm_test.h", "bao_flow_patchmatch_multiscale_cuda.h", "bao_basic_cuda.h")]
     srcs.append(os.path.join(_HERE, "..", "tools", "runeppm.cpp"))
     return any(os.path.getmtime(s) > t for s in srcs if os.path.isfile(s))
 
 
 def build(force=False, verbose=False, approx=False):
-    """Compile every HIP kernel + the C ABI into eppm_amd/lib/libeppm_hip.so and the runeppm CLI; approx=True also builds the opt-in
+    """Compile every HIP kernel + the C ABI into eppm_amd/lib/libeppm_hip.so, the parity tests' libeppm_hip_test.so and the runeppm CLI; approx=True also builds the opt-in
     libeppm_hip_approx.so (`make approx`: v_exp_f32 arithmetic, not bit-identical, never part of the default build)."""
     if approx:
         subprocess.check_call(["make", "-C", _CSRC, "-j", str(min(8, os.cpu_count() or 1)), "approx"], stdout=None if verbose else subprocess.DEVNULL)

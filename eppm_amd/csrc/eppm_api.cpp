@@ -5,7 +5,9 @@
 // _prepare_data :212-215, compute_flow :217-306.  Dead work of the reference is not reproduced: the
 // level-1/0 weighted-median calls on never-initialised planes (driver :281), the debug D2H
 // of the level-2 flow (:265-270) and the per-call RNG cudaMalloc (kernel.cu:1767).
+#include <ctype.h>
 #include <math.h>
+#include <sched.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -119,8 +121,10 @@ namespace {
 // refs: eppm_host_register calls outstanding on the block (several owners may register the same block -- runeppm --gpus N --pin
 // shares its images between the workers' objects -- and it is unpinned when the LAST of them unregisters); users: DMA transfers of
 // contexts in flight on it (held from the look-up that decides "read / write in place" until the transfer has completed: a look-up
-// and its hipMemcpyAsync are one critical step with respect to unregistration).
-struct HostBlock { size_t bytes; bool owned; int refs; int users; };
+// and its hipMemcpyAsync are one critical step with respect to unregistration).  closing: the last owner is waiting for the users to
+// drain before it unpins -- no new transfer starts on the block (host_acquire skips it, the caller stages), and a concurrent
+// eppm_host_register of a registered (not owned) block REVIVES it: the waiter then leaves the pinning to the new owner.
+struct HostBlock { size_t bytes; bool owned; int refs; int users; bool closing; };
 std::mutex g_reg_mu;
 std::condition_variable g_reg_cv;
 std::map<uintptr_t, HostBlock> g_reg;
@@ -132,11 +136,17 @@ std::map<uintptr_t, HostBlock>::iterator covering(const void* p, size_t bytes)  
     --it;
     return ((uintptr_t)p + bytes <= it->first + it->second.bytes) ? it : g_reg.end();
 }
+void drop_alias(uintptr_t p)                                                              // g_reg_mu held; one entry (equal keys map to one base)
+{
+    auto al = g_reg_alias.find(p);
+    if (al != g_reg_alias.end()) g_reg_alias.erase(al);
+}
 bool host_registered(const void* p, size_t bytes)
 {
     if (!p) return false;
     std::lock_guard<std::mutex> lk(g_reg_mu);
-    return covering(p, bytes) != g_reg.end();
+    auto it = covering(p, bytes);
+    return it != g_reg.end() && !it->second.closing;
 }
 // the block covering [p, p + bytes) marked in use (0 when there is none): the caller DMAs from / into it, then host_release(base)
 uintptr_t host_acquire(const void* p, size_t bytes)
@@ -144,7 +154,7 @@ uintptr_t host_acquire(const void* p, size_t bytes)
     if (!p) return 0;
     std::lock_guard<std::mutex> lk(g_reg_mu);
     auto it = covering(p, bytes);
-    if (it == g_reg.end()) return 0;
+    if (it == g_reg.end() || it->second.closing) return 0;
     it->second.users++;
     return it->first;
 }
@@ -158,6 +168,16 @@ void host_release(uintptr_t base)
 struct HostHold {                       // releases what a call acquired, on every return path
     std::vector<uintptr_t> v;
     bool add(const void* p, size_t bytes) { const uintptr_t b = host_acquire(p, bytes); if (b) v.push_back(b); return b != 0; }
+    // both planes or neither: a plane that is held is a plane the copy engine will write
+    bool add2(const void* p, const void* q, size_t bytes)
+    {
+        const uintptr_t a = host_acquire(p, bytes);
+        if (!a) return false;
+        const uintptr_t b = host_acquire(q, bytes);
+        if (!b) { host_release(a); return false; }
+        v.push_back(a); v.push_back(b);
+        return true;
+    }
     void release() { for (uintptr_t b : v) host_release(b); v.clear(); }
     ~HostHold() { release(); }
 };
@@ -169,36 +189,54 @@ extern "C" int eppm_host_register(void* p, size_t bytes)
     std::lock_guard<std::mutex> lk(g_reg_mu);          // held across the check and hipHostRegister: two threads registering one block
     auto it = covering(p, bytes);
     if (it != g_reg.end()) {
+        if (it->second.closing) {
+            if (it->second.owned) return set_err(EPPM_ERR_STATE, "eppm_host_register: the block is being released by eppm_host_free");
+            it->second.closing = false;                // the last owner was on its way out: this owner keeps the pages pinned
+            g_reg_cv.notify_all();
+        }
         it->second.refs++;
         if (it->first != (uintptr_t)p) g_reg_alias.emplace((uintptr_t)p, it->first);
         return EPPM_OK;
     }
     HIPCHK(hipHostRegister(p, bytes, hipHostRegisterPortable));
-    g_reg[(uintptr_t)p] = HostBlock{bytes, false, 1, 0};
+    g_reg[(uintptr_t)p] = HostBlock{bytes, false, 1, 0, false};
     return EPPM_OK;
 }
 extern "C" int eppm_host_unregister(void* p)
 {
     std::unique_lock<std::mutex> lk(g_reg_mu);
-    uintptr_t base = (uintptr_t)p;
-    auto al = g_reg_alias.find(base);
-    auto it = g_reg.find(base);
-    if (al != g_reg_alias.end()) { it = g_reg.find(al->second); g_reg_alias.erase(al); }
+    const uintptr_t key = (uintptr_t)p;
+    auto al = g_reg_alias.find(key);
+    auto it = (al != g_reg_alias.end()) ? g_reg.find(al->second) : g_reg.find(key);
     if (it == g_reg.end()) return set_err(EPPM_ERR_ARG, "eppm_host_unregister: not a block registered with eppm_host_register");
     if (it->second.owned) {          // a range inside eppm_host_alloc memory was registered on top: drop that owner; the block itself goes with eppm_host_free
         if (it->second.refs <= 1) return set_err(EPPM_ERR_ARG, "eppm_host_unregister: a block from eppm_host_alloc is released with eppm_host_free");
         it->second.refs--;
+        drop_alias(key);
         return EPPM_OK;
     }
-    if (--it->second.refs > 0) return EPPM_OK;          // another owner still holds the registration
+    if (it->second.refs > 1) { it->second.refs--; drop_alias(key); return EPPM_OK; }          // another owner still holds the registration
     // last owner: wait for the transfers in flight on the block (a context of another thread between its look-up and the end of its
-    // copy); bounded, so that unregistering under one's own pending eppm_compute_begin_into is an error and not a deadlock
-    base = it->first;
-    const bool idle = g_reg_cv.wait_for(lk, std::chrono::seconds(5), [&] { auto q = g_reg.find(base); return q == g_reg.end() || q->second.users == 0; });
+    // copy); bounded, so that unregistering under one's own pending eppm_compute_begin_into is an error and not a deadlock.  The wait
+    // drops the lock: the block is marked closing meanwhile (no new transfer starts on it), and a thread that registers it again in
+    // that window becomes its owner -- the pages then stay pinned.  The alias entry goes only when this owner is really gone, so a
+    // retry after EPPM_ERR_STATE finds the block through the same pointer.
+    const uintptr_t base = it->first;
+    it->second.refs = 0;
+    it->second.closing = true;
+    const bool idle = g_reg_cv.wait_for(lk, std::chrono::seconds(5), [&] {
+        auto q = g_reg.find(base);
+        return q == g_reg.end() || !q->second.closing || q->second.users == 0;
+    });
     it = g_reg.find(base);
-    if (it == g_reg.end()) return EPPM_OK;
-    if (!idle) { it->second.refs = 1; return set_err(EPPM_ERR_STATE, "eppm_host_unregister: a transfer is still in flight on the block (eppm_compute_end pending?)"); }
+    if (it == g_reg.end()) { drop_alias(key); return EPPM_OK; }
+    if (!it->second.closing) { drop_alias(key); return EPPM_OK; }              // revived by a concurrent eppm_host_register: its owner now
+    if (!idle || it->second.users != 0) {
+        it->second.refs = 1; it->second.closing = false;
+        return set_err(EPPM_ERR_STATE, "eppm_host_unregister: a transfer is still in flight on the block (eppm_compute_end pending?)");
+    }
     g_reg.erase(it);
+    drop_alias(key);
     HIPCHK(hipHostUnregister((void*)base));
     return EPPM_OK;
 }
@@ -208,7 +246,7 @@ extern "C" int eppm_host_alloc(void** p, size_t bytes)
     if (!p || !bytes) return set_err(EPPM_ERR_ARG, "eppm_host_alloc: NULL or empty block");
     HIPCHK(hipHostMalloc(p, bytes, hipHostMallocPortable));
     std::lock_guard<std::mutex> lk(g_reg_mu);
-    g_reg[(uintptr_t)*p] = HostBlock{bytes, true, 1, 0};
+    g_reg[(uintptr_t)*p] = HostBlock{bytes, true, 1, 0, false};
     return EPPM_OK;
 }
 extern "C" int eppm_host_free(void* p)
@@ -218,9 +256,12 @@ extern "C" int eppm_host_free(void* p)
         std::unique_lock<std::mutex> lk(g_reg_mu);
         auto it = g_reg.find((uintptr_t)p);
         if (it == g_reg.end() || !it->second.owned) return set_err(EPPM_ERR_ARG, "eppm_host_free: not a block from eppm_host_alloc");
-        if (!g_reg_cv.wait_for(lk, std::chrono::seconds(5), [&] { auto q = g_reg.find((uintptr_t)p); return q == g_reg.end() || q->second.users == 0; }))
-            return set_err(EPPM_ERR_STATE, "eppm_host_free: a transfer is still in flight on the block (eppm_compute_end pending?)");
-        g_reg.erase((uintptr_t)p);
+        it->second.closing = true;                     // no new transfer starts on memory that is about to go
+        const bool idle = g_reg_cv.wait_for(lk, std::chrono::seconds(5), [&] { auto q = g_reg.find((uintptr_t)p); return q == g_reg.end() || q->second.users == 0; });
+        it = g_reg.find((uintptr_t)p);
+        if (it == g_reg.end()) return EPPM_OK;
+        if (!idle) { it->second.closing = false; return set_err(EPPM_ERR_STATE, "eppm_host_free: a transfer is still in flight on the block (eppm_compute_end pending?)"); }
+        g_reg.erase(it);
     }
     HIPCHK(hipHostFree(p));
     return EPPM_OK;
@@ -265,9 +306,11 @@ struct RngTables {
     int per_lane = 0, refs = 0;
     unsigned long long last_use = 0;
     // the numbers of the first rand_iters search launches of a run, drawn ahead (PmRngDev::rand_tab): [launch][block][G][512] int16
+    // (these three under build_mu, not under the global lock: building a table allocates, launches and synchronises)
+    std::mutex build_mu;
     int16_t* rand_tab = nullptr;
     int rand_iters = 0;
-    std::vector<void*> retired;        // smaller tables older contexts may still read
+    std::vector<void*> retired;        // smaller tables older contexts may still read; freed with the entry
 };
 std::mutex g_rngtab_mu;
 std::vector<RngTables*> g_rngtab;
@@ -337,13 +380,29 @@ static int rngtab_acquire(RngTables** out, int device, int w, int h, const eppm_
 #ifndef EPPM_RAND_TABLE
 #define EPPM_RAND_TABLE 1
 #endif
-static std::atomic<int> g_rand_table{1};       // test switch "rand_table": 0 = contexts created afterwards draw while they search (the form above 512 MB)
+// Kernel-variant switches of the parity tests.  The product library has none: the functions below are constants.  libeppm_hip_test.so
+// (the same objects with this file compiled -DEPPM_TEST_HOOKS; include/eppm_test.h) exports eppm_test_set_option, which sets the DEFAULTS a
+// context copies when it is created (eppm_ctx::opt_*) and what the context-less stage launchers read; a context in use is never affected.
+#ifdef EPPM_TEST_HOOKS
+static std::atomic<int> g_rand_table{1};       // "rand_table": 0 = contexts created afterwards draw while they search (the form above 512 MB)
+static std::atomic<int> g_sweep_spec{-1};      // "sweep_spec": -1 by iteration, 0 never, 1 always, 2 always and without the work list, 3 always in the merged form
+static std::atomic<int> g_no_split{0};         // "c2f_no_split"
+static int opt_rand_table() { return g_rand_table.load(); }
+static int opt_sweep_spec() { return g_sweep_spec.load(); }
+static int opt_no_split() { return g_no_split.load(); }
+#else
+static constexpr int opt_rand_table() { return 1; }
+static constexpr int opt_sweep_spec() { return -1; }
+static constexpr int opt_no_split() { return 0; }
+#endif
 static const int16_t* rngtab_rand_table(RngTables* t, int iters, size_t* stride)
 {
     const int gx = (t->w + kBlock - 1) / kBlock, gy = (t->h + kBlock - 1) / kBlock, nb = gx * gy;
     *stride = (size_t)nb * 512 * t->G;
-    if (!EPPM_RAND_TABLE || iters < 1 || !g_rand_table.load()) return nullptr;
-    std::lock_guard<std::mutex> lk(g_rngtab_mu);
+    if (!EPPM_RAND_TABLE || iters < 1 || !opt_rand_table()) return nullptr;
+    // the caller holds a reference on the entry (rngtab_acquire): it cannot go away.  Only contexts of this very (device, geometry,
+    // num_guess, seed) wait for each other here; creating and destroying contexts of any other kind goes on meanwhile.
+    std::lock_guard<std::mutex> lk(t->build_mu);
     if (t->rand_iters >= iters) return t->rand_tab;
     const size_t bytes = *stride * 2 * (size_t)iters;
     if (bytes > ((size_t)512 << 20)) return nullptr;
@@ -488,29 +547,31 @@ static hipError_t pooled_stream_create(hipStream_t* out, int device)
 static void pooled_stream_destroy(hipStream_t s, int device)
 {
     if (!s) return;
-#ifndef EPPM_EXPERIMENT_PM_LANE          // (that build's streams may carry CU masks: never pooled)
     if (EPPM_MEM_CACHE) {
         std::lock_guard<std::mutex> lk(g_memcache_mu);
         if (g_streams.size() < 16) { g_streams.push_back(PooledStream{device, s}); return; }
     }
-#endif
     (void)hipStreamDestroy(s);
 }
-// gives every cached block back to the runtime (memory accounting, tests)
+// gives every cached block back to the runtime (memory accounting, tests): slabs, pinned staging buffers, pooled streams, and the
+// generator tables no context uses any more (with their drawn-ahead numbers -- up to 512 MB each -- and retired smaller tables).
+// What stays resident afterwards: the tables of contexts that still exist, and the three look-up tables per (device, radius) (< 1 KB).
 extern "C" int eppm_release_cached_memory(void)
 {
-    std::lock_guard<std::mutex> lk(g_memcache_mu);
-    for (const CachedBlock& b : g_memcache) { if (b.pinned) (void)hipHostFree(b.p); else (void)hipFree(b.p); }
-    g_memcache.clear();
-    for (const PooledStream& p : g_streams) (void)hipStreamDestroy(p.s);
-    g_streams.clear();
+    {
+        std::lock_guard<std::mutex> lk(g_memcache_mu);
+        for (const CachedBlock& b : g_memcache) { if (b.pinned) (void)hipHostFree(b.p); else (void)hipFree(b.p); }
+        g_memcache.clear();
+        for (const PooledStream& p : g_streams) (void)hipStreamDestroy(p.s);
+        g_streams.clear();
+    }
+    std::lock_guard<std::mutex> lk(g_rngtab_mu);
+    for (size_t i = 0; i < g_rngtab.size();) {
+        if (g_rngtab[i]->refs == 0) { rngtab_free(g_rngtab[i]); g_rngtab.erase(g_rngtab.begin() + i); }
+        else i++;
+    }
     return EPPM_OK;
 }
-
-// Kernel-variant switches of the parity tests (eppm_test_set_option).  The values below are only the DEFAULTS a context copies when it
-// is created (eppm_ctx::opt_*) and what the context-less stage launchers read; a context in use is never affected by a later call.
-static std::atomic<int> g_sweep_spec{-1};      // "sweep_spec": -1 by iteration, 0 never, 1 always, 2 always and without the work list, 3 always in the merged form
-static std::atomic<int> g_no_split{0};         // "c2f_no_split"
 
 // ---------------------------------------------------------------------------------------------------
 // context
@@ -527,8 +588,6 @@ struct eppm_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int opt_sweep_spec = -1, opt_no_split = 0;     // kernel-variant switches, copied from the process defaults at creation (test support)
-    hipStream_t stream_pm = nullptr;    // -DEPPM_EXPERIMENT_PM_LANE only: the quarter-resolution stages on a stream of their own (priority / CU mask)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     eppm_params prm;
     int h = 0, w = 0, nl = 0;
     int npairs = 1, n_active = 1;
@@ -637,9 +696,6 @@ extern "C" int eppm_destroy(eppm_ctx* c)
     if (c->ev_h2d) (void)hipEventDestroy(c->ev_h2d);
     cache_free(c->h_flow, c->h_flow_bytes, true, c->device);
     rng_free(c->rng);
-    if (c->stream_pm) { (void)hipStreamSynchronize(c->stream_pm); (void)hipStreamDestroy(c->stream_pm); }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream && c->stream) pooled_stream_destroy(c->stream, c->device);
     delete c;
     return EPPM_OK;
@@ -756,60 +812,16 @@ extern "C" int eppm_create_batch(eppm_ctx** out, int h, int w, int device, const
     HIPCHK(hipSetDevice(device));
     eppm_ctx* c = new eppm_ctx();
     c->device = device; c->prm = p; c->h = h; c->w = w; c->npairs = npairs; c->n_active = 1;
-    c->opt_sweep_spec = g_sweep_spec.load(); c->opt_no_split = g_no_split.load();
+    c->opt_sweep_spec = opt_sweep_spec(); c->opt_no_split = opt_no_split();
     c->nl = pyr_init_dim(c->H, c->W, h, w, p.levels, 0.5f);
     const int L = c->nl - 1;
     if (c->H[L] < 1 || c->W[L] < 1 || (c->W[L] + p.seg_len - 1) / p.seg_len > 1024 || (c->H[L] + p.seg_len - 1) / p.seg_len > 1024) {
         delete c;
         return set_err(EPPM_ERR_ARG, "eppm_create: unsupported size %dx%d", w, h);
     }
-    // Round 4 measured giving the quarter-resolution stages (PatchMatch + level-2 post-processing) a lane of their own -- a second
-    // stream per context, plain / high priority (hipStreamCreateWithPriority) / confined to K CUs per XCD (hipExtStreamCreateWithCUMask)
-    // with or without the complementary mask on this stream: every form LOSES (190.1 -> 182.5 plain, 179.3 high priority, 64-130 with
-    // CU masks; profiles/r04x_a_*).  Each kernel class is bound by the occupancy of the CUs it holds, so partitioning conserves
-    // CU-time, and co-residency on ONE CU is blocked by the refine's footprint (2 workgroups = all VGPRs and 157 of 160 KB LDS).
-    // The code is kept for reproduction behind -DEPPM_EXPERIMENT_PM_LANE (tools/build_variant.sh; EPPM_PM_LANE=plain|prio|mask:K,
-    // EPPM_MAIN_MASK=K in the environment) and is not part of the default build.
-    hipError_t e = hipSuccess;
-#ifdef EPPM_EXPERIMENT_PM_LANE
-    {
-        const char* mm = getenv("EPPM_MAIN_MASK");         // bit i of a CU mask = CU i / 8 of XCD i % 8
-        const int km = mm ? atoi(mm) : 0;
-        if (km > 0 && km < 32) {
-            uint32_t mask[8];
-            for (int i = 0; i < 256; i++) { if (i % 32 == 0) mask[i / 32] = 0; if (i / 8 >= km) mask[i / 32] |= 1u << (i % 32); }
-            e = hipExtStreamCreateWithCUMask(&c->stream, 8, mask);
-        } else {
-            e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        }
-    }
-#else
-    e = pooled_stream_create(&c->stream, c->device);
-#endif
+    const hipError_t e = pooled_stream_create(&c->stream, c->device);
     if (e != hipSuccess) { delete c; return set_err(EPPM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->own_stream = true;
-#ifdef EPPM_EXPERIMENT_PM_LANE
-    if (const char* lane = getenv("EPPM_PM_LANE")) {
-        hipError_t e2 = hipSuccess;
-        if (!strncmp(lane, "prio", 4)) {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            e2 = hipStreamCreateWithPriority(&c->stream_pm, hipStreamNonBlocking, hi);
-        } else if (!strncmp(lane, "mask:", 5)) {
-            const int k = atoi(lane + 5);
-            uint32_t mask[8];
-            for (int i = 0; i < 256; i++) { if (i % 32 == 0) mask[i / 32] = 0; if (i / 8 < k) mask[i / 32] |= 1u << (i % 32); }
-            e2 = hipExtStreamCreateWithCUMask(&c->stream_pm, 8, mask);
-        } else if (!strncmp(lane, "plain", 5)) {
-            e2 = hipStreamCreateWithFlags(&c->stream_pm, hipStreamNonBlocking);
-        }
-        if (e2 != hipSuccess) { eppm_destroy(c); return set_err(EPPM_ERR_HIP, "EPPM_PM_LANE stream: %s", hipGetErrorString(e2)); }
-        if (c->stream_pm) {
-            (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-            (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-        }
-    }
-#endif
     int r = ctx_alloc(c);
     if (r != EPPM_OK) { eppm_destroy(c); return r; }
     *out = c;
@@ -1110,12 +1122,6 @@ static int compute_all(eppm_ctx* c)
     const int lw = c->W[L], lh = c->H[L];
 
     stage_begin(c, c->ev, "patchmatch");
-    hipStream_t s_main = s;
-    if (c->stream_pm) {
-        (void)hipEventRecord(c->ev_fork, s_main);
-        (void)hipStreamWaitEvent(c->stream_pm, c->ev_fork, 0);
-        s = c->stream_pm;
-    }
     {
         PmBatch b;
         b.n = 2; b.cpitch = lw; b.npitch = lw; b.npairs = bt.n; b.stride = bt.stride;
@@ -1142,11 +1148,6 @@ static int compute_all(eppm_ctx* c)
     launch_fill_holes(c->nnf_tmp, c->nnf1, c->img1[L], (int)(c->ipitch[L] / 4), lw, lh, lw, s, bt);          // driver :240
     std::swap(c->nnf1, c->nnf_tmp);
     launch_nnf2flow(c->flow[L], lw, c->nnf1, lw, lw, lh, s, bt);                                             // driver :258
-    if (c->stream_pm) {
-        (void)hipEventRecord(c->ev_join, c->stream_pm);
-        (void)hipStreamWaitEvent(s_main, c->ev_join, 0);
-        s = s_main;
-    }
     stage_end(c, c->ev);
 
     static const char* up_names[] = {"upsample_L0", "upsample_L1", "upsample_L2", "upsample_L3", "upsample_L4", "upsample_L5", "upsample_L6"};
@@ -1195,7 +1196,7 @@ extern "C" int eppm_batch_compute_device(eppm_ctx* c, void* const* d_flows)
 // de-interleave (on the device) and the device-to-host copies and returns; end waits.  When begin knows the destination planes
 // and they lie in registered memory, the copy engine writes them directly; otherwise the planes land in the context's pinned
 // staging and end copies them out.
-static int compute_begin(eppm_ctx* c, int n_out, float* const* u, float* const* v)
+static int compute_begin_impl(eppm_ctx* c, int n_out, float* const* u, float* const* v)
 {
     CHK(compute_all(c));
     const size_t n = (size_t)c->h * c->w;
@@ -1204,7 +1205,7 @@ static int compute_begin(eppm_ctx* c, int n_out, float* const* u, float* const* 
         float* du = (u && k < n_out) ? u[k] : nullptr;
         float* dv = (v && k < n_out) ? v[k] : nullptr;
         const float* src = c->of_pair(c->d_uv, k);
-        if (du && dv && host_registered(du, n * 4) && host_registered(dv, n * 4) && c->out_hold.add(du, n * 4) && c->out_hold.add(dv, n * 4)) {
+        if (du && dv && c->out_hold.add2(du, dv, n * 4)) {          // both planes in registered memory, held until eppm_compute_end
             HIPCHK(hipMemcpyAsync(du, src, n * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipMemcpyAsync(dv, src + n, n * 4, hipMemcpyDeviceToHost, c->stream));
             c->out_u[k] = du; c->out_v[k] = dv;
@@ -1219,6 +1220,17 @@ static int compute_begin(eppm_ctx* c, int n_out, float* const* u, float* const* 
     }
     c->flow_pending = true;
     return EPPM_OK;
+}
+static int compute_begin(eppm_ctx* c, int n_out, float* const* u, float* const* v)
+{
+    const int r = compute_begin_impl(c, n_out, u, v);
+    if (r != EPPM_OK && !c->out_hold.v.empty()) {
+        // eppm_compute_end will refuse to run (nothing is pending): the planes held so far must not stay in use until the context dies.
+        // Copies already queued into them drain first.
+        (void)hipStreamSynchronize(c->stream);
+        c->out_hold.release();
+    }
+    return r;
 }
 
 extern "C" int eppm_compute_begin(eppm_ctx* c)
@@ -1357,6 +1369,52 @@ extern "C" int eppm_memcpy2d_h2d(void* d, size_t dp, const void* s, size_t sp, s
 extern "C" int eppm_memcpy2d_d2h(void* d, size_t dp, const void* s, size_t sp, size_t wb, size_t rows) { HIPCHK(hipMemcpy2D(d, dp, s, sp, wb, rows, hipMemcpyDeviceToHost)); return EPPM_OK; }
 extern "C" int eppm_memset_device(void* p, int v, size_t n) { HIPCHK(hipMemset(p, v, n)); return EPPM_OK; }
 extern "C" int eppm_device_synchronize(void) { HIPCHK(hipDeviceSynchronize()); return EPPM_OK; }
+// PCI address of a device ("0000:c1:00.0", hipDeviceGetPCIBusId) and, from sysfs, the NUMA node its slot hangs off
+extern "C" int eppm_device_pci_bus_id(int device, char* buf, size_t len)
+{
+    if (!buf || len < 13) return set_err(EPPM_ERR_ARG, "eppm_device_pci_bus_id: buffer of at least 13 bytes");
+    HIPCHK(hipDeviceGetPCIBusId(buf, (int)len, device));
+    for (char* q = buf; *q; q++) *q = (char)tolower((unsigned char)*q);          // sysfs spells the address in lower case
+    return EPPM_OK;
+}
+// One host thread per GPU: binds the CALLING thread (and the threads it creates afterwards) to the CPUs of the NUMA node the
+// device's PCIe slot belongs to, intersected with the CPUs the thread may run on now -- staging copies, the DMA descriptors and the
+// launch path then stay on the socket next to the GPU.  numa_node = -1 / ncpus = 0 and no binding when sysfs does not say (a container
+// without the topology, a single-node host): never an error.
+extern "C" int eppm_bind_thread_to_device(int device, int* numa_node, int* ncpus)
+{
+    if (numa_node) *numa_node = -1;
+    if (ncpus) *ncpus = 0;
+    char bdf[32] = "";
+    CHK(eppm_device_pci_bus_id(device, bdf, sizeof bdf));
+    char path[128];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    int node = -1;
+    if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    if (node < 0) return EPPM_OK;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    cpu_set_t want, have;
+    CPU_ZERO(&want);
+    if (FILE* f = fopen(path, "r")) {          // "0-31,128-159"
+        int a = 0, b = 0;
+        for (;;) {
+            if (fscanf(f, "%d", &a) != 1) break;
+            b = a;
+            int ch = fgetc(f);
+            if (ch == '-') { if (fscanf(f, "%d", &b) != 1) break; ch = fgetc(f); }
+            for (int k = a; k <= b && k < CPU_SETSIZE; k++) CPU_SET(k, &want);
+            if (ch != ',') break;
+        }
+        fclose(f);
+    }
+    if (sched_getaffinity(0, sizeof have, &have) != 0) return EPPM_OK;
+    CPU_AND(&want, &want, &have);
+    const int n = CPU_COUNT(&want);
+    if (n < 1 || sched_setaffinity(0, sizeof want, &want) != 0) return EPPM_OK;
+    if (numa_node) *numa_node = node;
+    if (ncpus) *ncpus = n;
+    return EPPM_OK;
+}
 extern "C" int eppm_device_mem_info(size_t* free_bytes, size_t* total_bytes)
 {
     size_t f = 0, t = 0;
@@ -1524,14 +1582,14 @@ extern "C" int eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const ep
     PlanesH P;
     CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
     void* spec = nullptr;
-    const bool speculative = g_sweep_spec.load() >= 1;         // the stand-alone entry point has no iteration count: classic unless forced
+    const bool speculative = opt_sweep_spec() >= 1;         // the stand-alone entry point has no iteration count: classic unless forced
     // the evaluation cache of the sweeps lives for ONE call here (the planes of the next call may be other images): emptied first
     const size_t plane_bytes = cost_pitch * h;
     CHK(get_scratch(ds, plane_bytes * 8, &spec, 4));
     HIPCHK(hipMemsetAsync((char*)spec + plane_bytes * 4, 0xff, plane_bytes * 4, g_stream));
     b.cache_plane = plane_bytes / 4;
     void* wl = nullptr;                                        // work list of the speculative form: lengths and stamps cleared per call
-    if (speculative && sweep_list_on(g_sweep_spec.load())) {
+    if (speculative && sweep_list_on(opt_sweep_spec())) {
         b.wl_units = pm_worklist_units(w, h, g_prm.seg_len);
         const size_t wl_bytes = pm_worklist_words(w, h, g_prm.seg_len) * 4;
         CHK(get_scratch(ds, wl_bytes, &wl, 5));
@@ -1610,6 +1668,8 @@ extern "C" int eppm_resize_flow(eppm_float2* d_out, int outH, int outW, const ep
     launch_resize_flow((float*)d_out, outH, outW, (const float*)d_in, h, w, ratio, 1.0f, g_stream);
     return finish();
 }
+// ---- test support: libeppm_hip_test.so only (include/eppm_test.h); the product library exports none of it ----
+#ifdef EPPM_TEST_HOOKS
 static int probe(const float* x, float* y, int n, int which)
 {
     float *dx = nullptr, *dy = nullptr;
@@ -1621,7 +1681,6 @@ static int probe(const float* x, float* y, int n, int which)
     (void)hipFree(dx); (void)hipFree(dy);
     return finish();
 }
-// ---- test support ----
 extern "C" int eppm_test_set_option(const char* name, int value)
 {
     if (!name) return set_err(EPPM_ERR_ARG, "eppm_test_set_option: NULL name");
@@ -1638,6 +1697,7 @@ extern "C" int eppm_probe_c2f_window(int patch_r, int* span_x, int* span_y)
 }
 extern "C" int eppm_probe_fast_exp(const float* x, float* y, int n) { return probe(x, y, n, 0); }
 extern "C" int eppm_probe_div_const(const float* x, float* y, int n, int which) { return probe(x, y, n, 1 + which); }
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // the reference's live extern "C" launchers (driver :40-62)
@@ -1713,8 +1773,8 @@ extern "C" void baoCudaPatchMatch(eppm_short2* d_disp_vec, float* d_cost, eppm_u
     b.wl_units = pm_worklist_units(w, h, g_prm.seg_len);
     g_launch_status = get_scratch(ds, pm_worklist_words(w, h, g_prm.seg_len) * 4, &wl, 5);       // (k_pm_init_field clears it)
     if (g_launch_status != EPPM_OK) return;
-    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0, (float*)spec, (int32_t*)((char*)spec + plane_bytes * 4), sweep_list_on(g_sweep_spec.load()) ? (uint32_t*)wl : nullptr);
-    run_patchmatch(b, r, ds->lut_pm, g_prm, g_stream, g_sweep_spec.load());
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0, (float*)spec, (int32_t*)((char*)spec + plane_bytes * 4), sweep_list_on(opt_sweep_spec()) ? (uint32_t*)wl : nullptr);
+    run_patchmatch(b, r, ds->lut_pm, g_prm, g_stream, opt_sweep_spec());
     if (b.p[0].nnf != (int16_t*)d_disp_vec && (g_launch_status = copy_d2d(d_disp_vec, b.p[0].nnf, disp_pitch * h)) != EPPM_OK) return;
     g_launch_status = finish();
 }
@@ -1783,7 +1843,7 @@ extern "C" void baoCudaBLFCostFilterRefine(eppm_float2* d_flow_vec, eppm_uchar4*
     PlanesH P;
     g_launch_status = mk_planes(ds, &P, d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch);
     if (g_launch_status != EPPM_OK) return;
-    launch_c2f_refine(P, (float*)d_flow_vec, ds->lut_pm, g_prm.patch_r, nullptr, g_stream, kOnePair, g_no_split.load() != 0);
+    launch_c2f_refine(P, (float*)d_flow_vec, ds->lut_pm, g_prm.patch_r, nullptr, g_stream, kOnePair, opt_no_split() != 0);
     g_launch_status = finish();
 }
 
@@ -1799,7 +1859,7 @@ extern "C" void baoCudaBLF_C2F(eppm_float2** pFlowPyr, eppm_uchar4** pImgPyr1, e
     PlanesH P;
     g_launch_status = mk_planes(ds, &P, pImgPyr1[l], pImgPyr2[l], pCensusPyr1[l], pCensusPyr2[l], arrW[l], arrH[l], arrPitchUchar4[l], arrPitchUchar1[l]);
     if (g_launch_status != EPPM_OK) return;
-    launch_c2f_refine(P, (float*)pFlowPyr[l], ds->lut_pm, g_prm.patch_r, nullptr, g_stream, kOnePair, g_no_split.load() != 0);                       // refine :1086
+    launch_c2f_refine(P, (float*)pFlowPyr[l], ds->lut_pm, g_prm.patch_r, nullptr, g_stream, kOnePair, opt_no_split() != 0);                       // refine :1086
     g_launch_status = finish();
 }
 

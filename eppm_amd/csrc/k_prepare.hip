@@ -299,24 +299,4 @@ void launch_rgb_to_rgba(uint32_t* out, int pitch_px, const uint8_t* rgb, int h, 
     hipLaunchKernelGGL(k_rgb_to_rgba, grid, block, 0, s, out, pitch_px, rgb, h, w, bt.stride);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// arithmetic probes for the parity tests of the shared float formulas
-// ---------------------------------------------------------------------------------------------------
-__global__ void k_probe(const float* __restrict__ x, float* __restrict__ y, int n, int which)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float v = x[i];
-    float r;
-    if (which == 0) r = fast_exp(v);
-    else if (which == 1) r = div_ad2(v);
-    else if (which == 2) r = div_wmf2(v);
-    else r = unorm8(v);
-    y[i] = r;
-}
-void launch_probe(const float* x, float* y, int n, int which, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_probe, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n, which);
-}
-
 }  // namespace eppm

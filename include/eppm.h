@@ -178,6 +178,12 @@ int  eppm_memcpy2d_h2d(void* dst, size_t dpitch, const void* src, size_t spitch,
 int  eppm_memcpy2d_d2h(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows);
 int  eppm_memset_device(void* p, int value, size_t bytes);
 int  eppm_device_synchronize(void);
+/* PCI address of a device, lower case as sysfs spells it ("0000:c1:00.0"; hipDeviceGetPCIBusId); buf: at least 13 bytes */
+int  eppm_device_pci_bus_id(int device, char* buf, size_t len);
+/* Multi-GPU hosts (one host thread per GPU, one context each: pair i -> GPU i mod N): binds the CALLING thread, and the threads it
+ * creates afterwards, to the CPUs of the NUMA node the device's PCIe slot belongs to (sysfs), within the CPUs the thread may use now.
+ * *numa_node = -1, *ncpus = 0 and nothing bound when the topology is not visible; either pointer may be NULL. */
+int  eppm_bind_thread_to_device(int device, int* numa_node, int* ncpus);
 /* free / total memory of the current device (sizing the number of contexts in flight; leak checks) */
 int  eppm_device_mem_info(size_t* free_bytes, size_t* total_bytes);
 /* A destroyed context's slab and pinned staging buffers are kept (a few blocks, bounded in bytes) for the next context of the same size:
@@ -277,23 +283,6 @@ int  eppm_gauss_filter_rgba(eppm_uchar4* d_out, const eppm_uchar4* d_in, size_t 
 int  eppm_resize_rgba(eppm_uchar4* d_out, size_t out_pitch, int outH, int outW, const eppm_uchar4* d_in, size_t in_pitch,
         int h, int w, float ratio);
 int  eppm_resize_flow(eppm_float2* d_out, int outH, int outW, const eppm_float2* d_in, int h, int w, float ratio);
-/* test support: switches with which the parity tests steer launches onto a specific kernel variant (a host program never needs them;
- * every variant computes the same bits).  A call sets the DEFAULT that contexts created afterwards copy, and what the context-less stage
- * launchers below read; a context that exists already is not affected.  "c2f_no_split" = 1: the candidate refine is never split over
- * several workgroups per tile, so that small images run the LDS-window kernels too.  "sweep_spec": -1 (default) the sweeps of PatchMatch
- * iterations >= 2 (the third on) run in the speculative two-launch form when a launch covers at least 100 000 pixels (two 1024x436 pairs,
- * one 1920x1080 pair), 0 never, 1 always (also in eppm_pm_seg_propagate, which otherwise runs the classic form), 2 always and without
- * the work list (phase B walks every chain), 3 always and in the merged form (one phase A for the four sweeps of an iteration, the form the
- * library takes by itself from the sixth iteration on).  "rand_table": 1 (default) a context's random searches read numbers drawn ahead per geometry,
- * 0 they draw while they search -- the form a context takes by itself when the table would exceed 512 MB. */
-int  eppm_test_set_option(const char* name, int value);
-/* admissible spread (max - min, pixels) of a 16x16 tile's candidate centres for which the LDS-window refine kernels stage the
- * target window; wider tiles take the per-access path inside the same launch (patch_r 9 or 17) */
-int  eppm_probe_c2f_window(int patch_r, int* span_x, int* span_y);
-/* device-side arithmetic probes (parity of the shared float formulas): y[i] = f(x[i]) for n host floats */
-int  eppm_probe_fast_exp(const float* x, float* y, int n);
-int  eppm_probe_div_const(const float* x, float* y, int n, int which); /* 0: /(.1f*.1f) 1: /(.02f*.02f) 2: unorm8 (x = 0..255) */
-
 /* ----------------------------------------------------------------------------------------
  * file formats used by the reference's CLI (main.cpp:56-69)
  * -------------------------------------------------------------------------------------- */

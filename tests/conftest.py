@@ -16,6 +16,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 
 
+# The pytest process loads libeppm_hip_test.so: the product library's own objects plus the switches and probes of include/eppm_test.h
+# (eppm_amd/csrc/Makefile).  In-process only: bench.py, runeppm, the reference's main.cpp and smoke(), which the tests start as child
+# processes, load the product library.
+import eppm_amd  # noqa: E402
+
+eppm_amd.select_library("test")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -14,22 +14,46 @@ from eppm_amd import _lib
 from oracle import oracle as O
 
 
-def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "eppm.h")).read()
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b((?:eppm|baoCuda)\w*)\s*\(", hdr))
+    return set(re.findall(r"\b((?:eppm|baoCuda)\w*)\s*\(", hdr))
+
+
+def _exported(path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _declared("eppm.h")
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
-    L = eppm_amd.lib()
+    P = C.CDLL(eppm_amd.lib_path(""))          # the PRODUCT library (this process otherwise works on the test library, conftest.py)
     for s in declared:
-        getattr(L, s)          # raises AttributeError if not exported
-    L.eppm_version.restype = C.c_char_p
-    assert b"approx" not in L.eppm_version()
+        getattr(P, s)          # raises AttributeError if not exported
+    P.eppm_version.restype = C.c_char_p
+    assert b"approx" not in P.eppm_version()
     if os.path.exists(eppm_amd.lib_path("approx")):   # the opt-in approx-exp build (`make approx`; not part of the default build) exports the same ABI and names itself
         A = C.CDLL(eppm_amd.lib_path("approx"))
         for s in declared:
             getattr(A, s)
         A.eppm_version.restype = C.c_char_p
         assert b"approx-exp" in A.eppm_version()
+
+
+def test_test_hooks_live_in_the_test_library_only():
+    """include/eppm_test.h = the switches and probes of the parity tests.  The product library exports none of them (nothing matching
+    eppm_test* / eppm_probe*), the test library exports them on top of everything include/eppm.h declares, and the two are linked from the
+    same objects except eppm_api.o (compiled with / without -DEPPM_TEST_HOOKS) and the probe kernel."""
+    hooks = _declared("eppm_test.h")
+    assert hooks == set(_lib.TEST_SYMBOLS) and not (hooks & _declared("eppm.h"))
+    prod, test = _exported(eppm_amd.lib_path("")), _exported(eppm_amd.lib_path("test"))
+    assert not [s for s in prod if s.startswith("eppm_test") or s.startswith("eppm_probe")]
+    assert hooks <= test and _declared("eppm.h") <= test and _declared("eppm.h") <= prod
+    assert {s for s in test - prod if not s.startswith("_")} == hooks          # nothing else differs in the exported C ABI
+    mk = open(os.path.join(ROOT, "eppm_amd", "csrc", "Makefile")).read()
+    assert "OBJS_T = $(filter-out $(OBJ)/eppm_api.o,$(OBJS)) $(OBJ)/eppm_api_test.o $(OBJ)/k_probe.o" in mk
+    assert eppm_amd.lib()._name == eppm_amd.lib_path("test")                   # what the pytest process itself computes with
 
 
 def test_drop_in_class_header_compiles_and_links(tmp_path):

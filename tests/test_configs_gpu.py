@@ -263,6 +263,21 @@ def test_class_pinned_caller_buffers_cli(tmp_path):
     assert outs[0] == outs[1] and len(outs[0]) == 12 + 320 * 200 * 8
 
 
+@pytest.mark.parametrize("mode", ["", "--pin", "--trust"])
+def test_class_reads_through_rewritten_pointer_tables(tmp_path, mode):
+    """The reference indexes its images through the row-pointer tables on every call (basic/bao_basic_cuda.h:258-267).  The class reads a
+    bao_alloc-shaped table as one block only after checking EVERY pixel pointer, on every call (for a table seen before: while the
+    device already works, redoing the call through the pointers when the walk fails).  tests/csrc/class_tables.cpp rewrites the interior
+    pointers of a table between two calls, row ends untouched: the flow must be that of the image the pointers describe -- with plain
+    and with pinned caller buffers; the opt-in trust cache ("trust_verified_tables") is the documented exception."""
+    exe = str(tmp_path / "class_tables")
+    libdir = os.path.join(ROOT, "eppm_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "csrc", "class_tables.cpp"), "-o", exe,
+                           "-L", libdir, "-leppm_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe] + ([mode] if mode else []), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().startswith("OK"), r.stdout + r.stderr
+
+
 def test_class_pinned_blocks_shared_by_two_workers(tmp_path):
     """runeppm --gpus 2 --pin on one GPU: two objects on two host threads register the SAME image blocks (registrations are counted:
     the worker that finishes first must not unpin the pages under the other's DMA reads) and their own flow planes; every
@@ -628,6 +643,35 @@ def test_bench_two_ranks_share_one_gpu(backend):
         assert "config3_verified" not in d
 
 
+def test_bench_eight_ranks_share_one_gpu():
+    """The rehearsal of the run the driver makes on an 8-GPU node, `python bench.py --gpus 8`, on the one GPU of the test box: eight rank
+    processes (spawned by the parent before anything touches the GPU), each with its three 8-pair batch contexts, its own 24 of the 64
+    pairs in flight (ranks 3..7 wrap around the 64: (rank * 24 + j) mod 64), its share of the 64 config-3 pairs through the host
+    boundary, every rank's synth workers running side by side -- barrier and MAX over gloo.  One JSON line, exit code 0, every flow
+    verified, well inside two minutes.  Not exercised here, and not exercisable on one GPU: RCCL between eight devices (the barrier
+    falls back to gloo by agreement when it is unusable) and eight PCIe / NUMA paths."""
+    import time
+    env = dict(os.environ, EPPM_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "16", "--dist-backend", "gloo", "--no-extras",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    wall = time.time() - t0
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(line) == 1 and line[0].startswith("{"), out.stdout[:2000]          # ONE line on stdout and nothing else
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 16 and d["value"] > 0 and d["scaling"] == "weak"
+    tv = d["timed_region_verified"]                 # 16 steps per rank -> 16 flows per rank
+    assert tv["of"] == 128 and tv["ok"] == 128 and tv["inputs_differ_on_this_host"] == 0 and tv["all_ok"], tv
+    v = d["config3_verified"]
+    assert v["pairs"] == 64 and v["verified_pairs"] == 64 and v["all_ok"] and v["state"] == "verified", v
+    hb = d["config"]["host_binding"]["ranks"]
+    assert len(hb) == 8 and all(r["pci"] == hb[0]["pci"] for r in hb), hb              # eight ranks seen, all on the one device
+    assert wall < 120, wall
+
+
 def test_bench_default_line_is_self_verifying():
     """The one line the driver records (python bench.py at N = 1): every flow of the timed region hashed against the committed oracle
     flows, the single-pair latency beside ms_per_step, BASELINE configs[3] and [4] as `other_configs` (each checked against its oracle
@@ -646,7 +690,12 @@ def test_bench_default_line_is_self_verifying():
         assert oc[key]["verified"] == dict(oc[key]["verified"], ok=ctxs, of=ctxs, state="verified"), oc[key]
         assert oc[key]["value"] > 0 and oc[key]["ms_per_step"] > 0
     assert d["roofline"]["frac"] > 0 and d["roofline"]["hbm"]["frac"] > 0 if d["roofline"].get("hbm") else d["roofline"]["frac"] > 0
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    wh = cb["whole_host"]           # the box's own rate: one 16-thread oracle process per 16 hardware threads, distinct pairs
+    assert "error" not in wh and wh["processes"] == max(1, len(os.sched_getaffinity(0)) // 16) and wh["cores"] == wh["processes"] * wh["threads_per_process"]
+    assert cb["value"] == wh["value"] and cb["single_pair_16_threads"]["value"] > 0
+    assert d["config"]["host_binding"]["ranks"][0]["pci"]
     assert "approx_exp_variant" not in d and d["vs_baseline"] is None
     hb = d["host_boundary"]
     assert "error" not in hb and hb["pipelined"] > 0 and hb["sync"] > 0

@@ -153,6 +153,36 @@ def test_bench_gpus_n_spawns_its_own_ranks(tmp_path):
     assert bad.returncode == 1 and "ranks failed" in bad.stderr, (bad.returncode, bad.stderr)
 
 
+def test_bench_gpus_8_spawns_eight_ranks(tmp_path):
+    """The same with --gpus 8 (BASELINE configs[2]'s rank count): eight rank processes rendezvous on the port the parent picked, one line
+    comes back.  (The real ranks, eight of them on one GPU: tests/test_configs_gpu.py::test_bench_eight_ranks_share_one_gpu.)"""
+    stub = tmp_path / "stub.py"
+    stub.write_text(STUB)
+    drv = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        sys.argv = ["bench.py", "--gpus", "8", "--steps", "16"]
+        bench.spawn_ranks(bench.parse_args_known(), script={str(stub)!r})
+    """)
+    ok = subprocess.run([sys.executable, "-c", drv], capture_output=True, text=True, timeout=600)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    line = [ln for ln in ok.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1 and '"n_gpus": 8' in line[0], ok.stdout
+
+
+def test_cpu_whole_host_baseline_uses_every_cpu_once():
+    """bench.cpu_whole_host: one oracle process per `threads_per_proc` CPUs, each bound to its own CPUs, each with a distinct pair, rounds
+    started together; `cores` is what was busy.  Small pairs here; the GPU box runs it at 1024x436 with 16 threads per process."""
+    import bench
+    ncpu = len(os.sched_getaffinity(0))
+    tpp = max(1, ncpu // 2)
+    r = bench.cpu_whole_host(96, 64, tpp, rounds=2)
+    assert "error" not in r, r
+    assert r["processes"] == ncpu // tpp and r["cores"] == r["processes"] * tpp and r["kind"] == "port"
+    assert r["value"] > 0 and len(r["round_s"]) == 2 and r["value"] == r["processes"] * 96 * 64 / sorted(r["round_s"])[1] / 1e6
+
+
 def test_ranks_agree_on_the_backend_when_the_probe_fails_on_one_rank(tmp_path):
     """bench.agree_on_group: two gloo ranks, the "RCCL" probe succeeds on rank 0 and raises on rank 1 (a partial failure): BOTH must
     end up on the gloo group -- decided by a MIN over the gloo control group -- and a barrier + MAX over the agreed group completes.

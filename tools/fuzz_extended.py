@@ -23,6 +23,7 @@ def same(got, want):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    eppm_amd.select_library("test")          # the sweeps' forms are forced through eppm_test_set_option (include/eppm_test.h)
     L = eppm_amd.lib()
     bad = runs = 0
     for seed in range(first, first + n):

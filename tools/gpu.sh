@@ -18,14 +18,28 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 MODE=$1
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 QUIET="--no-cpu-baseline --no-extras"
-swap_in() { cp $R/gpurun_variants/$1/libeppm_hip.so $R/eppm_amd/lib/libeppm_hip.so; }
-keep_orig() { cp $R/eppm_amd/lib/libeppm_hip.so /tmp/libeppm_hip.orig.so; trap 'cp /tmp/libeppm_hip.orig.so $R/eppm_amd/lib/libeppm_hip.so' EXIT; }
-prof_env() { cd /tmp; export TMPDIR=/tmp; }
+# a variant that is missing or misspelt must stop the job, not benchmark the previous library under the new label
+swap_in() { cp $R/gpurun_variants/$1/libeppm_hip.so $R/eppm_amd/lib/libeppm_hip.so || { echo "swap_in: no variant '$1'" >&2; exit 1; }
+            if [ -f $R/gpurun_variants/$1/libeppm_hip_test.so ]; then cp $R/gpurun_variants/$1/libeppm_hip_test.so $R/eppm_amd/lib/libeppm_hip_test.so || exit 1; fi; }
+# the saved original is this job's own (mktemp): two A/B jobs on one box never restore each other's variant
+keep_orig() { ORIG=$(mktemp -d /tmp/eppm_orig.XXXXXX) || exit 1; cp $R/eppm_amd/lib/libeppm_hip.so $R/eppm_amd/lib/libeppm_hip_test.so $ORIG/ || exit 1
+              trap 'cp $ORIG/libeppm_hip.so $ORIG/libeppm_hip_test.so $R/eppm_amd/lib/; rm -rf $ORIG' EXIT; }
+# rocprofv3 runs: the synthetic pairs come from the file cache (filled here, by plain child processes), so that the profiled bench.py
+# starts no `python -m eppm_amd.synth` workers under the profiler's preload (each would add an output directory of its own)
+warm_synth() { (cd $R && python3 - <<'PY'
+from eppm_amd import synth
+jobs = [(436, 1024, 1234 + i, 20.0) for i in range(64)] + [(1080, 1920, 1234, 40.0), (2160, 3840, 1234, 60.0)]
+synth.make_pairs_parallel(jobs)
+PY
+) ; }
+prof_env() { warm_synth; cd /tmp; export TMPDIR=/tmp; }
 kstats() { python3 - "$1" "${2:-k_}" <<'PY'
-import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0]
+import csv, glob, os, sys
+# the bench process's file: the one with kernel rows (child processes that never launch a kernel leave empty or no stats files)
+fs = [f for f in glob.glob(sys.argv[1] + "/*/*kernel_stats.csv") if "k_" in open(f).read()]
+f = max(fs, key=os.path.getsize)
 for r in csv.DictReader(open(f)):
     if sys.argv[2] in r["Name"] and float(r["Percentage"]) > 0.3:
         print(f'{r["Name"][:72]:72s} calls {r["Calls"]:>5s} avg_us {float(r["AverageNs"])/1e3:9.1f} pct {r["Percentage"]}')

@@ -86,7 +86,7 @@ static bool apply_opt(eppm_params& p, const std::string& name, long long v)
     else if (name == "seed") p.seed = (unsigned long long)v;
     else if (name == "propagation") p.propagation = (int)v;
     else if (name == "levels") p.levels = (int)v;
-    else if (name == "pin_caller_buffers" || name == "verify_tables_every_call") return true;      // options of the class, not of eppm_params
+    else if (name == "pin_caller_buffers" || name == "verify_tables_every_call" || name == "trust_verified_tables") return true;      // options of the class, not of eppm_params
     else return false;
     return true;
 }
@@ -178,6 +178,7 @@ int main(int argc, char** argv)
         for (int g = 0; g < o.gpus; g++)
             workers.emplace_back([&, g]() {
                 const int dev = g % ndev;          // more workers than devices: they share (one context each; all read the same pinned images)
+                if (o.gpus > 1) eppm_bind_thread_to_device(dev, nullptr, nullptr);     // this worker's host side next to its GPU (NUMA node of the PCIe slot)
                 if (o.batch > 1) {       // batch context through the C ABI: B pairs per launch sequence
                     eppm_params prm;
                     eppm_default_params(&prm);

@@ -736,8 +736,8 @@ def cold_window(args, device, params, pair):
 def cpu_baseline(w, h):
     """The CPU oracle (oracle/, a port of the reference's kernel semantics: the reference has no CPU path) timed on this host's cores,
     on a bounded sample of the workload:
-      * `value` = `whole_host`: what the BOX computes -- floor(hardware threads / 16) oracle processes side by side, each on 16 OpenMP
-        threads bound to 16 hardware threads of its own, each computing a DISTINCT pair of the workload (seeds 1234 + i), all started
+      * `value` = `whole_host`: what the BOX computes -- floor(physical cores / 16) oracle processes side by side, each on 16 OpenMP
+        threads bound to 16 physical cores of its own, each computing a DISTINCT pair of the workload (seeds 1234 + i), all started
         together; three such rounds, the median round reported; `cores` = the threads actually busy.  (One process cannot use the box:
         the oracle's lockstep sweeps synchronise every step, 16-32 threads are fastest, 128 take twice and 256 nine times as long,
         tools/orc_threads.py.)
@@ -772,19 +772,65 @@ def cpu_baseline(w, h):
     out["single_pair_16_threads"] = single
     out["single_thread"] = {"value": qw * qh / dt1 / 1e6, "unit": "Mflow-vectors/s", "cores": 1,
                             "sample": f"centre {qw}x{qh} crop of the same pair, whole path once, {dt1:.1f} s, one thread"}
-    wh = cpu_whole_host(w, h, n)
+    cores, quota = physical_cores(os.sched_getaffinity(0)), cpu_quota()
+    usable = len(cores) if quota is None else max(1, min(len(cores), int(quota)))
+    if usable // n <= 1:
+        # everything this job may use IS one n-thread process: the runs above are the whole-host figure (no second set of runs)
+        wh = {"value": single["value"], "unit": "Mflow-vectors/s", "cores": n, "kind": "port", "processes": 1, "threads_per_process": n,
+              "round_s": runs, "hardware_threads": ncpu, "physical_cores": len(cores), "smt_siblings_used": False, "cgroup_cpu_quota": quota,
+              "usable_cpus": usable,
+              "sample": single["sample"] + (f"; the job's cgroup allows {quota:g} CPUs of time (cpu.max) on this {ncpu}-thread host, so one {n}-thread "
+                                            "process is everything it may use (more busy threads are throttled: profiles/r05x_b_cpu_layouts.txt)" if quota is not None else "")}
+    else:
+        wh = cpu_whole_host(w, h, n)
     out["whole_host"] = wh
     if "value" in wh:          # the throughput figure of the box is the baseline of a throughput metric
         out.update({"value": wh["value"], "cores": wh["cores"], "sample": wh["sample"]})
     return out
 
 
-def cpu_whole_host(w, h, threads_per_proc, rounds=3):
-    """floor(CPUs / threads_per_proc) worker processes (this file, --cpu-worker), each bound to its own CPUs, each holding its own
-    pair; a round = every worker computes its pair once, all started by one "go"; the round's wall time runs from the go to the last
-    answer.  Bounded: rounds x one pair per worker (~4 s per round on the GPU box)."""
-    cpus = sorted(os.sched_getaffinity(0))
-    nproc = max(1, len(cpus) // threads_per_proc)
+def physical_cores(cpus):
+    """One hardware thread per physical core among `cpus` (sysfs thread_siblings_list; every CPU its own core when sysfs does not say)."""
+    seen, out = set(), []
+    for c in sorted(cpus):
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            out.append(c)
+    return out
+
+
+def cpu_quota():
+    """CPUs of time the job's cgroup may use (cgroup v2 cpu.max / v1 cpu.cfs_quota_us), or None when unlimited.  The GPU boxes of this
+    pool show 256 hardware threads and give a job 16 CPUs ("1600000 100000"): more busy threads than that are throttled, not run."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / p if q > 0 else None
+    except Exception:
+        return None
+
+
+def cpu_whole_host(w, h, threads_per_proc, rounds=3, smt=False, env_extra=None, budget_s=30.0, ignore_quota=False):
+    """One worker process (this file, --cpu-worker) per `threads_per_proc` CPUs the job may really use -- physical cores (one hardware
+    thread each), capped by the cgroup's CPU quota: on the GPU boxes of this pool cpu.max gives a job 16 CPUs of a 256-thread host, and
+    8 x 16 or 16 x 16 busy threads are throttled to that (24-84 s per pair against 2.5 s for one process alone:
+    profiles/r05x_b_cpu_layouts.txt; ignore_quota=True reproduces it) -- each bound to its own cores, each holding its own pair; a round = every worker computes its pair once, all started by one "go"; the round's wall time runs from
+    the go to the last answer.  Bounded: rounds x one pair per worker, and no further round once budget_s is spent."""
+    allowed = sorted(os.sched_getaffinity(0))
+    cpus = allowed if smt else physical_cores(allowed)
+    quota = cpu_quota()
+    usable = len(cpus) if (quota is None or ignore_quota) else max(1, min(len(cpus), int(quota)))
+    nproc = max(1, usable // threads_per_proc)
+    threads_per_proc = min(threads_per_proc, usable)
     procs = []
     try:
         from oracle import oracle as O
@@ -792,6 +838,7 @@ def cpu_whole_host(w, h, threads_per_proc, rounds=3):
         for i in range(nproc):
             mine = cpus[i * threads_per_proc:(i + 1) * threads_per_proc]
             env = dict(os.environ, OMP_NUM_THREADS=str(len(mine)), OMP_PROC_BIND="false")
+            env.update(env_extra or {})
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                 env.pop(k, None)
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(h), str(w), str(1234 + i),
@@ -800,6 +847,7 @@ def cpu_whole_host(w, h, threads_per_proc, rounds=3):
             if p.stdout.readline().strip() != "ready":
                 raise RuntimeError("a CPU-baseline worker did not start")
         walls, per_pair = [], []
+        t_all = time.perf_counter()
         for _ in range(rounds):
             t0 = time.perf_counter()
             for p in procs:
@@ -807,14 +855,21 @@ def cpu_whole_host(w, h, threads_per_proc, rounds=3):
                 p.stdin.flush()
             per_pair += [float(p.stdout.readline()) for p in procs]
             walls.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all + walls[-1] > budget_s:
+                break
         for p in procs:
             p.stdin.write("quit\n")
             p.stdin.flush()
         wall = float(sorted(walls)[len(walls) // 2])
-        return {"value": nproc * w * h / wall / 1e6, "unit": "Mflow-vectors/s", "cores": nproc * threads_per_proc, "kind": "port",
+        busy = nproc * threads_per_proc
+        return {"value": nproc * w * h / wall / 1e6, "unit": "Mflow-vectors/s", "cores": busy, "kind": "port",
                 "processes": nproc, "threads_per_process": threads_per_proc, "round_s": walls, "pair_s_min_max": [min(per_pair), max(per_pair)],
-                "sample": f"{nproc} oracle process(es) x {threads_per_proc} OpenMP threads = {nproc * threads_per_proc} of {len(cpus)} hardware threads busy, each "
-                          f"process bound to its own CPUs and computing a distinct {w}x{h} pair (seeds 1234..{1233 + nproc}), whole path; {rounds} rounds "
+                "hardware_threads": len(allowed), "physical_cores": len(physical_cores(allowed)), "smt_siblings_used": bool(smt),
+                "cgroup_cpu_quota": quota, "usable_cpus": usable,
+                "sample": f"{nproc} oracle process(es) x {threads_per_proc} OpenMP threads = {busy} threads on {busy} "
+                          f"{'hardware threads' if smt else 'physical cores (one hardware thread per core)'} of a host with {len(allowed)} hardware threads"
+                          f"{'' if quota is None else f' whose cgroup gives this job {quota:g} CPUs of time (cpu.max)'}, each "
+                          f"process bound to its own CPUs and computing a distinct {w}x{h} pair (seeds 1234..{1233 + nproc}), whole path; {len(walls)} round(s) "
                           f"of one pair per process, started together; median round {wall:.2f} s"}
     except Exception as ex:                  # a reported extra, never a reason to lose the line
         return {"error": str(ex)[:300]}

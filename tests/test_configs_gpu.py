@@ -693,7 +693,9 @@ def test_bench_default_line_is_self_verifying():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     wh = cb["whole_host"]           # the box's own rate: one 16-thread oracle process per 16 hardware threads, distinct pairs
-    assert "error" not in wh and wh["processes"] == max(1, len(os.sched_getaffinity(0)) // 16) and wh["cores"] == wh["processes"] * wh["threads_per_process"]
+    assert "error" not in wh and wh["processes"] == max(1, wh["usable_cpus"] // 16) and wh["cores"] == wh["processes"] * wh["threads_per_process"]
+    assert wh["usable_cpus"] == min(wh["physical_cores"], int(wh["cgroup_cpu_quota"] or wh["physical_cores"]))       # what the job's cgroup lets it use
+    assert sum(wh["round_s"]) < 60, wh              # bounded: the default bench line finishes within minutes
     assert cb["value"] == wh["value"] and cb["single_pair_16_threads"]["value"] > 0
     assert d["config"]["host_binding"]["ranks"][0]["pci"]
     assert "approx_exp_variant" not in d and d["vs_baseline"] is None

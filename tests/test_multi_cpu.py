@@ -175,11 +175,11 @@ def test_cpu_whole_host_baseline_uses_every_cpu_once():
     """bench.cpu_whole_host: one oracle process per `threads_per_proc` CPUs, each bound to its own CPUs, each with a distinct pair, rounds
     started together; `cores` is what was busy.  Small pairs here; the GPU box runs it at 1024x436 with 16 threads per process."""
     import bench
-    ncpu = len(os.sched_getaffinity(0))
+    ncpu = len(bench.physical_cores(os.sched_getaffinity(0)))
     tpp = max(1, ncpu // 2)
     r = bench.cpu_whole_host(96, 64, tpp, rounds=2)
     assert "error" not in r, r
-    assert r["processes"] == ncpu // tpp and r["cores"] == r["processes"] * tpp and r["kind"] == "port"
+    assert r["physical_cores"] == ncpu and r["processes"] == ncpu // tpp and r["cores"] == r["processes"] * tpp and r["kind"] == "port"
     assert r["value"] > 0 and len(r["round_s"]) == 2 and r["value"] == r["processes"] * 96 * 64 / sorted(r["round_s"])[1] / 1e6
 
 

@@ -7,6 +7,7 @@
 #   test        GPU suite (PYTEST_ARGS, default "-x -q")               bench       the default bench line -> gpurun_out/bench_latest.json
 #   quick       GPU suite + a short bench with stage times             stats       rocprofv3 --kernel-trace --stats of BENCH_ARGS -> gpurun_out/stats_$TAG
 #   ab          VARIANTS="a b": default bench per variant (BENCH_ARGS) abstage     VARIANTS: single-stream stage times (tools/stage_times.py; SIZE=WxH PATCH_R= BATCH=)
+#   vtest       VARIANTS: the GPU suite (K="expr") on each variant's libraries
 #   abk         VARIANTS: per-kernel averages under rocprofv3 (BENCH_ARGS, FILTER=k_pm)
 #   pmc         PMC="counters.." in one pass of BENCH_ARGS -> gpurun_out/pmc_$TAG + per-kernel summary
 #   tcp         TA/TCP/TD counters per kernel (is a gather kernel L1 bound?)
@@ -69,6 +70,10 @@ ab)
   for r in $(seq 1 ${ROUNDS:-2}); do for v in $VARIANTS; do swap_in $v
     python bench.py $QUIET --steps ${STEPS:-96} ${BENCH_ARGS} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', round(d['value'],2), round(d['ms_per_step'],4), d['timed_region_verified']['ok'], '/', d['timed_region_verified']['of'])"
   done; done ;;
+vtest)
+  # parity of library variants: the GPU suite (K = pytest -k expression) with each variant's libraries swapped in
+  cd $R; keep_orig
+  for v in $VARIANTS; do swap_in $v; echo "== $v"; timeout ${TEST_TIMEOUT:-1500} python -m pytest tests -m gpu -x -q ${K:+-k "$K"} 2>&1 | tail -3; done ;;
 abstage)
   cd $R; keep_orig
   for r in $(seq 1 ${ROUNDS:-3}); do for v in $VARIANTS; do swap_in $v; python tools/stage_times.py $v $r; done; done ;;

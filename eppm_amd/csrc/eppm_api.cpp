@@ -1061,14 +1061,25 @@ static bool sweep_speculative(int iteration, long long pixels, int m)
     return m < 0 ? (iteration >= EPPM_SPEC_FROM_ITER && pixels >= EPPM_SPEC_MIN_PIXELS) : m != 0;
 }
 // From this iteration on the four speculative sweeps share ONE phase A (k_patchmatch.hip, k_pm_spec_all: the merged form): the field has
-// converged far enough that a phase-A launch costs its launch, and four of them per iteration are three too many.  Mode 3 of the test
-// switch forces the merged form from the first iteration.
+// converged far enough that a phase-A launch costs its launch, and four of them per iteration are three too many.  The threshold depends
+// on the size of a PROBLEM, not of the launch (round 5, A/B within one lease, profiles/r05x_c_merged_threshold_by_size.txt): the merged
+// phase A touches every pixel for four directions at once, and on a 480x270 or 960x540 problem that pays two iterations later than on
+// a 256x109 one -- 1920x1080: 187.4-188.0 Mflow-vectors/s from the eighth iteration against 186.4-187.0 from the sixth, 3840x2160 R = 17:
+// 139.9-140.8 ms against 141.0-141.9; eight 1024x436 pairs per launch: from the fifth to the eighth equal within the noise.  Mode 3 of
+// the test switch forces the merged form from the first iteration.
 #ifndef EPPM_MERGED_FROM_ITER
 #define EPPM_MERGED_FROM_ITER 5
 #endif
-static bool sweeps_merged(int iteration, long long pixels, int m)
+#ifndef EPPM_MERGED_FROM_ITER_LARGE
+#define EPPM_MERGED_FROM_ITER_LARGE 7        // problems of more than EPPM_MERGED_LARGE_PIXELS pixels
+#endif
+#ifndef EPPM_MERGED_LARGE_PIXELS
+#define EPPM_MERGED_LARGE_PIXELS 65536
+#endif
+static bool sweeps_merged(int iteration, long long pixels, long long problem_pixels, int m)
 {
-    return m == 3 || (m < 0 && EPPM_MERGED_FROM_ITER >= 0 && iteration >= EPPM_MERGED_FROM_ITER && sweep_speculative(iteration, pixels, m));
+    const int from = problem_pixels > EPPM_MERGED_LARGE_PIXELS ? EPPM_MERGED_FROM_ITER_LARGE : EPPM_MERGED_FROM_ITER;
+    return m == 3 || (m < 0 && from >= 0 && iteration >= from && sweep_speculative(iteration, pixels, m));
 }
 // one directional sweep on the batch; keeps the result in p[k].nnf (swaps the ping-pong pair when needed)
 static void sweep(PmBatch& b, const float* lut, const eppm_params& prm, int dir, hipStream_t s, bool speculative = false)
@@ -1103,8 +1114,8 @@ static void run_patchmatch(PmBatch& b, eppm_pm_rng* rng, const float* lut, const
         if (prm.propagation == 1) jump(b, lut, prm, s);
         else if (prm.propagation == 2) neighbor(b, lut, prm, 10, s);
         else {
-            const long long pixels = (long long)b.n * b.npairs * b.p[0].P.w * b.p[0].P.h;
-            if (sweeps_merged(it, pixels, spec_mode) && launch_pm_sweeps_merged(b, lut, prm.patch_r, prm.seg_len, it, s)) { /* in place */ }
+            const long long problem_pixels = (long long)b.p[0].P.w * b.p[0].P.h, pixels = problem_pixels * b.n * b.npairs;
+            if (sweeps_merged(it, pixels, problem_pixels, spec_mode) && launch_pm_sweeps_merged(b, lut, prm.patch_r, prm.seg_len, it, s)) { /* in place */ }
             else for (int dir = 0; dir < 4; dir++) sweep(b, lut, prm, dir, s, sweep_speculative(it, pixels, spec_mode));
         }
         search(b, rng, lut, prm, s, it);

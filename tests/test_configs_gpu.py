@@ -317,6 +317,73 @@ def test_unregister_under_a_pending_transfer_fails_instead_of_unpinning():
     assert np.array_equal(u, want[0]) and np.array_equal(v, want[1])
 
 
+def test_last_owner_leaving_meets_a_new_owner_arriving():
+    """The window inside eppm_host_unregister: the LAST owner waits (lock dropped) for a transfer in flight on the block, and meanwhile
+    another thread registers the same block.  The new owner must keep the pinning: the waiter, once the transfer is over, returns OK
+    WITHOUT unpinning, the block stays registered, transfers into it stay direct, and the new owner's own unregister succeeds and unpins.
+    (Before round 5 the waiter erased the block and unpinned it under the new owner, whose unregister then failed: ADVICE r4.)"""
+    import ctypes as C
+    import threading
+    import time
+    import eppm_amd
+    from eppm_amd import synth
+    L = eppm_amd.lib()
+    h, w = 96, 128
+    a, b, _, _ = synth.make_pair(h, w, seed=4, max_flow=5.0)
+    uv = np.zeros((2, h, w), np.float32)
+    p, n = C.c_void_p(uv.ctypes.data), C.c_size_t(uv.nbytes)
+    assert L.eppm_host_register(p, n) == 0                                   # owner A
+    e = eppm_amd.EPPM()
+    e.init(a, b, h, w)
+    want = e.compute_flow()
+    e.compute_flow_begin(out=(uv[0], uv[1]))                                  # a transfer in flight on the block
+    res = {}
+    t = threading.Thread(target=lambda: res.update(rc=L.eppm_host_unregister(p)))   # A leaves: last owner, waits for the transfer
+    t.start()
+    time.sleep(0.3)
+    assert t.is_alive()                                                      # (waiting: bounded at 5 s)
+    assert L.eppm_host_is_registered(p, n) == 0                              # closing: no NEW transfer starts on it ...
+    assert L.eppm_host_register(p, n) == 0                                   # ... until owner B arrives and keeps it
+    assert L.eppm_host_is_registered(p, n) == 1
+    u, v = e.compute_flow_end(out=(uv[0], uv[1]))                             # the transfer ends; the waiter wakes up
+    t.join(timeout=10)
+    assert not t.is_alive() and res["rc"] == 0, res
+    assert L.eppm_host_is_registered(p, n) == 1                              # B's registration stands
+    assert np.array_equal(u, want[0]) and np.array_equal(v, want[1])
+    uv[:] = 0
+    e.compute_flow_begin(out=(uv[0], uv[1]))                                  # still written in place by the copy engine
+    u2, v2 = e.compute_flow_end(out=(uv[0], uv[1]))
+    assert np.array_equal(uv[0], want[0]) and np.array_equal(uv[1], want[1]) and u2 is not None and v2 is not None
+    assert L.eppm_host_unregister(p) == 0 and L.eppm_host_is_registered(p, n) == 0     # B leaves: unpinned now
+    assert L.eppm_host_unregister(p) != 0
+    e.close()
+
+
+def test_unregister_through_an_inner_pointer_can_be_retried_after_a_timeout():
+    """A range registered INSIDE a registered block is an owner of that block, found through an alias entry.  When it is the last owner
+    and its unregister times out under a pending transfer (EPPM_ERR_STATE), the SAME pointer must still name the block afterwards:
+    the retry after eppm_compute_end succeeds.  (Before round 5 the alias entry was erased before the wait: 'not a block'.)"""
+    import ctypes as C
+    import eppm_amd
+    from eppm_amd import synth
+    L = eppm_amd.lib()
+    h, w = 96, 128
+    a, b, _, _ = synth.make_pair(h, w, seed=4, max_flow=5.0)
+    uv = np.zeros((2, h, w), np.float32)
+    p, n = C.c_void_p(uv.ctypes.data), C.c_size_t(uv.nbytes)
+    inner, ni = C.c_void_p(uv[1].ctypes.data), C.c_size_t(uv[1].nbytes)
+    assert L.eppm_host_register(p, n) == 0 and L.eppm_host_register(inner, ni) == 0      # two owners; the second through an alias
+    assert L.eppm_host_unregister(p) == 0 and L.eppm_host_is_registered(p, n) == 1       # the alias owner is the last one now
+    e = eppm_amd.EPPM()
+    e.init(a, b, h, w)
+    e.compute_flow_begin(out=(uv[0], uv[1]))
+    assert L.eppm_host_unregister(inner) == 3 and b"in flight" in L.eppm_last_error()    # EPPM_ERR_STATE after the bounded wait
+    assert L.eppm_host_is_registered(p, n) == 1
+    e.compute_flow_end(out=(uv[0], uv[1]))
+    assert L.eppm_host_unregister(inner) == 0 and L.eppm_host_is_registered(p, n) == 0  # the retry, same pointer
+    e.close()
+
+
 def test_host_registration_is_counted():
     """eppm_host_register twice on one block (and once on a range inside it) = three owners: the block stays registered until the
     third eppm_host_unregister; a context computing into it in between is unaffected."""

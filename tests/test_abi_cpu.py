@@ -70,6 +70,11 @@ def test_drop_in_class_header_compiles_and_links(tmp_path):
 def test_argument_errors_without_gpu():
     L = eppm_amd.lib()
     ctx = C.c_void_p()
+    small = C.create_string_buffer(8)
+    assert L.eppm_device_pci_bus_id(0, small, C.c_size_t(8)) == 1 and L.eppm_device_pci_bus_id(0, None, C.c_size_t(32)) == 1      # EPPM_ERR_ARG
+    node, n = C.c_int(7), C.c_int(7)
+    rc = L.eppm_bind_thread_to_device(0, C.byref(node), C.byref(n))          # no device here: an error code, outputs reset, nothing bound
+    assert rc in (0, 2) and (rc == 0 or (node.value, n.value) == (-1, 0))
     assert L.eppm_create(C.byref(ctx), 2, 2, 0, None) == 1            # EPPM_ERR_ARG: too small
     assert b"out of range" in L.eppm_last_error()
     p = eppm_amd.Params(patch_r=40)

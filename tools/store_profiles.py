@@ -13,9 +13,10 @@ for name in ("bench_default.json", "bench_like_driver.json", "bench_streams3.jso
     if os.path.exists(f"{src}/{name}") and os.path.getsize(f"{src}/{name}") > 0:
         shutil.copy(f"{src}/{name}", f"{dst}/{tag}_{name}")
 for d in ("stats_default", "stats_single", "stats_batch8"):
-    f = glob.glob(f"{src}/{d}/*/*kernel_stats.csv")
+    # the bench process's file: the one with kernel rows (child processes that launch no kernel leave empty or no stats files)
+    f = [x for x in glob.glob(f"{src}/{d}/*/*kernel_stats.csv") if "k_" in open(x).read()]
     if f:
-        shutil.copy(f[0], f"{dst}/{tag}_{d}_kernel_stats.csv")
+        shutil.copy(max(f, key=os.path.getsize), f"{dst}/{tag}_{d}_kernel_stats.csv")
 summ = {}
 for d in sorted(os.listdir(src)):
     if d.startswith("pmc_") and glob.glob(f"{src}/{d}/*/*counter_collection.csv"):

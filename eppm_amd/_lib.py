@@ -48,7 +48,7 @@ _variant = None
 def select_library(variant):
     """Which build this PROCESS loads: "" the product library (default), "test" libeppm_hip_test.so (the same objects plus the test
     hooks of include/eppm_test.h: tests/conftest.py selects it for the pytest process; child processes -- bench.py, the CLI, smoke() --
-    are not affected), "approx" the opt-in approx-exp build.  Must be called before the first lib()."""
+    are not affected), "tol" the tolerance library (libeppm_hip_tol.so, not bit-identical).  Must be called before the first lib()."""
     global _variant
     if _lib is not None and variant != _variant:
         raise EppmError("select_library: a library is loaded already")

@@ -7,17 +7,18 @@ _CSRC = os.path.join(_HERE, "csrc")
 
 
 def lib_path(variant=None):
-    """The product library; variant="test": the parity tests' library (libeppm_hip_test.so: the same objects + include/eppm_test.h);
-    variant="approx": the opt-in approx-exp build.  variant=None reads EPPM_HIP_VARIANT from the environment."""
+    """The product library (bit-identical to the oracle); variant="test": the parity tests' library (libeppm_hip_test.so: the same objects +
+    include/eppm_test.h); variant="tol": the tolerance library (libeppm_hip_tol.so: integer-domain tables in the patch term, NOT
+    bit-identical, inside 1e-3 px EPE on the bundled pair; never the default).  variant=None reads EPPM_HIP_VARIANT from the environment."""
     variant = variant if variant is not None else os.environ.get("EPPM_HIP_VARIANT", "")
-    if variant not in ("", "exact", "approx", "test"):
+    if variant not in ("", "exact", "tol", "test"):
         raise ValueError(f"unknown library variant {variant!r}")
-    name = {"approx": "libeppm_hip_approx.so", "test": "libeppm_hip_test.so"}.get(variant, "libeppm_hip.so")
+    name = {"tol": "libeppm_hip_tol.so", "test": "libeppm_hip_test.so"}.get(variant, "libeppm_hip.so")
     return os.path.join(_HERE, "lib", name)
 
 
 def _stale():
-    outs = [lib_path(""), lib_path("test")]
+    outs = [lib_path(""), lib_path("test"), lib_path("tol")]
     if not all(os.path.exists(o) for o in outs):
         return True
     t = min(os.path.getmtime(o) for o in outs)
@@ -27,11 +28,9 @@ def _stale():
     return any(os.path.getmtime(s) > t for s in srcs if os.path.isfile(s))
 
 
-def build(force=False, verbose=False, approx=False):
-    """Compile every HIP kernel + the C ABI into eppm_amd/lib/libeppm_hip.so, the parity tests' libeppm_hip_test.so and the runeppm CLI; approx=True also builds the opt-in
-    libeppm_hip_approx.so (`make approx`: v_exp_f32 arithmetic, not bit-identical, never part of the default build)."""
-    if approx:
-        subprocess.check_call(["make", "-C", _CSRC, "-j", str(min(8, os.cpu_count() or 1)), "approx"], stdout=None if verbose else subprocess.DEVNULL)
+def build(force=False, verbose=False):
+    """Compile every HIP kernel + the C ABI into eppm_amd/lib/libeppm_hip.so, the parity tests' libeppm_hip_test.so, the tolerance library
+    libeppm_hip_tol.so (the same sources with -DEPPM_TOL; never loaded unless asked for) and the runeppm CLI."""
     if not force and not _stale():
         return lib_path("")
     if not os.path.exists("/opt/rocm/bin/hipcc"):

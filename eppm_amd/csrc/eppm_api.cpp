@@ -54,10 +54,10 @@ static int set_err(int code, const char* fmt, ...)
     } while (0)
 
 extern "C" const char* eppm_last_error(void) { return g_err; }
-#ifdef EPPM_APPROX_EXP
-extern "C" const char* eppm_version(void) { return "eppm-hip 0.2 (gfx950, approx-exp: v_exp_f32, not bit-identical to the oracle)"; }
+#ifdef EPPM_TOL
+extern "C" const char* eppm_version(void) { return "eppm-hip 0.3 (gfx950, tolerance arithmetic: integer-domain tables in the patch term, not bit-identical to the oracle)"; }
 #else
-extern "C" const char* eppm_version(void) { return "eppm-hip 0.2 (gfx950)"; }
+extern "C" const char* eppm_version(void) { return "eppm-hip 0.3 (gfx950)"; }
 #endif
 
 extern "C" int eppm_default_params(eppm_params* p)
@@ -87,6 +87,17 @@ static void host_pm_lut(int R, std::vector<float>& v)
     const float sig_s = 0.5f * R;   // PM_SIG_S, defs.h:47
     for (int i = 0; i <= R; i++) v[i] = expf(-(i * i) / (sig_s * sig_s));
     for (int i = 0; i <= 8; i++) v[R + 1 + i] = 1 - expf(-float(i * i) / (0.3f * 8 * 0.3f * 8));
+#ifdef EPPM_TOL
+    // the tolerance library's integer-domain tables (eppm_device.cuh: make_texel): td[k] = 1 - exp(-(k/255)^2/s), ta[k] = exp(-(k/255)^2/s),
+    // s = LAMBDA_AD^2 = PM_SIG_R^2 as the float product the reference forms (defs.h:48,51), everything else in double
+    v.resize(R + 1 + 9 + 512);
+    const double s = double(0.1f * 0.1f);
+    for (int k = 0; k < 256; k++) {
+        const double d = double(k) / 255.0, e = exp(-(d * d) / s);
+        v[R + 10 + k] = float(1.0 - e);
+        v[R + 10 + 256 + k] = float(e);
+    }
+#endif
 }
 static void host_wmf_lut(std::vector<float>& v)
 {

@@ -51,9 +51,6 @@ __device__ __forceinline__ float fast_exp(float x)
     // v_mul, v_rndne, v_sub, 5 x v_fma, v_cvt, v_ldexp.  (Forming rint(y) with the 1.5*2^23 constant and reading the
     // exponent from the mantissa bits trades the half-rate v_rndne/v_cvt for three full-rate instructions; measured
     // 2.5 % slower in the refine kernel: the instruction count is what costs, tools/microbench/valu_rate.hip.)
-#ifdef EPPM_APPROX_EXP       // the opt-in tolerance build (make approx): the hardware v_exp_f32, NOT the shared formula
-    return __builtin_amdgcn_exp2f(x * 0x1.715476p+0f);
-#endif
     const float y = x * 0x1.715476p+0f;
     const float n = __builtin_rintf(y);
     const float f = y - n;
@@ -81,13 +78,8 @@ constexpr DivConst make_div_const(float c)
 }
 __device__ __forceinline__ float div_const(float x, const DivConst d) { return __builtin_fmaf(x, d.zh, x * d.zl); }
 static_assert(kPmSigR2 == kLambdaAd2 && kBlfSigR2 == kWmfSigR2, "one helper per distinct constant");
-#ifdef EPPM_APPROX_EXP       // the opt-in tolerance build: the argument of the hardware exp needs no correctly rounded quotient either
-__device__ __forceinline__ float div_ad2(float x) { return x * (1.0f / kLambdaAd2); }
-__device__ __forceinline__ float div_wmf2(float x) { return x * (1.0f / kWmfSigR2); }
-#else
 __device__ __forceinline__ float div_ad2(float x) { constexpr DivConst d = make_div_const(kLambdaAd2); return div_const(x, d); }   // also PM_SIG_R^2
 __device__ __forceinline__ float div_wmf2(float x) { constexpr DivConst d = make_div_const(kWmfSigR2); return div_const(x, d); }    // also POSTPROC_BLF_SIG_R^2
-#endif
 
 // unorm8 -> float exactly as c/255.0f (cudaReadModeNormalizedFloat)
 __device__ __forceinline__ float unorm8(float c) { constexpr DivConst d = make_div_const(255.0f); return div_const(c, d); }
@@ -129,6 +121,7 @@ struct Planes {
     int pitch;              // pixels
 };
 
+#ifndef EPPM_TOL
 // The census byte is stored shifted left by 2, so that w1 ^ w2 is the byte offset of entry (c1 ^ c2) in a
 // 256-entry table cnx[b] = cn[popcount(b)]: xor + LDS read + add (4 VALU cycles fewer per sample than
 // xor + v_bcnt (half rate) + the 9-entry table).
@@ -141,6 +134,30 @@ __device__ __forceinline__ float census_cost(const float* __restrict__ cnx, uint
 {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cnx) + (w1 ^ w2));
 }
+#else
+// ---- the tolerance library (libeppm_hip_tol.so, -DEPPM_TOL) ------------------------------------------------
+// NOT bit-identical to the oracle: the two software exp of a patch term (and their exact divisions) become table reads in the
+// INTEGER domain.  A channel of a texel is u8/255, so the L-inf distance of two texels is k/255 with k the integer L-inf distance of
+// their bytes (up to the rounding of u8/255, 1 ulp), hence
+//     1 - exp(-d^2/s) + cn[hamming]  = tdc[k_d][hamming]          exp(-(a^2+b^2)/s) = ta[k_a] * ta[k_b]
+// with the tables formed on the host in double.  Perturbation: ~2e-7 relative on a patch cost -- the class of the reference's own
+// 2-ulp __expf (bao_pmflow_kernel.cu:283,289); what it does to the flow is measured by tools/tolerance_envelope.py on the CPU
+// (mean EPE <= 7e-6 px on frame10/frame11, 0 on the 1024x436 synthetic pair) and asserted on the GPU by the -m gpu suite.
+//
+// Texel = { s*R, s*G, s*B as INTEGER BIT PATTERNS, census * 0x01010101 }, s = kTolScale = the byte stride of a table row.  An
+// integer below 2^23 read as a float is a denormal, and gfx950 adds denormals exactly at full rate (kernels run with
+// float_denorm_mode_32 = preserve): v_sub_f32 x3 + v_max3_f32 |.| leave the bits of s*k -- the byte offset of table row k -- in 4
+// instructions / 10 issue cycles, no conversion (tools/ubench/denormal_int_linf.hip: 0 mismatches, 2.3 / 4.0 cycles).  The census
+// byte is replicated into the four bytes of its word, so that popcount(w1 ^ w2) = 4 * hamming = the byte offset inside the row:
+// v_xor + v_bcnt_u32_b32 (which adds the row offset for free) and ONE LDS read give the whole cost term.
+constexpr int kTolRow = 10;                          // floats per row: [0..8] = 1 - exp(-(k/255)^2/s) + cn[hamming], [9] = exp(-(k/255)^2/s)
+constexpr unsigned kTolScale = 4u * kTolRow;         // bytes per row
+__device__ __forceinline__ float4 make_texel(uint32_t rgba, uint32_t census)
+{
+    return make_float4(__uint_as_float((rgba & 0xffu) * kTolScale), __uint_as_float(((rgba >> 8) & 0xffu) * kTolScale),
+                       __uint_as_float(((rgba >> 16) & 0xffu) * kTolScale), __uint_as_float((census & 0xffu) * 0x01010101u));
+}
+#endif
 __device__ __forceinline__ float one_minus_fast_exp(float x) { return 1 - fast_exp(x); }
 __device__ __forceinline__ rgbf texel_rgb(const float4 t) { return rgbf{t.x, t.y, t.z}; }
 
@@ -177,6 +194,7 @@ __device__ __forceinline__ uint32_t tex_rgba(const uint32_t* img, int pitch, int
 
 // ---- one sample of the patch cost (bao_pmflow_kernel.cu:275-295), both texels already fetched ------
 // gsp = gs[|j|]*gs[|i|] (the product is formed first in the reference too: "weight *= a*b").
+#ifndef EPPM_TOL
 __device__ __forceinline__ void patch_terms(const float4 q1, const float4 q2, const rgbf c1, const rgbf c2, float gsp,
                                             const float* __restrict__ cnx, float& cost_term, float& weight_term)
 {
@@ -195,6 +213,38 @@ __device__ __forceinline__ void patch_terms(const float4 q1, const float4 q2, co
     cost_term = cost;
     weight_term = weight;
 }
+// the running sums of a patch advance by one sample: the reference's two separate chains
+__device__ __forceinline__ void patch_accum(float& cost_sum, float& weight_sum, float cost_term, float weight_term)
+{
+    cost_sum += cost_term;
+    weight_sum += weight_term;
+}
+#else
+// byte offset of the table row of the L-inf distance of two texels (see make_texel)
+__device__ __forceinline__ uint32_t linf_row(const rgbf a, const rgbf b) { return __float_as_uint(max_abs_diff(a, b)); }
+__device__ __forceinline__ float tol_cost(const float* __restrict__ tdc, uint32_t row, uint32_t w1, uint32_t w2)
+{
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(tdc) + (row + (uint32_t)__builtin_popcount(w1 ^ w2)));
+}
+__device__ __forceinline__ float tol_weight(const float* __restrict__ tdc, uint32_t row)
+{
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(tdc) + (row + 4u * (kTolRow - 1)));
+}
+// cost_term = the sample's cost (NOT yet multiplied by its weight: patch_accum fuses that), weight_term = its weight
+__device__ __forceinline__ void patch_terms(const float4 q1, const float4 q2, const rgbf c1, const rgbf c2, float gsp,
+                                            const float* __restrict__ tdc, float& cost_term, float& weight_term)
+{
+    const rgbf p1 = texel_rgb(q1);
+    const rgbf p2 = texel_rgb(q2);
+    cost_term = tol_cost(tdc, linf_row(p1, p2), __float_as_uint(q1.w), __float_as_uint(q2.w));
+    weight_term = (tol_weight(tdc, linf_row(c1, p1)) * gsp) * tol_weight(tdc, linf_row(c2, p2));
+}
+__device__ __forceinline__ void patch_accum(float& cost_sum, float& weight_sum, float cost_term, float weight_term)
+{
+    cost_sum = __builtin_fmaf(cost_term, weight_term, cost_sum);
+    weight_sum += weight_term;
+}
+#endif
 
 __device__ __forceinline__ void patch_sample(const Planes& P, const rgbf c1, const rgbf c2, int sx1, int sy1, int sx2,
                                              int sy2, float gsp, const float* __restrict__ cnx, float& cost_term,
@@ -205,15 +255,23 @@ __device__ __forceinline__ void patch_sample(const Planes& P, const rgbf c1, con
     patch_terms(q1, q2, c1, c2, gsp, cnx, cost_term, weight_term);
 }
 
-// LUTs staged in LDS by every patch kernel: gsp[i*S + j] = gs[|2j-R|]*gs[|2i-R|], cnx[b] = cn[popcount(b)]
+// LUTs staged in LDS by every patch kernel: gsp[i*S + j] = gs[|2j-R|]*gs[|2i-R|], and the table of the per-sample terms -- tab():
+// exact library cnx[b] = cn[popcount(b)]; tolerance library tdc[k][0..9] (see make_texel)
 template <int MAXS>
 struct PatchLutT {
     float gsp[MAXS * MAXS];
+#ifndef EPPM_TOL
     float cnx[256];
+    __device__ __forceinline__ const float* tab() const { return cnx; }
+#else
+    float tdc[256 * kTolRow];
+    __device__ __forceinline__ const float* tab() const { return tdc; }
+#endif
 };
 using PatchLut = PatchLutT<kMaxS>;     // any radius the ABI accepts; kernels instantiated per radius use PatchLutT<R + 1>
 
-// lut_src layout in global memory: gs[0..R] then cn[0..8]
+// lut_src layout in global memory: gs[0..R] then cn[0..8]; tolerance library: then td[0..255] = 1 - exp(-(k/255)^2/s) and
+// ta[0..255] = exp(-(k/255)^2/s), s = LAMBDA_AD^2 = PM_SIG_R^2, formed in double on the host (eppm_api.cpp: host_pm_lut)
 template <int MAXS>
 __device__ __forceinline__ void load_patch_lut(PatchLutT<MAXS>& L, const float* __restrict__ lut_src, int R, int tid, int nthreads)
 {
@@ -223,7 +281,14 @@ __device__ __forceinline__ void load_patch_lut(PatchLutT<MAXS>& L, const float* 
         const int ai = abs(2 * i - R), aj = abs(2 * j - R);
         L.gsp[i * S + j] = lut_src[aj] * lut_src[ai];
     }
+#ifndef EPPM_TOL
     for (int t = tid; t < 256; t += nthreads) L.cnx[t] = lut_src[R + 1 + __builtin_popcount(t)];
+#else
+    for (int t = tid; t < 256 * kTolRow; t += nthreads) {
+        const int k = t / kTolRow, p = t - k * kTolRow;
+        L.tdc[t] = (p < kTolRow - 1) ? lut_src[R + 10 + k] + lut_src[R + 1 + p] : lut_src[R + 10 + 256 + k];
+    }
+#endif
 }
 
 // ---- the patch cost, bao_pmflow_kernel.cu:255-301: sequential i-outer / j-inner accumulation ------
@@ -252,9 +317,8 @@ __device__ __forceinline__ float patch_dist(const Planes& P, const PatchLut& L, 
             for (int k = 0; k < 5; k++) {
                 if (j0 + k < S) {
                     float ct, wt;
-                    patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.cnx, ct, wt);
-                    cost_sum += ct;
-                    weight_sum += wt;
+                    patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.tab(), ct, wt);
+                    patch_accum(cost_sum, weight_sum, ct, wt);
                 }
             }
         }
@@ -291,9 +355,8 @@ __device__ __forceinline__ float patch_dist_pass(const Planes& P, const PatchLut
                 cy2 = cy1 + vv + (float)(j)*kc[PASS][2] + (float)(i)*kc[PASS][3];
             }
             float ct, wt;
-            patch_sample(P, c1, c2, x1 + j, y1 + i, (int)floorf(cx2), (int)floorf(cy2), L.gsp[ii * S + jj], L.cnx, ct, wt);
-            cost_sum += ct;
-            weight_sum += wt;
+            patch_sample(P, c1, c2, x1 + j, y1 + i, (int)floorf(cx2), (int)floorf(cy2), L.gsp[ii * S + jj], L.tab(), ct, wt);
+            patch_accum(cost_sum, weight_sum, ct, wt);
         }
     }
     return cost_sum / weight_sum;

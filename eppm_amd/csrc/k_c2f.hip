@@ -210,9 +210,13 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
             const float4 q1 = s_src[(ty + 2 * ii) * TW + tx + 2 * jj];
             const rgbf p1 = texel_rgb(q1);
             const uint32_t k1 = __float_as_uint(q1.w);
+#ifdef EPPM_TOL
+            const float wsrc = tol_weight(L.tab(), linf_row(c1, p1)) * L.gsp[ii * S + jj];      // the source half of the weight: once per sample
+#else
             float a2 = max_abs_diff(c1, p1);
             a2 *= a2;
             const float gsp = L.gsp[ii * S + jj];
+#endif
             // byte offsets of the three targets: clamped column (in bytes throughout: no shift) + clamped rows
             const int dx16 = (PASS == 0) ? (2 * jj - R) * 16 : T.off[TP][ii * S + jj].dx16;
             float4 q2[3];                                 // the three gathers are issued back to back, then consumed
@@ -235,6 +239,11 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
 #pragma unroll
             for (int n = 0; n < 3; n++) {
                 const rgbf p2 = texel_rgb(q2[n]);
+#ifdef EPPM_TOL
+                const float cost = tol_cost(L.tab(), linf_row(p1, p2), k1, __float_as_uint(q2[n].w));
+                const float weight = wsrc * tol_weight(L.tab(), linf_row(c2[n], p2));
+                patch_accum(cs[n], ws[n], cost, weight);
+#else
                 float cost = max_abs_diff(p1, p2);
                 cost = one_minus_fast_exp(div_ad2(-(cost * cost)));
                 cost += census_cost(L.cnx, k1, __float_as_uint(q2[n].w));
@@ -245,6 +254,7 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
                 cost *= weight;
                 cs[n] += cost;
                 ws[n] += weight;
+#endif
             }
         }
     }
@@ -380,7 +390,11 @@ struct C2fWinGeom {
     static constexpr int yhi() { int v = R; const auto T = make_c2f_tables<R>(); for (int p = 0; p < 3; p++) for (int i = 0; i <= R; i++) v = T.rowdy[p][i] + 1 > v ? T.rowdy[p][i] + 1 : v; return v; }
 };
 #ifndef EPPM_C2F_WIN_H
+#ifdef EPPM_TOL
+#define EPPM_C2F_WIN_H 46      // the tolerance library's 10 KB term table: a 46-row window and a 40-texel source row stride keep two workgroups per CU
+#else
 #define EPPM_C2F_WIN_H 50
+#endif
 #endif
 #ifndef EPPM_C2F_PASS2
 #define EPPM_C2F_PASS2 1
@@ -410,9 +424,13 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
             const float4 q1 = s_src[(ty + 2 * ii) * TW + tx + 2 * jj];
             const rgbf p1 = texel_rgb(q1);
             const uint32_t k1 = __float_as_uint(q1.w);
+#ifdef EPPM_TOL
+            const float wsrc = tol_weight(L.tab(), linf_row(c1, p1)) * L.gsp[ii * S + jj];      // the source half of the weight: once per 6 terms
+#else
             float a2 = max_abs_diff(c1, p1);
             a2 *= a2;
             const float gsp = L.gsp[ii * S + jj];
+#endif
             const int soffA = (rdyA + ((PA != 0) ? T.off[TA][ii * S + jj].up : 0)) * (WW * 16) + ((PA == 0) ? (2 * jj - R) * 16 : T.off[TA][ii * S + jj].dx16);
             const int soffB = (rdyB + ((PB != 0) ? T.off[TB][ii * S + jj].up : 0)) * (WW * 16) + ((PB == 0) ? (2 * jj - R) * 16 : T.off[TB][ii * S + jj].dx16);
             const char* wa = reinterpret_cast<const char*>(s_win) + (wbase + soffA);
@@ -422,6 +440,18 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
             for (int n = 0; n < 3; n++) { qa[n] = *reinterpret_cast<const float4*>(wa + n * (WW * 16)); qb[n] = *reinterpret_cast<const float4*>(wb + n * (WW * 16)); }
 #pragma unroll
             for (int n = 0; n < 3; n++) {
+#ifdef EPPM_TOL
+                {
+                    const rgbf p2 = texel_rgb(qa[n]);
+                    const float cost = tol_cost(L.tab(), linf_row(p1, p2), k1, __float_as_uint(qa[n].w));
+                    patch_accum(csA[n], wsA[n], cost, wsrc * tol_weight(L.tab(), linf_row(c2[n], p2)));
+                }
+                {
+                    const rgbf p2 = texel_rgb(qb[n]);
+                    const float cost = tol_cost(L.tab(), linf_row(p1, p2), k1, __float_as_uint(qb[n].w));
+                    patch_accum(csB[n], wsB[n], cost, wsrc * tol_weight(L.tab(), linf_row(c2[n], p2)));
+                }
+#else
                 {
                     const rgbf p2 = texel_rgb(qa[n]);
                     float cost = max_abs_diff(p1, p2);
@@ -448,6 +478,7 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
                     csB[n] += cost;
                     wsB[n] += weight;
                 }
+#endif
             }
         }
     }
@@ -465,7 +496,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EPPM_C2F_WI
 void k_c2f_refine_win(PlanesH Ph, float* __restrict__ flow_, const float* __restrict__ lut, size_t pstride)
 {
     constexpr int TWU = kBlock + 2 * R;
+#ifdef EPPM_TOL
+    constexpr int TW = (TWU + 7) / 8 * 8;         // row stride = 128 B mod 256 B: the two 8-lane halves of a ds_read_b128 group still fall on disjoint banks
+#else
     constexpr int TW = (TWU + 15) / 16 * 16;
+#endif
     constexpr int WW = 64, WH = EPPM_C2F_WIN_H;                      // window: row stride 64 texels = 1 KiB (conflict-free ds_read_b128)
     constexpr int XLO = C2fWinGeom<R>::xlo(), XHI = C2fWinGeom<R>::xhi(), YLO = C2fWinGeom<R>::ylo(), YHI = C2fWinGeom<R>::yhi();
     // admissible spread of the candidate centres (max - min): a read lands at window column (cx + dx) - wx0 with cx in [mnx-1, mxx+1],

@@ -167,9 +167,8 @@ __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L
                 if (j0 + k < S) {
                     float ct, wt;
                     if (PK) q2[k] = make_texel(w2[k], w2[k] >> 24);
-                    patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.cnx, ct, wt);
-                    cost_sum += ct;
-                    weight_sum += wt;
+                    patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.tab(), ct, wt);
+                    patch_accum(cost_sum, weight_sum, ct, wt);
                 }
             }
         }
@@ -240,6 +239,26 @@ __device__ __forceinline__ float dpp_prev_lane(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
+// The sums of the lanes' chunks.  Exact library: the two running sums hop lane to lane while every lane adds its chunk -- the
+// reference's order of additions; the complete sums end in lane NL - 1 of the group.  Tolerance library (the order of the additions is
+// free): every lane sums its own chunk, then log2(LPC) DPP / swizzle steps add the lanes of the group; every lane of the group ends
+// with the complete sums.
+template <int LPC>
+__device__ __forceinline__ float dpp_group_sum(float v)
+{
+    static_assert(LPC == 4 || LPC == 16 || LPC == 32 || LPC == 64, "lanes per group");
+    // quad_perm [1,0,3,2], [2,3,0,1]: the sum of each quad in all four lanes
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));
+    if (LPC >= 16) {
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    }
+    if (LPC >= 32) v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401f /* xor 16: the other row of the 32-lane half */));
+    if (LPC >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 // One patch evaluation spread over the LPC lanes of a DPP row (16) or of a whole wave (64), for kernels whose source samples lie in
 // the (kBlock + 2 RT)^2 LDS tile of a 16x16 block: the S*S samples are dealt to the lanes in contiguous chunks, each lane forms the
 // terms of its chunk, and the two running sums hop lane to lane while every lane adds its chunk -- the reference's order of additions,
@@ -265,9 +284,15 @@ __device__ __forceinline__ float coop_patch_dist(const Planes& P, const LUT& L, 
 #pragma unroll
     for (int k = 0; k < CH; k++) {
         tc[k] = 0.0f; tw[k] = 0.0f;
-        if (t0 + k < NS) patch_terms(s_src[so[k]], q2[k], c1, c2, L.gsp[t0 + k], L.cnx, tc[k], tw[k]);
+        if (t0 + k < NS) patch_terms(s_src[so[k]], q2[k], c1, c2, L.gsp[t0 + k], L.tab(), tc[k], tw[k]);
     }
     float ac = 0.0f, aw = 0.0f;
+#ifdef EPPM_TOL
+#pragma unroll
+    for (int q = 0; q < CH; q++) patch_accum(ac, aw, tc[q], tw[q]);           // (a lane past the last sample holds zeros)
+    (void)NL;
+    return dpp_group_sum<LPC>(ac) / dpp_group_sum<LPC>(aw);
+#else
 #pragma unroll
     for (int ln = 0; ln < NL; ln++) {
         if (ln > 0) { ac = dpp_prev_lane<LPC>(ac); aw = dpp_prev_lane<LPC>(aw); }
@@ -278,6 +303,7 @@ __device__ __forceinline__ float coop_patch_dist(const Planes& P, const LUT& L, 
     }
     const int src = ((threadIdx.x & 63) / LPC) * LPC + (NL - 1);      // lane holding the complete sums (wave-relative)
     return __shfl(ac, src, 64) / __shfl(aw, src, 64);
+#endif
 }
 
 // LPC = lanes per chain (16, 32 or 64)
@@ -517,12 +543,18 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
                     if (q < CH) {
                         const int t = t0 + q;
                         tc[q] = 0.0f; tw[q] = 0.0f;
-                        if (t < NS) patch_terms(q1[k], q2[k], c1, c2, L.gsp[t], L.cnx, tc[q], tw[q]);
+                        if (t < NS) patch_terms(q1[k], q2[k], c1, c2, L.gsp[t], L.tab(), tc[q], tw[q]);
                     }
                 }
             }
-            // sequential sums in sample order: lane 0's chunk first, then the partial sums move one lane right
             float ac = 0.0f, aw = 0.0f;
+#ifdef EPPM_TOL
+            // free summation order: every lane its own chunk, then the lanes of the chain (dpp_group_sum)
+#pragma unroll
+            for (int q = 0; q < CH; q++) patch_accum(ac, aw, tc[q], tw[q]);
+            cv = dpp_group_sum<LPC>(ac) / dpp_group_sum<LPC>(aw);
+#else
+            // sequential sums in sample order: lane 0's chunk first, then the partial sums move one lane right
             constexpr int NL = (NS + CH - 1) / CH;       // lanes that own samples
 #pragma unroll
             for (int ln = 0; ln < NL; ln++) {
@@ -535,6 +567,7 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
             const int src = ((threadIdx.x & 63) / LPC) * LPC + (NL - 1);   // lane holding the complete sums (wave-relative)
             const float cs = __shfl(ac, src, 64), ws = __shfl(aw, src, 64);
             cv = cs / ws;
+#endif
             if (!SPEC && ccand && r == 0) { ccand[cidx] = cpack; cval[cidx] = cv; }
             }
             if (cv < cur_best) {

@@ -95,6 +95,26 @@ void orc_set_num_threads(int n)
  *                   plausible random stream.
  * ---------------------------------------------------------------------------------------- */
 static struct { int sweep_order, post_inplace, exp_mode, seed_variant; } g_var = {0, 0, 0, 0};
+/* Tolerance-arithmetic variants (tools/tolerance_envelope.py: how far would an integer-domain table form of the patch term move
+ * the flow? -- the design study behind libeppm_hip_tol.so; never the parity oracle).
+ *   mode  bit 1: 1 - exp(-d^2/s) = TD[kd], exp(-(a^2+b^2)/s) = TA[ka]*TA[kb] with k the integer L-inf distance of the u8 texels
+ *         bit 2: cost_sum advances by fmaf(cost, weight, cost_sum)
+ *         bit 4: the S*S terms are summed as S row sums (each in j order) added in i order, instead of one chain
+ *         bit 8: hardware-exp class: expf() wherever the table form does not apply (smoothing, weighted median)
+ *   scope bit 1: PatchMatch (cost field, sweeps, search)   bit 2: candidate refine   bit 4: smoothing / weighted median weights */
+static struct { int mode, scope; } g_tol = {0, 0};
+static float g_tol_td[256], g_tol_ta[256], g_tol_tw[256];
+void orc_set_tol_variant(int mode, int scope)
+{
+    g_tol.mode = mode; g_tol.scope = scope;
+    const double s = (double)(LAMBDA_AD * LAMBDA_AD);
+    for (int k = 0; k < 256; k++) {
+        const double d = (double)k / 255.0;
+        g_tol_td[k] = (float)(1.0 - exp(-(d * d) / s));
+        g_tol_ta[k] = (float)exp(-(d * d) / s);
+        g_tol_tw[k] = (float)exp(-(d * d) / (double)(WMF_SIG_R * WMF_SIG_R));      /* == POSTPROC_BLF_SIG_R^2 */
+    }
+}
 void orc_set_variant(int sweep_order, int post_inplace, int exp_mode, int seed_variant)
 {
     g_var.sweep_order = sweep_order; g_var.post_inplace = post_inplace; g_var.exp_mode = exp_mode; g_var.seed_variant = seed_variant;
@@ -449,10 +469,47 @@ static inline void patch_sample(const orc_uchar4* img1, const orc_uchar4* img2, 
     *weight_sum += weight;
 }
 
+/* tolerance-arithmetic variant of one sample (orc_set_tol_variant): integer L-inf distances of the u8 texels index two tables */
+static inline int iabs_(int v) { return v < 0 ? -v : v; }
+static inline int max_abs_diff_u8(orc_uchar4 a, orc_uchar4 b)
+{
+    return imax(imax(iabs_((int)a.x - (int)b.x), iabs_((int)a.y - (int)b.y)), iabs_((int)a.z - (int)b.z));
+}
+static inline orc_uchar4 tex_u8x4(const orc_uchar4* img, int w, int h, int x, int y)
+{
+    x = iclamp(x, 0, w - 1); y = iclamp(y, 0, h - 1);
+    return img[(size_t)y * w + x];
+}
+static inline void patch_sample_tol(const orc_uchar4* img1, const orc_uchar4* img2, const uint8_t* c1, const uint8_t* c2,
+                                    int w, int h, orc_uchar4 center1, orc_uchar4 center2, int sx1, int sy1, int sx2, int sy2,
+                                    float gs_j, float gs_i, const float* cn, float* cost_sum, float* weight_sum)
+{
+    const orc_uchar4 p1 = tex_u8x4(img1, w, h, sx1, sy1), p2 = tex_u8x4(img2, w, h, sx2, sy2);
+    const int hamming = popcount8(tex_u8(c1, w, h, sx1, sy1) ^ tex_u8(c2, w, h, sx2, sy2));
+    const float cost = g_tol_td[max_abs_diff_u8(p1, p2)] + cn[hamming];
+    const float wa = g_tol_ta[max_abs_diff_u8(center1, p1)] * (gs_j * gs_i);      /* the source half, hoisted on the GPU */
+    const float weight = wa * g_tol_ta[max_abs_diff_u8(center2, p2)];
+    if (g_tol.mode & 2) *cost_sum = fmaf(cost, weight, *cost_sum); else *cost_sum += cost * weight;
+    *weight_sum += weight;
+}
+
 float orc_patch_dist(const orc_uchar4* img1, const orc_uchar4* img2, const uint8_t* c1, const uint8_t* c2,
                      int w, int h, int R, const float* gs, const float* cn, int x1, int y1, int x2, int y2)
 {
     init_unorm();
+    if ((g_tol.mode & 1) && (g_tol.scope & 1)) {
+        const orc_uchar4 k1 = tex_u8x4(img1, w, h, x1, y1), k2 = tex_u8x4(img2, w, h, x2, y2);
+        float cost_sum = 0.0f, weight_sum = 0.0f;
+        for (int i = -R; i <= R; i += 2) {
+            float cr = 0.0f, wr = 0.0f;
+            float* pc = (g_tol.mode & 4) ? &cr : &cost_sum;
+            float* pw = (g_tol.mode & 4) ? &wr : &weight_sum;
+            for (int j = -R; j <= R; j += 2)
+                patch_sample_tol(img1, img2, c1, c2, w, h, k1, k2, x1 + j, y1 + i, x2 + j, y2 + i, gs[abs(j)], gs[abs(i)], cn, pc, pw);
+            if (g_tol.mode & 4) { cost_sum += cr; weight_sum += wr; }
+        }
+        return cost_sum / weight_sum;
+    }
     rgbf center1 = tex_rgb(img1, w, h, x1, y1);
     rgbf center2 = tex_rgb(img2, w, h, x2, y2);
     float cost_sum = 0.0f, weight_sum = 0.0f;
@@ -473,6 +530,9 @@ float orc_patch_dist_planefit(const orc_uchar4* img1, const orc_uchar4* img2, co
     rgbf center2 = tex_rgb(img2, w, h, x2, y2);
     const float uu = (float)(x2 - x1);
     const float vv = (float)(y2 - y1);
+    const int tol = (g_tol.mode & 1) && (g_tol.scope & 2);
+    const orc_uchar4 k1 = tex_u8x4(img1, w, h, x1, y1), k2 = tex_u8x4(img2, w, h, x2, y2);
+    float rows_c[64] = {0}, rows_w[64] = {0};
     float c4[4];
     for (int pass = 0; pass < 4; pass++) {
         const float* cf = kPlaneCoef[pass];
@@ -487,9 +547,17 @@ float orc_patch_dist_planefit(const orc_uchar4* img1, const orc_uchar4* img2, co
                     cx2 = cx1 + uu + (j)*cf[0] + (i)*cf[1];
                     cy2 = cy1 + vv + (j)*cf[2] + (i)*cf[3];
                 }
+                if (tol) {
+                    float* pc = (g_tol.mode & 4) ? &rows_c[(i + R) / 2] : &cost_sum;
+                    float* pw = (g_tol.mode & 4) ? &rows_w[(i + R) / 2] : &weight_sum;
+                    patch_sample_tol(img1, img2, c1, c2, w, h, k1, k2, (int)floorf(cx1), (int)floorf(cy1),
+                                     (int)floorf(cx2), (int)floorf(cy2), gs[abs(j)], gs[abs(i)], cn, pc, pw);
+                } else
                 patch_sample(img1, img2, c1, c2, w, h, center1, center2, (int)floorf(cx1), (int)floorf(cy1),
                              (int)floorf(cx2), (int)floorf(cy2), gs[abs(j)], gs[abs(i)], cn, &cost_sum, &weight_sum);
             }
+        if (tol && (g_tol.mode & 4))
+            for (int r = 0; r <= R; r++) { cost_sum += rows_c[r]; weight_sum += rows_w[r]; rows_c[r] = rows_w[r] = 0.0f; }
         c4[pass] = cost_sum / weight_sum;
     }
     /* __min(cost1,__min(cost2,__min(cost3,cost4))) :512 with __min(a,b) = (a<b)?a:b
@@ -1028,7 +1096,8 @@ void orc_flow_smoothing(orc_float2* flow, const orc_uchar4* img, int w, int h)
                     if (cf.x > UNKNOWN_FLOW_THRESH || cf.y > UNKNOWN_FLOW_THRESH) continue;
                     rgbf pix = tex_rgb(img, w, h, cx, cy);
                     float delta_r = max_abs_diff(center, pix);
-                    float coef_r = orc_fast_exp(-(delta_r * delta_r) / (POSTPROC_BLF_SIG_R * POSTPROC_BLF_SIG_R));
+                    float coef_r = (g_tol.scope & 4) ? g_tol_tw[max_abs_diff_u8(tex_u8x4(img, w, h, x, y), tex_u8x4(img, w, h, cx, cy))]
+                                 : orc_fast_exp(-(delta_r * delta_r) / (POSTPROC_BLF_SIG_R * POSTPROC_BLF_SIG_R));
                     float coef_s = g[abs(dx)] * g[abs(dy)];
                     float wgt = coef_r * coef_s;
                     nx += wgt * cf.x; ny += wgt * cf.y; wsum += wgt;

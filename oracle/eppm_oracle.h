@@ -57,6 +57,10 @@ void  orc_default_params(orc_params* p);
 /* OTHER legal readings of the racy / unspecified parts of the reference, for measuring how far they move the flow
  * (tools/parity_envelope.py); all zero = the lockstep oracle, the only reading used for parity.  See eppm_oracle.c. */
 void  orc_set_variant(int sweep_order, int post_inplace, int exp_mode, int seed_variant);
+/* Tolerance-arithmetic variants: the integer-domain table form of the patch term and freer summation orders that
+ * libeppm_hip_tol.so uses (tools/tolerance_envelope.py measures their end-point error against the default oracle; (0, 0) = off).
+ * mode / scope bits: see eppm_oracle.c.  Never the parity oracle. */
+void  orc_set_tol_variant(int mode, int scope);
 
 /* ---- arithmetic building blocks ---- */
 float orc_fast_exp(float x);                       /* restates __expf (see .c) */

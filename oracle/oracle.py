@@ -363,6 +363,12 @@ def set_variant(sweep_order=0, post_inplace=0, exp_mode=0, seed_variant=0):
     lib().orc_set_variant(int(sweep_order), int(post_inplace), int(exp_mode), int(seed_variant))
 
 
+def set_tol_variant(mode=0, scope=0):
+    """Tolerance-arithmetic variants of the patch term (eppm_oracle.c: orc_set_tol_variant); (0, 0) = the lockstep oracle.
+    Used only by tools/tolerance_envelope.py and its test."""
+    lib().orc_set_tol_variant(int(mode), int(scope))
+
+
 def num_threads():
     return lib().orc_num_threads()
 

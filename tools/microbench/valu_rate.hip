@@ -62,6 +62,19 @@ KERNEL(k_mul_lo,   "v_mul_lo_u32 %4, %4, %5\n")
 KERNEL(k_add3,     "v_add3_u32 %4, %4, %5, %4\n")
 KERNEL(k_sub_e64,  "v_sub_f32_e64 %0, %1, |%0|\n")
 KERNEL(k_mov,      "v_mov_b32_e32 %0, %1\n")
+// round 6: the integer-domain patch term of the tolerance library
+KERNEL(k_sad_u32,  "v_sad_u32 %4, %5, %4, 0\n")
+KERNEL(k_sad_u8,   "v_sad_u8 %4, %5, %4, 0\n")
+KERNEL(k_max3_u32, "v_max3_u32 %4, %5, %4, %4\n")
+KERNEL(k_max3_i32, "v_max3_i32 %4, %5, %4, %4\n")
+KERNEL(k_cvt_u32,  "v_cvt_u32_f32 %4, %0\n")
+KERNEL(k_mul24_sdwa, "v_mul_u32_u24_sdwa %4, %5, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n")
+KERNEL(k_lshl_sdwa, "v_lshlrev_b32_sdwa %4, %5, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n")
+KERNEL(k_sub_sdwa, "v_sub_u32_sdwa %4, %5, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n")
+KERNEL(k_pk_max_u16, "v_pk_max_u16 %4, %5, %4\n")
+KERNEL(k_pk_sub_i16, "v_pk_sub_i16 %4, %5, %4\n")
+KERNEL(k_max_u32,  "v_max_u32_e32 %4, %5, %4\n")
+KERNEL(k_and_or,   "v_and_or_b32 %4, %4, %5, %4\n")
 
 // packed fp32: two independent IEEE operations per lane in one instruction (64-bit register pairs)
 #define KERNEL_PK(name, asmtext)                                                               \
@@ -98,6 +111,9 @@ int main()
         {"v_bfe_u32", k_bfe}, {"v_perm_b32", k_perm}, {"v_cmp_lt_f32 vcc", k_cmp}, {"v_cvt_f32_i32", k_cvt_f_i}, {"v_cvt_f32_ubyte0", k_cvt_ub},
         {"v_mad_u32_u24", k_mad24}, {"v_floor_f32", k_floor}, {"v_fract_f32", k_fract}, {"v_mul_lo_u32", k_mul_lo}, {"v_add3_u32", k_add3},
         {"v_sub_f32_e64 |abs|", k_sub_e64}, {"v_mov_b32", k_mov},
+        {"v_sad_u32", k_sad_u32}, {"v_sad_u8", k_sad_u8}, {"v_max3_u32", k_max3_u32}, {"v_max3_i32", k_max3_i32}, {"v_cvt_u32_f32", k_cvt_u32},
+        {"v_mul_u32_u24_sdwa", k_mul24_sdwa}, {"v_lshlrev_b32_sdwa", k_lshl_sdwa}, {"v_sub_u32_sdwa", k_sub_sdwa}, {"v_pk_max_u16", k_pk_max_u16},
+        {"v_pk_sub_i16", k_pk_sub_i16}, {"v_max_u32", k_max_u32}, {"v_and_or_b32", k_and_or},
         {"v_pk_add_f32 (2 adds)", k_pk_add}, {"v_pk_mul_f32 (2 muls)", k_pk_mul}, {"v_pk_fma_f32 (2 fmas)", k_pk_fma},
     };
     hipEvent_t e0, e1;

@@ -1,10 +1,11 @@
-"""End-point error of the opt-in libeppm_hip_approx.so (hardware v_exp_f32 instead of the shared exp formula; NOT bit-identical)
-against the exact library -- which equals the CPU oracle bit for bit (tests/), so this is the EPE against the oracle at sizes the
-oracle cannot be re-run at on the GPU box.  Cases: the bundled frame10/frame11 pair forwards (north_star's tolerance case:
-<= 1e-3 px mean EPE) and backwards, BASELINE configs[1] (1024x436), configs[3] (1920x1080), configs[4] (3840x2160, radius 17;
-only with --all) and the eight fixed-seed fuzz cases of tests/test_configs_gpu.py.  Prints one JSON line.
+"""End-point error of the tolerance library libeppm_hip_tol.so (integer-domain tables instead of the two software exp of the patch
+term, free summation order; NOT bit-identical) against the exact library -- which equals the CPU oracle bit for bit (tests/), so
+this is the EPE against the oracle at sizes the oracle cannot be re-run at on the GPU box.  Cases: the bundled frame10/frame11
+pair forwards (north_star's tolerance case: <= 1e-3 px mean EPE) and backwards, BASELINE configs[1] (1024x436), configs[3]
+(1920x1080), configs[4] (3840x2160, radius 17; only with --all) and the eight fixed-seed fuzz cases of tests/test_configs_gpu.py.
+Prints one JSON line.
 
-usage: approx_exp_epe.py [--all]        (internal: --dump FILE computes the flows with the library EPPM_HIP_VARIANT selects)"""
+usage: tolerance_epe.py [--all]        (internal: --dump FILE computes the flows with the library EPPM_HIP_VARIANT selects)"""
 import json
 import os
 import subprocess
@@ -36,7 +37,10 @@ def cases(all_sizes):
 def flows(all_sizes):
     import eppm_amd
     res = {}
-    for name, a, b, params in cases(all_sizes):
+    todo = cases(all_sizes)
+    # (importing tests/conftest.py selected the parity tests' library for this process: select the one this run is about)
+    eppm_amd.select_library(os.environ.get("EPPM_HIP_VARIANT", "") or "")
+    for name, a, b, params in todo:
         h, w, _ = a.shape
         e = eppm_amd.EPPM(params=eppm_amd.Params(**params) if params else None)
         e.init(a, b, h, w)
@@ -53,8 +57,8 @@ def main():
         np.savez(sys.argv[sys.argv.index("--dump") + 1], version=np.array(ver), **res)
         return
     with tempfile.TemporaryDirectory() as td:
-        f = os.path.join(td, "approx.npz")
-        env = dict(os.environ, EPPM_HIP_VARIANT="approx")
+        f = os.path.join(td, "tol.npz")
+        env = dict(os.environ, EPPM_HIP_VARIANT="tol")
         subprocess.run([sys.executable, os.path.abspath(__file__), "--dump", f] + (["--all"] if all_sizes else []), env=env, check=True)
         ap = np.load(f)
         approx = {k: ap[k] for k in ap.files}
@@ -64,7 +68,7 @@ def main():
     for k in sorted(k[:-2] for k in exact if k.endswith("_u")):
         epe = np.sqrt((approx[k + "_u"].astype(np.float64) - exact[k + "_u"]) ** 2 + (approx[k + "_v"].astype(np.float64) - exact[k + "_v"]) ** 2)
         out["cases"][k] = {"epe_mean_px": float(epe.mean()), "epe_p99_px": float(np.percentile(epe, 99)), "epe_max_px": float(epe.max()),
-                           "pixels_differing": float((epe > 0).mean()), "pixels": int(epe.size)}
+                           "pixels_differing": float((epe > 0).mean()), "frac_over_1px": float((epe > 1.0).mean()), "pixels": int(epe.size)}
     # the keys bench.py and the test read
     out["pair"] = "frame10/11 640x480"
     out["epe_mean_px"] = out["cases"]["bundled_640x480"]["epe_mean_px"]

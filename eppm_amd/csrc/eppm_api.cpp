@@ -612,6 +612,8 @@ struct eppm_ctx {
     uint8_t *cen1[kMaxLevels] = {}, *cen2[kMaxLevels] = {};
     void *pk1[kMaxLevels] = {}, *pk2[kMaxLevels] = {};       // float4 texel planes {r,g,b,census}, linear (pitch = w)
     uint32_t *pc1[kMaxLevels] = {}, *pc2[kMaxLevels] = {};   // the same texels in 4 bytes, at the levels the LDS-window refine runs on
+    uint32_t *pp1 = nullptr, *pp2 = nullptr;                 // tolerance library: column-parity planes of pc at the PatchMatch level (PlanesH::pp1)
+    int pp_pitch = 0, pp_pad = 0;
     int16_t *nnf1 = nullptr, *nnf2 = nullptr, *nnf_tmp = nullptr, *nnf_tmp2 = nullptr;
     float *cost1 = nullptr, *cost2 = nullptr;
     float *spec1 = nullptr, *spec2 = nullptr;   // evaluation cache of the sweeps (PmProblem::spec / scand): four direction planes each
@@ -657,6 +659,11 @@ static PlanesH planes(const eppm_ctx* c, int l, bool swap)
     p.pitch = c->W[l];
     p.pc1 = swap ? c->pc2[l] : c->pc1[l];
     p.pc2 = swap ? c->pc1[l] : c->pc2[l];
+    if (l == c->nl - 1 && c->pp1) {
+        p.pp1 = swap ? c->pp2 : c->pp1;
+        p.pp2 = swap ? c->pp1 : c->pp2;
+        p.pp_pitch = c->pp_pitch; p.pp_pad = c->pp_pad;
+    }
     return p;
 }
 
@@ -772,6 +779,12 @@ static int ctx_alloc(eppm_ctx* c)
     }
     const int L = c->nl - 1;
     const size_t n2 = (size_t)c->W[L] * c->H[L];
+#ifdef EPPM_TOL
+    c->pp_pad = (c->prm.patch_r + 2) & ~1;                  // even and >= R + 1: a target column is in [0, w], a sample within R of it
+    c->pp_pitch = parity_pitch(c->W[L], c->pp_pad);
+    plane((void**)&c->pp1, (size_t)2 * c->H[L] * c->pp_pitch * 4);
+    plane((void**)&c->pp2, (size_t)2 * c->H[L] * c->pp_pitch * 4);
+#endif
     plane((void**)&c->nnf1, n2 * 4);
     plane((void**)&c->nnf2, n2 * 4);
     plane((void**)&c->nnf_tmp, n2 * 4);
@@ -914,6 +927,11 @@ static int prepare(eppm_ctx* c)
             J.packed = k ? c->pc2[i] : c->pc1[i];
         }
     launch_census_batch(cb, s, bt);
+    if (c->pp1) {
+        const int L = c->nl - 1;
+        launch_parity_planes(c->pp1, c->pp_pitch, c->pp_pad, c->pc1[L], c->W[L], c->W[L], c->H[L], s, bt);
+        launch_parity_planes(c->pp2, c->pp_pitch, c->pp_pad, c->pc2[L], c->W[L], c->W[L], c->H[L], s, bt);
+    }
     stage_end(c, c->ev_prep);
     HIPCHK(hipGetLastError());
     c->have_images = true;

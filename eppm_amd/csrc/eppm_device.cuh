@@ -136,22 +136,21 @@ __device__ __forceinline__ float census_cost(const float* __restrict__ cnx, uint
 }
 #else
 // ---- the tolerance library (libeppm_hip_tol.so, -DEPPM_TOL) ------------------------------------------------
-// NOT bit-identical to the oracle: the two software exp of a patch term (and their exact divisions) become table reads in the
-// INTEGER domain.  A channel of a texel is u8/255, so the L-inf distance of two texels is k/255 with k the integer L-inf distance of
-// their bytes (up to the rounding of u8/255, 1 ulp), hence
-//     1 - exp(-d^2/s) + cn[hamming]  = tdc[k_d][hamming]          exp(-(a^2+b^2)/s) = ta[k_a] * ta[k_b]
-// with the tables formed on the host in double.  Perturbation: ~2e-7 relative on a patch cost -- the class of the reference's own
-// 2-ulp __expf (bao_pmflow_kernel.cu:283,289); what it does to the flow is measured by tools/tolerance_envelope.py on the CPU
-// (mean EPE <= 7e-6 px on frame10/frame11, 0 on the 1024x436 synthetic pair) and asserted on the GPU by the -m gpu suite.
+// NOT bit-identical to the oracle: the two software exp of a patch term (and their exact divisions) leave the patch term.  A channel
+// of a texel is u8/255, so the L-inf distance of two texels is k/255 with k the INTEGER L-inf distance of their bytes (up to the
+// rounding of u8/255, 1 ulp), hence
+//     1 - exp(-d^2/s) = td[k_d]          exp(-(a^2+b^2)/s) = ta[k_a] * ta[k_b]   or   exp2(-c (k_a^2 + k_b^2)),  c = log2(e) / (255^2 s)
+// with the 256-entry tables formed on the host in double.  Perturbation: ~2e-7 relative on a patch cost -- the class of the
+// reference's own 2-ulp __expf (bao_pmflow_kernel.cu:283,289); what it does to the flow is measured by tools/tolerance_envelope.py
+// on the CPU (mean EPE <= 1.1e-5 px on frame10/frame11, 0 on the 1024x436 synthetic pair) and asserted on the GPU by the -m gpu suite.
 //
-// Texel = { s*R, s*G, s*B as INTEGER BIT PATTERNS, census * 0x01010101 }, s = kTolScale = the byte stride of a table row.  An
-// integer below 2^23 read as a float is a denormal, and gfx950 adds denormals exactly at full rate (kernels run with
-// float_denorm_mode_32 = preserve): v_sub_f32 x3 + v_max3_f32 |.| leave the bits of s*k -- the byte offset of table row k -- in 4
-// instructions / 10 issue cycles, no conversion (tools/ubench/denormal_int_linf.hip: 0 mismatches, 2.3 / 4.0 cycles).  The census
-// byte is replicated into the four bytes of its word, so that popcount(w1 ^ w2) = 4 * hamming = the byte offset inside the row:
-// v_xor + v_bcnt_u32_b32 (which adds the row offset for free) and ONE LDS read give the whole cost term.
-constexpr int kTolRow = 10;                          // floats per row: [0..8] = 1 - exp(-(k/255)^2/s) + cn[hamming], [9] = exp(-(k/255)^2/s)
-constexpr unsigned kTolScale = 4u * kTolRow;         // bytes per row
+// Texel = { 4R, 4G, 4B as INTEGER BIT PATTERNS, census * 0x01010101 }.  An integer below 2^23 read as a float is a denormal, and
+// gfx950 subtracts denormals exactly at full rate (kernels run with float_denorm_mode_32 = preserve): v_sub_f32 x3 + v_max3_f32 |.|
+// leave the bits of 4k -- the byte offset of table entry k -- in 4 instructions / 10 issue cycles, no conversion
+// (tools/ubench/denormal_int_linf.hip: 0 mismatches; 2.3 / 4.0 cycles per instruction).  The census byte is replicated into the four
+// bytes of its word: popcount(w1 ^ w2) = 4 * hamming = the byte offset of cn[hamming] (9 entries in 9 banks: conflict free, where the
+// exact library's 256-entry cnx[] costs ~5 bank-conflict cycles per read).
+constexpr unsigned kTolScale = 4u;                   // texel channel = kTolScale * byte value = byte offset into td[] / ta[]
 __device__ __forceinline__ float4 make_texel(uint32_t rgba, uint32_t census)
 {
     return make_float4(__uint_as_float((rgba & 0xffu) * kTolScale), __uint_as_float(((rgba >> 8) & 0xffu) * kTolScale),
@@ -220,24 +219,51 @@ __device__ __forceinline__ void patch_accum(float& cost_sum, float& weight_sum, 
     weight_sum += weight_term;
 }
 #else
-// byte offset of the table row of the L-inf distance of two texels (see make_texel)
-__device__ __forceinline__ uint32_t linf_row(const rgbf a, const rgbf b) { return __float_as_uint(max_abs_diff(a, b)); }
-__device__ __forceinline__ float tol_cost(const float* __restrict__ tdc, uint32_t row, uint32_t w1, uint32_t w2)
+struct TolTables {            // in LDS, first member of every kernel's table block (offsets below 64 KB: immediates of the ds_read)
+    float td[256];            // 1 - exp(-(k/255)^2/s)
+    float ta[256];            // exp(-(k/255)^2/s)
+    float cn[16];             // cn[0..8], kernel.cu:670-687
+};
+// byte offset 4k of table entry k = the L-inf distance of two texels (see make_texel)
+__device__ __forceinline__ uint32_t linf_off(const rgbf a, const rgbf b) { return __float_as_uint(max_abs_diff(a, b)); }
+__device__ __forceinline__ float tol_at(const float* __restrict__ t, uint32_t byte_off)
 {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(tdc) + (row + (uint32_t)__builtin_popcount(w1 ^ w2)));
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(t) + byte_off);
 }
-__device__ __forceinline__ float tol_weight(const float* __restrict__ tdc, uint32_t row)
+// 1 - exp(-d^2/s) + cn[hamming]
+__device__ __forceinline__ float tol_cost(const TolTables& T, const rgbf p1, const rgbf p2, uint32_t w1, uint32_t w2)
 {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(tdc) + (row + 4u * (kTolRow - 1)));
+    return tol_at(T.td, linf_off(p1, p2)) + tol_at(T.cn, (uint32_t)__builtin_popcount(w1 ^ w2));
 }
+// exp2(lsrc - c k^2) by the hardware v_exp_f32, for an L-inf distance given as its byte offset 4k; c = log2(e) / (255^2 s).  Results
+// below 2^-126 are 0 (the instruction flushes; the exact library keeps them down to 2^-150).
+constexpr float kTolExpC = (float)(1.4426950408889634 / (255.0 * 255.0 * (double)kPmSigR2) / (double)(kTolScale * kTolScale));
+__device__ __forceinline__ float tol_exp_arg(uint32_t off4k, float lsrc)
+{
+    const float kf = (float)off4k;
+    return __builtin_fmaf(kf * kf, -kTolExpC, lsrc);
+}
+// a word {R, G, B, census} of the 4-byte planes -> the texel make_texel builds from it: three SDWA shifts (byte k << 2) and a byte permute
+// (census into all four bytes), 16 issue cycles; `two` = a register holding 2 (an SDWA operand cannot be an inline constant)
+__device__ __forceinline__ float4 unpack_texel(uint32_t w, uint32_t two)
+{
+    uint32_t r, g, b;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w));
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(g) : "v"(two), "v"(w));
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(b) : "v"(two), "v"(w));
+    static_assert(kTolScale == 4u, "the shift above");
+    return make_float4(__uint_as_float(r), __uint_as_float(g), __uint_as_float(b), __uint_as_float(__builtin_amdgcn_perm(w, w, 0x03030303u)));
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // cost_term = the sample's cost (NOT yet multiplied by its weight: patch_accum fuses that), weight_term = its weight
 __device__ __forceinline__ void patch_terms(const float4 q1, const float4 q2, const rgbf c1, const rgbf c2, float gsp,
-                                            const float* __restrict__ tdc, float& cost_term, float& weight_term)
+                                            const TolTables& T, float& cost_term, float& weight_term)
 {
     const rgbf p1 = texel_rgb(q1);
     const rgbf p2 = texel_rgb(q2);
-    cost_term = tol_cost(tdc, linf_row(p1, p2), __float_as_uint(q1.w), __float_as_uint(q2.w));
-    weight_term = (tol_weight(tdc, linf_row(c1, p1)) * gsp) * tol_weight(tdc, linf_row(c2, p2));
+    cost_term = tol_cost(T, p1, p2, __float_as_uint(q1.w), __float_as_uint(q2.w));
+    weight_term = (tol_at(T.ta, linf_off(c1, p1)) * gsp) * tol_at(T.ta, linf_off(c2, p2));
 }
 __device__ __forceinline__ void patch_accum(float& cost_sum, float& weight_sum, float cost_term, float weight_term)
 {
@@ -246,8 +272,9 @@ __device__ __forceinline__ void patch_accum(float& cost_sum, float& weight_sum, 
 }
 #endif
 
+template <class TAB>
 __device__ __forceinline__ void patch_sample(const Planes& P, const rgbf c1, const rgbf c2, int sx1, int sy1, int sx2,
-                                             int sy2, float gsp, const float* __restrict__ cnx, float& cost_term,
+                                             int sy2, float gsp, const TAB& cnx, float& cost_term,
                                              float& weight_term)
 {
     const float4 q1 = tex_px(P.pk1, P.pitch, P.w, P.h, sx1, sy1);
@@ -255,39 +282,45 @@ __device__ __forceinline__ void patch_sample(const Planes& P, const rgbf c1, con
     patch_terms(q1, q2, c1, c2, gsp, cnx, cost_term, weight_term);
 }
 
-// LUTs staged in LDS by every patch kernel: gsp[i*S + j] = gs[|2j-R|]*gs[|2i-R|], and the table of the per-sample terms -- tab():
-// exact library cnx[b] = cn[popcount(b)]; tolerance library tdc[k][0..9] (see make_texel)
+// LUTs staged in LDS by every patch kernel: gsp[i*S + j] = gs[|2j-R|]*gs[|2i-R|], and the table(s) of the per-sample terms -- tab():
+// exact library cnx[b] = cn[popcount(b)]; tolerance library td[], ta[], cn[] (TolTables, FIRST: low LDS addresses)
 template <int MAXS>
 struct PatchLutT {
-    float gsp[MAXS * MAXS];
 #ifndef EPPM_TOL
+    float gsp[MAXS * MAXS];
     float cnx[256];
     __device__ __forceinline__ const float* tab() const { return cnx; }
 #else
-    float tdc[256 * kTolRow];
-    __device__ __forceinline__ const float* tab() const { return tdc; }
+    TolTables T;
+    float gsp[MAXS * MAXS];
+    __device__ __forceinline__ const TolTables& tab() const { return T; }
 #endif
 };
 using PatchLut = PatchLutT<kMaxS>;     // any radius the ABI accepts; kernels instantiated per radius use PatchLutT<R + 1>
+#ifdef EPPM_TOL
+#define EPPM_LUT_ALIGN alignas(1024)   // the LDS allocator places the most aligned object first: the tables' offsets fit a ds_read's 16-bit immediate
+#else
+#define EPPM_LUT_ALIGN
+#endif
 
 // lut_src layout in global memory: gs[0..R] then cn[0..8]; tolerance library: then td[0..255] = 1 - exp(-(k/255)^2/s) and
 // ta[0..255] = exp(-(k/255)^2/s), s = LAMBDA_AD^2 = PM_SIG_R^2, formed in double on the host (eppm_api.cpp: host_pm_lut)
-template <int MAXS>
+// LOG2 (tolerance library's refine kernels): gsp[] holds log2 of the products -- the weight there is ONE exp2 of a summed argument
+template <bool LOG2 = false, int MAXS>
 __device__ __forceinline__ void load_patch_lut(PatchLutT<MAXS>& L, const float* __restrict__ lut_src, int R, int tid, int nthreads)
 {
     const int S = R + 1;
     for (int t = tid; t < S * S; t += nthreads) {
         const int i = t / S, j = t % S;
         const int ai = abs(2 * i - R), aj = abs(2 * j - R);
-        L.gsp[i * S + j] = lut_src[aj] * lut_src[ai];
+        const float g = lut_src[aj] * lut_src[ai];
+        L.gsp[i * S + j] = LOG2 ? log2f(g) : g;
     }
 #ifndef EPPM_TOL
     for (int t = tid; t < 256; t += nthreads) L.cnx[t] = lut_src[R + 1 + __builtin_popcount(t)];
 #else
-    for (int t = tid; t < 256 * kTolRow; t += nthreads) {
-        const int k = t / kTolRow, p = t - k * kTolRow;
-        L.tdc[t] = (p < kTolRow - 1) ? lut_src[R + 10 + k] + lut_src[R + 1 + p] : lut_src[R + 10 + 256 + k];
-    }
+    for (int t = tid; t < 256; t += nthreads) { L.T.td[t] = lut_src[R + 10 + t]; L.T.ta[t] = lut_src[R + 10 + 256 + t]; }
+    for (int t = tid; t < 16; t += nthreads) L.T.cn[t] = (t < 9) ? lut_src[R + 1 + t] : 0.0f;
 #endif
 }
 

@@ -35,7 +35,17 @@ struct PlanesH {            // host-side mirror of eppm::Planes: float4 texel pl
     // a whole tile / window in LDS read these and convert while storing (a quarter of the HBM and L2 bytes for the same values)
     const uint32_t* pc1 = nullptr;
     const uint32_t* pc2 = nullptr;
+    // optional, tolerance library only (NULL: absent): COLUMN-PARITY planes of the 4-byte texels at the PatchMatch level.  The patch samples
+    // every other column, so the S samples of a patch row are S CONSECUTIVE words of the plane of their column parity: 3 gathers per row of 10
+    // samples instead of 10 (the kernels that give a lane a whole evaluation run at the L1's lane rate).  Layout: word [p][y][i] = texel
+    // (clamp(2i + p - pp_pad, 0, w - 1), y) -- replicate padding = the clamp addressing of the texture model; pp_pitch words per row.
+    const uint32_t* pp1 = nullptr;
+    const uint32_t* pp2 = nullptr;
+    int pp_pitch = 0, pp_pad = 0;
 };
+inline int parity_pitch(int w, int pad) { return (w + 2 * pad + 1) / 2 + 1; }      // words per row of one parity plane
+// the two parity planes of one image (k_prepare.hip); pc = its 4-byte texel plane, pitch pc_pitch words
+void launch_parity_planes(uint32_t* pp, int pp_pitch, int pad, const uint32_t* pc, int pc_pitch, int w, int h, hipStream_t s, Batch bt = kOnePair);
 
 // ---- prepare (k_prepare.hip) ----
 void launch_gauss_rgba(uint32_t* out, const uint32_t* in, int pitch_px, int h, int w, float sigma, int radius, hipStream_t s, Batch bt = kOnePair);

@@ -17,6 +17,11 @@ namespace eppm {
 #ifndef EPPM_BLF_UNROLL
 #define EPPM_BLF_UNROLL 21
 #endif
+#ifdef EPPM_TOL
+#define EPPM_C2F_LOG2 true      // the tolerance library's tile kernels keep log2(gs_j gs_i): their weight is one exp2 (eppm_device.cuh)
+#else
+#define EPPM_C2F_LOG2 false
+#endif
 #define EPPM_PRAGMA_(x) _Pragma(#x)
 #define EPPM_UNROLL(n) EPPM_PRAGMA_(unroll n)
 
@@ -86,7 +91,7 @@ void launch_mul_scalar(float* flow, float scale, int h, int w, hipStream_t s)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_c2f_refine(PlanesH Ph, float* __restrict__ flow_, const float* __restrict__ lut, int R, size_t pstride)
 {
-    __shared__ PatchLut L;
+    __shared__ EPPM_LUT_ALIGN PatchLut L;
     load_patch_lut(L, lut, R, threadIdx.y * kBlock + threadIdx.x, 256);
     __syncthreads();
     const Planes P = to_dev(Ph, pstride, blockIdx.z);
@@ -193,6 +198,9 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLutT<R + 1>
     constexpr int S = R + 1;
     constexpr int TP = (PASS == 0) ? 0 : PASS - 1;
     const C2fTables<R>& T = c2f_tables<R>();
+#ifdef EPPM_TOL
+    const float* __restrict__ lg2 = L.gsp;          // log2(gs_j gs_i), load_patch_lut<true>
+#endif
     float cs[3] = {0.0f, 0.0f, 0.0f}, ws[3] = {0.0f, 0.0f, 0.0f};
     const unsigned pitch16 = (unsigned)P.pitch << 4;
 #pragma unroll 1
@@ -211,7 +219,7 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
             const rgbf p1 = texel_rgb(q1);
             const uint32_t k1 = __float_as_uint(q1.w);
 #ifdef EPPM_TOL
-            const float wsrc = tol_weight(L.tab(), linf_row(c1, p1)) * L.gsp[ii * S + jj];      // the source half of the weight: once per sample
+            const float lsrc = tol_exp_arg(linf_off(c1, p1), lg2[ii * S + jj]);               // log2 of the source half of the weight: once per sample
 #else
             float a2 = max_abs_diff(c1, p1);
             a2 *= a2;
@@ -240,9 +248,8 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
             for (int n = 0; n < 3; n++) {
                 const rgbf p2 = texel_rgb(q2[n]);
 #ifdef EPPM_TOL
-                const float cost = tol_cost(L.tab(), linf_row(p1, p2), k1, __float_as_uint(q2[n].w));
-                const float weight = wsrc * tol_weight(L.tab(), linf_row(c2[n], p2));
-                patch_accum(cs[n], ws[n], cost, weight);
+                const float cost = tol_cost(L.tab(), p1, p2, k1, __float_as_uint(q2[n].w));
+                patch_accum(cs[n], ws[n], cost, __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2[n], p2), lsrc)));
 #else
                 float cost = max_abs_diff(p1, p2);
                 cost = one_minus_fast_exp(div_ad2(-(cost * cost)));
@@ -292,10 +299,10 @@ __global__ __launch_bounds__(256) EPPM_C2F_OCC void k_c2f_refine_tiled(PlanesH P
     // of 8 lanes of one tile row and 8 of the next (MI355X LDS lane groups); with the stride = 0 mod 256 B the two
     // halves fall on disjoint banks (34-texel rows cost a 2-way conflict on about every read)
     constexpr int TW = (TWU + 15) / 16 * 16;
-    __shared__ PatchLutT<R + 1> L;
+    __shared__ EPPM_LUT_ALIGN PatchLutT<R + 1> L;
     __shared__ float4 s_src[TWU * TW];
     const int tid = threadIdx.y * kBlock + threadIdx.x;
-    load_patch_lut(L, lut, R, tid, 256);
+    load_patch_lut<EPPM_C2F_LOG2>(L, lut, R, tid, 256);
     const Planes P = to_dev(Ph, pstride, blockIdx.y);
     // XCD-aware tile order: workgroups are dealt round robin over the 8 XCDs (b % 8), each with its own L2.
     // Give XCD k the k-th contiguous eighth of the row-major tile list so that neighbouring tiles -- which
@@ -390,11 +397,7 @@ struct C2fWinGeom {
     static constexpr int yhi() { int v = R; const auto T = make_c2f_tables<R>(); for (int p = 0; p < 3; p++) for (int i = 0; i <= R; i++) v = T.rowdy[p][i] + 1 > v ? T.rowdy[p][i] + 1 : v; return v; }
 };
 #ifndef EPPM_C2F_WIN_H
-#ifdef EPPM_TOL
-#define EPPM_C2F_WIN_H 46      // the tolerance library's 10 KB term table: a 46-row window and a 40-texel source row stride keep two workgroups per CU
-#else
 #define EPPM_C2F_WIN_H 50
-#endif
 #endif
 #ifndef EPPM_C2F_PASS2
 #define EPPM_C2F_PASS2 1
@@ -414,6 +417,9 @@ __device__ __forceinline__ void c2f_pass2_win(const PatchLutT<R + 1>& L, const f
     constexpr int S = R + 1;
     constexpr int TA = (PA == 0) ? 0 : PA - 1, TB = (PB == 0) ? 0 : PB - 1;
     const C2fTables<R>& T = c2f_tables<R>();
+#ifdef EPPM_TOL
+    const float* __restrict__ lg2 = L.gsp;          // log2(gs_j gs_i), load_patch_lut<true>
+#endif
     float csA[3] = {0.0f, 0.0f, 0.0f}, wsA[3] = {0.0f, 0.0f, 0.0f}, csB[3] = {0.0f, 0.0f, 0.0f}, wsB[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll 1
     for (int ii = 0; ii < S; ii++) {
@@ -425,7 +431,7 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
             const rgbf p1 = texel_rgb(q1);
             const uint32_t k1 = __float_as_uint(q1.w);
 #ifdef EPPM_TOL
-            const float wsrc = tol_weight(L.tab(), linf_row(c1, p1)) * L.gsp[ii * S + jj];      // the source half of the weight: once per 6 terms
+            const float lsrc = tol_exp_arg(linf_off(c1, p1), lg2[ii * S + jj]);               // log2 of the source half of the weight: once per 6 terms
 #else
             float a2 = max_abs_diff(c1, p1);
             a2 *= a2;
@@ -443,13 +449,13 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
 #ifdef EPPM_TOL
                 {
                     const rgbf p2 = texel_rgb(qa[n]);
-                    const float cost = tol_cost(L.tab(), linf_row(p1, p2), k1, __float_as_uint(qa[n].w));
-                    patch_accum(csA[n], wsA[n], cost, wsrc * tol_weight(L.tab(), linf_row(c2[n], p2)));
+                    const float cost = tol_cost(L.tab(), p1, p2, k1, __float_as_uint(qa[n].w));
+                    patch_accum(csA[n], wsA[n], cost, __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2[n], p2), lsrc)));
                 }
                 {
                     const rgbf p2 = texel_rgb(qb[n]);
-                    const float cost = tol_cost(L.tab(), linf_row(p1, p2), k1, __float_as_uint(qb[n].w));
-                    patch_accum(csB[n], wsB[n], cost, wsrc * tol_weight(L.tab(), linf_row(c2[n], p2)));
+                    const float cost = tol_cost(L.tab(), p1, p2, k1, __float_as_uint(qb[n].w));
+                    patch_accum(csB[n], wsB[n], cost, __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2[n], p2), lsrc)));
                 }
 #else
                 {
@@ -496,11 +502,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EPPM_C2F_WI
 void k_c2f_refine_win(PlanesH Ph, float* __restrict__ flow_, const float* __restrict__ lut, size_t pstride)
 {
     constexpr int TWU = kBlock + 2 * R;
-#ifdef EPPM_TOL
-    constexpr int TW = (TWU + 7) / 8 * 8;         // row stride = 128 B mod 256 B: the two 8-lane halves of a ds_read_b128 group still fall on disjoint banks
-#else
     constexpr int TW = (TWU + 15) / 16 * 16;
-#endif
     constexpr int WW = 64, WH = EPPM_C2F_WIN_H;                      // window: row stride 64 texels = 1 KiB (conflict-free ds_read_b128)
     constexpr int XLO = C2fWinGeom<R>::xlo(), XHI = C2fWinGeom<R>::xhi(), YLO = C2fWinGeom<R>::ylo(), YHI = C2fWinGeom<R>::yhi();
     // admissible spread of the candidate centres (max - min): a read lands at window column (cx + dx) - wx0 with cx in [mnx-1, mxx+1],
@@ -508,7 +510,7 @@ void k_c2f_refine_win(PlanesH Ph, float* __restrict__ flow_, const float* __rest
     constexpr int SPAN_X = WW - 3 - (XHI - XLO), SPAN_Y = WH - 3 - (YHI - YLO);
     static_assert(SPAN_X >= kBlock - 1 && SPAN_Y >= kBlock - 1, "window too small for a constant-flow tile (spread kBlock - 1)");
     static_assert(TWU * TW * 16 >= 9 * 256 * 4, "the exchange buffer aliases the source tile");
-    __shared__ PatchLutT<R + 1> L;
+    __shared__ EPPM_LUT_ALIGN PatchLutT<R + 1> L;
     __shared__ float4 s_src[TWU * TW];
     __shared__ float4 s_win[WH * WW];
     __shared__ int s_mm[4];                                          // min ccx, max ccx, min ccy, max ccy of the tile's pixels
@@ -516,7 +518,7 @@ void k_c2f_refine_win(PlanesH Ph, float* __restrict__ flow_, const float* __rest
     const int ptid = threadIdx.y * kBlock + threadIdx.x;            // pixel of the tile
     const int grp = threadIdx.z;                                     // pass group
     const int tid = grp * 256 + ptid;
-    load_patch_lut(L, lut, R, tid, 512);
+    load_patch_lut<EPPM_C2F_LOG2>(L, lut, R, tid, 512);
     const Planes P = to_dev(Ph, pstride, blockIdx.y);
     const uint32_t* __restrict__ pc1 = pair_ptr_opt(Ph.pc1, pstride, blockIdx.y);
     const uint32_t* __restrict__ pc2 = pair_ptr_opt(Ph.pc2, pstride, blockIdx.y);
@@ -654,7 +656,7 @@ void k_c2f_refine_win4(PlanesH Ph, float* __restrict__ flow_, const float* __res
     static_assert(SPAN_X >= kBlock - 1 && SPAN_Y >= kBlock - 1, "window too small for a constant-flow tile (spread kBlock - 1)");
     static_assert(TWU * TW * 16 >= 27 * 256 * 4, "the exchange buffer aliases the source tile");
     static_assert(sizeof(PatchLutT<R + 1>) + (TWU * TW + WH * WW) * 16 + 16 <= 160 * 1024, "LDS budget of one CU");
-    __shared__ PatchLutT<R + 1> L;
+    __shared__ EPPM_LUT_ALIGN PatchLutT<R + 1> L;
     __shared__ float4 s_src[TWU * TW];
     __shared__ float4 s_win[WH * WW];
     __shared__ int s_mm[4];
@@ -662,7 +664,7 @@ void k_c2f_refine_win4(PlanesH Ph, float* __restrict__ flow_, const float* __res
     const int ptid = threadIdx.y * kBlock + threadIdx.x;
     const int grp = threadIdx.z;                                     // pass group: evaluates pass 3 - grp (0-based: 3 = the 4th pass)
     const int tid = grp * 256 + ptid;
-    load_patch_lut(L, lut, R, tid, 1024);
+    load_patch_lut<EPPM_C2F_LOG2>(L, lut, R, tid, 1024);
     const Planes P = to_dev(Ph, pstride, blockIdx.y);
     const uint32_t* __restrict__ pc1 = pair_ptr_opt(Ph.pc1, pstride, blockIdx.y);
     const uint32_t* __restrict__ pc2 = pair_ptr_opt(Ph.pc2, pstride, blockIdx.y);

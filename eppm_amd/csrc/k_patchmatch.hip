@@ -41,6 +41,8 @@ __device__ __forceinline__ PmProblem pm_problem(const PmBatch& B, unsigned q)
     p.P.pk2 = pair_ptr_opt(p.P.pk2, B.stride, pair);
     p.P.pc1 = pair_ptr_opt(p.P.pc1, B.stride, pair);
     p.P.pc2 = pair_ptr_opt(p.P.pc2, B.stride, pair);
+    p.P.pp1 = pair_ptr_opt(p.P.pp1, B.stride, pair);
+    p.P.pp2 = pair_ptr_opt(p.P.pp2, B.stride, pair);
     p.cost = pair_ptr_opt(p.cost, B.stride, pair);
     p.nnf = pair_ptr_opt(p.nnf, B.stride, pair);
     p.nnf_alt = pair_ptr_opt(p.nnf_alt, B.stride, pair);
@@ -112,7 +114,7 @@ void launch_pm_init_field(const PmBatch& b, const PmRngDev& rng, hipStream_t s)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pm_cost_field(PmBatch B, const float* __restrict__ lut, int R)
 {
-    __shared__ PatchLut L;
+    __shared__ EPPM_LUT_ALIGN PatchLut L;
     load_patch_lut(L, lut, R, threadIdx.y * kBlock + threadIdx.x, 256);
     __syncthreads();
     const PmProblem pr = pm_problem(B, blockIdx.z);
@@ -133,13 +135,16 @@ template <> struct SearchLut<0> { using type = PatchLut; };          // any radi
 __device__ __forceinline__ float patch_dist_any(const Planes& P, const PatchLut& L, int R, int x1, int y1, int x2, int y2) { return patch_dist(P, L, R, x1, y1, x2, y2); }
 template <int M> __device__ __forceinline__ float patch_dist_any(const Planes&, const PatchLutT<M>&, int, int, int, int, int) { return 0.0f; }   // never called (RT != 0)
 
-// PK: the target texels are gathered from the 4-byte plane pc2 = {R, G, B, census} and converted at use (make_texel, the function
+// PK = 1: the target texels are gathered from the 4-byte plane pc2 = {R, G, B, census} and converted at use (make_texel, the function
 // that built the float4 plane: the same bits).  A 64-lane gather of 4 bytes costs the L1 38 clocks where one of 16 bytes costs 52-78
 // (tools/ubench/gather_rate.hip), the conversion 12 VALU instructions per texel: for launches whose search runs at the L1's lane
 // rate with VALU slots to spare -- radius 17, or one small pair per launch -- not for the batched radius-9 launches (VALU bound).
-template <int RT, bool PK = false, class LUT>
+// PK = 2 (tolerance library): the S samples of a patch row are S consecutive words of the target's column-parity plane (PlanesH::pp2):
+// 3 gathers per row of 10 samples (16 + 16 + 8 bytes) instead of 10, unpacked by unpack_texel.  With the patch term at a third of its
+// exact instruction count these kernels run at the L1's lane rate; this divides their gathers by 3.3.
+template <int RT, int PK = 0, class LUT>
 __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L, int R, const float4* __restrict__ s_src, int TW,
-                                                   int tx, int ty, int x1, int y1, int x2, int y2, const uint32_t* __restrict__ pc2 = nullptr)
+                                                   int tx, int ty, int x1, int y1, int x2, int y2, const PlanesH& PH)
 {
     if (RT == 0) return patch_dist_any(P, L, R, x1, y1, x2, y2);
     constexpr int S = RT + 1;
@@ -147,26 +152,58 @@ __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L
     const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
     const rgbf c2 = texel_rgb(texel_at(P.pk2, texel_off(pitch16, P.w, P.h, x2, y2)));
     float cost_sum = 0.0f, weight_sum = 0.0f;
+#ifdef EPPM_TOL
+    if constexpr (PK == 2) {
+        static_assert(S % 4 == 2, "a row = whole dwordx4 gathers + one dwordx2");
+        // buffer loads: a dwordx4 at a 4-byte aligned per-lane offset in ONE instruction (a global load of that alignment is split by the
+        // compiler), 32-bit offsets; the descriptor is built from workgroup-uniform values (the problem's plane, its size)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(PH.pp2), 0, 2 * P.h * PH.pp_pitch * 4, 0x00020000);
+        const int xp = x2 - RT + PH.pp_pad;                       // padded column of the row's first sample, >= 1
+        const int rb = ((xp & 1) * P.h) * PH.pp_pitch + (xp >> 1);
+        uint32_t two = 2u;
+        asm volatile("" : "+v"(two));
+#pragma unroll 2
+        for (int ii = 0; ii < S; ii++) {
+            const int ro = (rb + iclamp(y2 + 2 * ii - RT, 0, P.h - 1) * PH.pp_pitch) * 4;      // byte offset of the row's first sample
+            const float4* __restrict__ srow = s_src + (ty + 2 * ii) * TW + tx;
+            uint32_t wq[S];
+#pragma unroll
+            for (int g = 0; g < S / 4; g++) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ro + 16 * g, 0, 0);
+                wq[4 * g] = v.x; wq[4 * g + 1] = v.y; wq[4 * g + 2] = v.z; wq[4 * g + 3] = v.w;
+            }
+            { const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, ro + 4 * (S - 2), 0, 0); wq[S - 2] = v.x; wq[S - 1] = v.y; }
+#pragma unroll
+            for (int jj = 0; jj < S; jj++) {
+                float ct, wt;
+                patch_terms(srow[2 * jj], unpack_texel(wq[jj], two), c1, c2, L.gsp[ii * S + jj], L.tab(), ct, wt);
+                patch_accum(cost_sum, weight_sum, ct, wt);
+            }
+        }
+        return cost_sum / weight_sum;
+    }
+#endif
+    const uint32_t* __restrict__ pc2 = PH.pc2;
     for (int ii = 0; ii < S; ii++) {
         const int i = 2 * ii - RT;
         const unsigned r2 = __umul24((unsigned)iclamp(y2 + i, 0, P.h - 1), (unsigned)pitch16);
         const float4* __restrict__ srow = s_src + (ty + 2 * ii) * TW + tx;
         for (int j0 = 0; j0 < S; j0 += 5) {
             float4 q1[5], q2[5];
-            uint32_t w2[PK ? 5 : 1];
+            uint32_t w2[PK == 1 ? 5 : 1];
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 const int jj = min(j0 + k, S - 1);
                 q1[k] = srow[2 * jj];
                 const unsigned o2 = r2 + ((unsigned)iclamp(x2 + 2 * jj - RT, 0, P.w - 1) << 4);
-                if (PK) w2[k] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(pc2) + (o2 >> 2));
+                if (PK == 1) w2[k] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(pc2) + (o2 >> 2));
                 else q2[k] = texel_at(P.pk2, o2);
             }
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 if (j0 + k < S) {
                     float ct, wt;
-                    if (PK) q2[k] = make_texel(w2[k], w2[k] >> 24);
+                    if (PK == 1) q2[k] = make_texel(w2[k], w2[k] >> 24);
                     patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.tab(), ct, wt);
                     patch_accum(cost_sum, weight_sum, ct, wt);
                 }
@@ -177,13 +214,13 @@ __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L
 }
 
 // the cost field with the source samples of the 16x16 block from an LDS tile, as in the search and in phase A of the sweeps (radius 9 / 17)
-template <int RT>
+template <int RT, int PK = 0>
 __global__ __launch_bounds__(256) void k_pm_cost_field_tile(PmBatch B, const float* __restrict__ lut, int R)
 {
     using LUT = typename SearchLut<RT>::type;
     constexpr int TW = kBlock + 2 * RT;
     __shared__ float4 s_src[TW * TW];
-    __shared__ LUT L;
+    __shared__ EPPM_LUT_ALIGN LUT L;
     const int tid = threadIdx.y * kBlock + threadIdx.x;
     load_patch_lut(L, lut, R, tid, 256);
     const PmProblem pr = pm_problem(B, blockIdx.z);
@@ -197,7 +234,17 @@ __global__ __launch_bounds__(256) void k_pm_cost_field_tile(PmBatch B, const flo
     const int x = blockIdx.x * kBlock + threadIdx.x, y = blockIdx.y * kBlock + threadIdx.y;
     if (x >= P.w || y >= P.h) return;
     const int dx = pr.nnf[(y * B.npitch + x) * 2], dy = pr.nnf[(y * B.npitch + x) * 2 + 1];
-    pr.cost[y * B.cpitch + x] = search_patch_dist<RT>(P, L, R, s_src, TW, threadIdx.x, threadIdx.y, x, y, dx, dy);
+    pr.cost[y * B.cpitch + x] = search_patch_dist<RT, PK>(P, L, R, s_src, TW, threadIdx.x, threadIdx.y, x, y, dx, dy, pr.P);
+}
+
+// tolerance library: every problem of the launch has its target's column-parity plane (PlanesH::pp2)
+static bool pm_has_parity(const PmBatch& b)
+{
+#ifdef EPPM_TOL
+    return b.p[0].P.pp2 && (b.n < 2 || b.p[1].P.pp2);
+#else
+    return false;
+#endif
 }
 
 void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t s)
@@ -207,7 +254,9 @@ void launch_pm_cost_field(const PmBatch& b, const float* lut, int R, hipStream_t
 #ifndef EPPM_COST_FIELD_TILE
 #define EPPM_COST_FIELD_TILE 1
 #endif
-    if (EPPM_COST_FIELD_TILE && R == 9) hipLaunchKernelGGL(k_pm_cost_field_tile<9>, grid, block, 0, s, b, lut, R);
+    if (EPPM_COST_FIELD_TILE && R == 9 && pm_has_parity(b)) hipLaunchKernelGGL((k_pm_cost_field_tile<9, 2>), grid, block, 0, s, b, lut, R);
+    else if (EPPM_COST_FIELD_TILE && R == 17 && pm_has_parity(b)) hipLaunchKernelGGL((k_pm_cost_field_tile<17, 2>), grid, block, 0, s, b, lut, R);
+    else if (EPPM_COST_FIELD_TILE && R == 9) hipLaunchKernelGGL(k_pm_cost_field_tile<9>, grid, block, 0, s, b, lut, R);
     else if (EPPM_COST_FIELD_TILE && R == 17) hipLaunchKernelGGL(k_pm_cost_field_tile<17>, grid, block, 0, s, b, lut, R);
     else hipLaunchKernelGGL(k_pm_cost_field, grid, block, 0, s, b, lut, R);
 }
@@ -357,7 +406,7 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
     constexpr int SEGS = SweepTile<LPC>::SEGS, LINES = SweepTile<LPC>::LINES, TROWS = S + LINES - 1;
     static_assert(!(SPEC && TILE), "phase B evaluates rarely: it gathers its source samples");
     extern __shared__ float4 s_tile[];          // TILE: TROWS sample rows + LINES centre rows of TW texels
-    __shared__ PatchLut L;
+    __shared__ EPPM_LUT_ALIGN PatchLut L;
     __shared__ int s_own[PRE ? CPB * kSpecMaxSteps : 1];       // PRE: per chain and step, the pixel's stored match (x | y << 16),
     __shared__ float s_cst[PRE ? CPB * kSpecMaxSteps : 1];     //      its stored cost,
     __shared__ float s_spc[PRE ? CPB * kSpecMaxSteps : 1];     //      phase A's cost of the rejection-path candidate (classic form: the cached cost)
@@ -630,14 +679,14 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
 // and appends the UNIT of a pixel that would accept -- segments 2u and 2u + 1 of its line, so that segments 0 and 1, the two
 // visitors of pixel L, are always listed together -- to the list, once (a stamp per unit holds the number of the last sweep that
 // listed it).  Phase B walks the listed chains only: from the fifth iteration on that is one chain in ten.
-template <int RT, bool IS_ROW, bool REVERSE>
+template <int RT, bool IS_ROW, bool REVERSE, int PK = 0>
 __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* __restrict__ lut, int R, int gx, int L_, int nseg)
 {
     using LUT = typename SearchLut<RT>::type;
     constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT;
     constexpr int DIR = IS_ROW ? (REVERSE ? 2 : 0) : (REVERSE ? 3 : 1);
     __shared__ float4 s_src[TW * TW];
-    __shared__ LUT L;
+    __shared__ EPPM_LUT_ALIGN LUT L;
     __shared__ uint32_t s_list[256];       // compacted work: pixel index inside the block
     __shared__ int s_cand[256];            // its candidate, x | y << 16
     __shared__ int s_wcount[4];
@@ -728,7 +777,7 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
     const int tx = pix & 15, ty = pix >> 4;
     const int px = bxx * kBlock + tx, py = byy * kBlock + ty;
     // (radius 17: gathering the 4-byte target plane here as the search does changes nothing: 57.5 vs 57.6 ms PatchMatch at 3840x2160)
-    const float cv = search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16);
+    const float cv = search_patch_dist<RT, PK>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16, pr.P);
     cval[py * B.cpitch + px] = cv;
     if (ccand) ccand[py * B.cpitch + px] = e;
     if (wl && cv < pr.cost[py * B.cpitch + px]) list_unit(px, py);
@@ -746,13 +795,13 @@ __global__ __launch_bounds__(256) void k_pm_sweep_spec(PmBatch B, const float* _
 //  * the cache answers by candidate, so an entry written here for a candidate the field no longer proposes is simply not used;
 //  * seeds: PmProblem::seed[d] = F0 here, kept current by the earlier sweeps' accepted candidates, never by sweep d itself.
 // ---------------------------------------------------------------------------------------------------
-template <int RT>
+template <int RT, int PK = 0>
 __global__ __launch_bounds__(256) void k_pm_spec_all(PmBatch B, const float* __restrict__ lut, int R, int gx)
 {
     using LUT = typename SearchLut<RT>::type;
     constexpr int TW = kBlock + 2 * RT;
     __shared__ float4 s_src[TW * TW];
-    __shared__ LUT L;
+    __shared__ EPPM_LUT_ALIGN LUT L;
     __shared__ uint16_t s_list[1024];      // compacted work: pixel index inside the block | direction << 8
     __shared__ int s_cand[1024];           // its candidate, x | y << 16
     __shared__ int s_wcount[16];           // [direction][wave]
@@ -862,7 +911,7 @@ __global__ __launch_bounds__(256) void k_pm_spec_all(PmBatch B, const float* __r
         const int pix = (int)s_list[slot] & 255, d = (int)s_list[slot] >> 8, e = s_cand[slot];
         const int tx = pix & 15, ty = pix >> 4;
         const int px = bxx * kBlock + tx, py = byy * kBlock + ty, ci = py * B.cpitch + px;
-        const float cv = search_patch_dist<RT>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16);
+        const float cv = search_patch_dist<RT, PK>(P, L, R, s_src, TW, tx, ty, px, py, (int)(int16_t)(e & 0xffff), e >> 16, pr.P);
         pr.spec[d * B.cache_plane + ci] = cv;
         pr.scand[d * B.cache_plane + ci] = e;
         if (cv < pr.cost[ci]) merged_list_unit(wl, B, d, px, py);
@@ -875,7 +924,7 @@ template <bool IS_ROW, bool REVERSE>
 __global__ __launch_bounds__(1024) void k_pm_seg_propagate(PmBatch B, const float* __restrict__ lut, int R, int L_, int nseg,
                                                            int lines_per_block)
 {
-    __shared__ PatchLut L;
+    __shared__ EPPM_LUT_ALIGN PatchLut L;
     load_patch_lut(L, lut, R, threadIdx.x, blockDim.x);
     const PmProblem pr = pm_problem(B, blockIdx.y);
     const Planes P = to_dev(pr.P);
@@ -935,6 +984,15 @@ static void launch_sweep_spec(const PmBatch& b, const float* lut, int R, int dir
 {
     const int w = b.p[0].P.w, h = b.p[0].P.h, gx = (w + kBlock - 1) / kBlock, gy = (h + kBlock - 1) / kBlock;
     dim3 grid(gx * gy * (b.n * b.npairs)), block(256);
+    if (pm_has_parity(b)) {
+        switch (dir) {
+            case 0: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, false, 2>), grid, block, 0, s, b, lut, R, gx, seg_len, nseg); break;
+            case 1: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, false, 2>), grid, block, 0, s, b, lut, R, gx, seg_len, nseg); break;
+            case 2: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, true, 2>), grid, block, 0, s, b, lut, R, gx, seg_len, nseg); break;
+            default: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, true, 2>), grid, block, 0, s, b, lut, R, gx, seg_len, nseg); break;
+        }
+        return;
+    }
     switch (dir) {
         case 0: hipLaunchKernelGGL((k_pm_sweep_spec<RT, true, false>), grid, block, 0, s, b, lut, R, gx, seg_len, nseg); break;
         case 1: hipLaunchKernelGGL((k_pm_sweep_spec<RT, false, false>), grid, block, 0, s, b, lut, R, gx, seg_len, nseg); break;
@@ -1072,7 +1130,9 @@ bool launch_pm_sweeps_merged(PmBatch& b, const float* lut, int R, int seg_len, i
     b.nseg_row = (w + seg_len - 1) / seg_len;
     b.nseg_col = (h + seg_len - 1) / seg_len;
     dim3 grid(gx * gy * (b.n * b.npairs)), block(256);
-    if (R == 9) hipLaunchKernelGGL(k_pm_spec_all<9>, grid, block, 0, s, b, lut, R, gx);
+    if (R == 9 && pm_has_parity(b)) hipLaunchKernelGGL((k_pm_spec_all<9, 2>), grid, block, 0, s, b, lut, R, gx);
+    else if (pm_has_parity(b)) hipLaunchKernelGGL((k_pm_spec_all<17, 2>), grid, block, 0, s, b, lut, R, gx);
+    else if (R == 9) hipLaunchKernelGGL(k_pm_spec_all<9>, grid, block, 0, s, b, lut, R, gx);
     else hipLaunchKernelGGL(k_pm_spec_all<17>, grid, block, 0, s, b, lut, R, gx);
     for (int dir = 0; dir < 4; dir++) {
         if (R == 9) launch_sweep_merged<9, EPPM_LPC9_SPEC>(b, lut, seg_len, dir, s);
@@ -1097,7 +1157,7 @@ bool launch_pm_sweeps_merged(PmBatch& b, const float* lut, int R, int seg_len, i
 template <bool NEIGHBOR>
 __global__ __launch_bounds__(256) void k_pm_jump(PmBatch B, const float* __restrict__ lut, int R, int step)
 {
-    __shared__ PatchLut L;
+    __shared__ EPPM_LUT_ALIGN PatchLut L;
     __shared__ float s_cost[4][64];
     __shared__ int s_cand[4][64];
     const PmProblem pr = pm_problem(B, blockIdx.z);
@@ -1222,7 +1282,7 @@ void launch_pm_rand_table(const PmRngDev& rng, uint32_t* work, int16_t* tab, int
 // ROWS = 2 (numbers drawn ahead only): a workgroup covers an EIGHTH of the block (2 rows, 32 pixels; a wave = two guesses of them) -- for
 // launches of so few workgroups that their count per CU quantises badly (one 1024x436 pair: 872 quarter-workgroups on 256 CUs run as 4
 // per CU where 3.4 are needed; the kernel runs at its CU's L1 rate, so the launch lasts as long as the fullest CU).
-template <int RT, bool PK = false, bool TAB = false, int ROWS = 4>
+template <int RT, int PK = 0, bool TAB = false, int ROWS = 4>
 __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
                                                           int search_range, int G)
 {
@@ -1231,7 +1291,7 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     constexpr int PIXW = 16 * ROWS, NSUB = kBlock / ROWS;        // pixels per workgroup, workgroups per 16x16 block
     constexpr int TW = (RT == 0) ? 1 : kBlock + 2 * RT, TH = (RT == 0) ? 1 : ROWS + 2 * RT;
     __shared__ float4 s_src[TW * TH];
-    __shared__ LUT L;
+    __shared__ EPPM_LUT_ALIGN LUT L;
     __shared__ int16_t s_rand[TAB ? 2 : 8 * 512];
     __shared__ float s_cost[8][64];
     __shared__ int s_guess[8][64];
@@ -1308,7 +1368,7 @@ __global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rn
     if (inimg) {
         float cv = INFINITY;
         if (evaluate) {
-            cv = search_patch_dist<RT, PK>(P, L, R, s_src, TW, lane & 15, lane >> 4, x, y, gx, gy, pr.P.pc2);
+            cv = search_patch_dist<RT, PK>(P, L, R, s_src, TW, lane & 15, lane >> 4, x, y, gx, gy, pr.P);
         }
         s_cost[k][lane] = cv;
     }
@@ -1338,13 +1398,20 @@ void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float*
 #ifndef EPPM_SEARCH_HALF_BELOW_WGS
 #define EPPM_SEARCH_HALF_BELOW_WGS 1024       // under four quarter-workgroups per CU: eighth-block workgroups (PatchMatch of one 1024x436 pair 1.362 -> 1.330 ms;
 #endif                                        // at 4080 workgroups, one 1920x1080 pair, they lose: 4.49 -> 4.57 ms)
-        if (R == 9 && (int)grid.x < EPPM_SEARCH_HALF_BELOW_WGS) {
-            hipLaunchKernelGGL((k_pm_random_search<9, false, true, 2>), dim3(grid.x * 2), dim3(32 * num_guess), 0, s, b, rng, lut, R, search_range, num_guess);
+        if (pm_has_parity(b)) {                                                        // tolerance library: column-parity target planes
+            if (R == 9 && (int)grid.x < EPPM_SEARCH_HALF_BELOW_WGS)
+                hipLaunchKernelGGL((k_pm_random_search<9, 2, true, 2>), dim3(grid.x * 2), dim3(32 * num_guess), 0, s, b, rng, lut, R, search_range, num_guess);
+            else if (R == 9) hipLaunchKernelGGL((k_pm_random_search<9, 2, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
+            else hipLaunchKernelGGL((k_pm_random_search<17, 2, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
             return;
         }
-        if (R == 9) hipLaunchKernelGGL((k_pm_random_search<9, false, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
-        else if (have_pc_t) hipLaunchKernelGGL((k_pm_random_search<17, true, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
-        else hipLaunchKernelGGL((k_pm_random_search<17, false, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
+        if (R == 9 && (int)grid.x < EPPM_SEARCH_HALF_BELOW_WGS) {
+            hipLaunchKernelGGL((k_pm_random_search<9, 0, true, 2>), dim3(grid.x * 2), dim3(32 * num_guess), 0, s, b, rng, lut, R, search_range, num_guess);
+            return;
+        }
+        if (R == 9) hipLaunchKernelGGL((k_pm_random_search<9, 0, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
+        else if (have_pc_t) hipLaunchKernelGGL((k_pm_random_search<17, 1, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
+        else hipLaunchKernelGGL((k_pm_random_search<17, 0, true>), grid, blockt, 0, s, b, rng, lut, R, search_range, num_guess);
         return;
     }
     // (radius 9 gathers the float4 plane: the 4-byte plane's conversions cost it more than the narrower gathers save, at every size)
@@ -1352,7 +1419,7 @@ void launch_pm_random_search(const PmBatch& b, const PmRngDev& rng, const float*
 #define EPPM_SEARCH_PK17 1
 #endif
     const bool have_pc = b.p[0].P.pc2 && (b.n < 2 || b.p[1].P.pc2);
-    if (R == 17 && have_pc && EPPM_SEARCH_PK17) hipLaunchKernelGGL((k_pm_random_search<17, true>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
+    if (R == 17 && have_pc && EPPM_SEARCH_PK17) hipLaunchKernelGGL((k_pm_random_search<17, 1>), grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else if (R == 9) hipLaunchKernelGGL(k_pm_random_search<9>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else if (R == 17) hipLaunchKernelGGL(k_pm_random_search<17>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);
     else hipLaunchKernelGGL(k_pm_random_search<0>, grid, block, 0, s, b, rng, lut, R, search_range, num_guess);

@@ -283,6 +283,23 @@ void launch_pack(void* texels, int tpitch, const uint32_t* img, int ipitch, cons
     hipLaunchKernelGGL(k_pack, grid, block, 0, s, (float4*)texels, tpitch, img, ipitch, census, cpitch, w, h);
 }
 
+// column-parity planes of a 4-byte texel plane (eppm_internal.h: PlanesH::pp1): word [p][y][i] = pc[y][clamp(2i + p - pad, 0, w - 1)]
+__global__ __launch_bounds__(256) void k_parity_planes(uint32_t* __restrict__ pp_, int pp_pitch, int pad, const uint32_t* __restrict__ pc_,
+                                                       int pc_pitch, int w, int h, size_t pstride)
+{
+    uint32_t* __restrict__ pp = pair_ptr(pp_, pstride, blockIdx.z);
+    const uint32_t* __restrict__ pc = pair_ptr(pc_, pstride, blockIdx.z);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y >> 1, par = blockIdx.y & 1;
+    if (i >= pp_pitch) return;
+    const int x = iclamp(2 * i + par - pad, 0, w - 1);
+    pp[((size_t)par * h + y) * pp_pitch + i] = pc[y * pc_pitch + x];
+}
+void launch_parity_planes(uint32_t* pp, int pp_pitch, int pad, const uint32_t* pc, int pc_pitch, int w, int h, hipStream_t s, Batch bt)
+{
+    dim3 block(256), grid((pp_pitch + 255) / 256, 2 * h, bt.n);
+    hipLaunchKernelGGL(k_parity_planes, grid, block, 0, s, pp, pp_pitch, pad, pc, pc_pitch, w, h, bt.stride);
+}
+
 // RGB (3 B/px, tightly packed rows) -> RGBA with alpha 0 (bao_rgb2rgba, basic/bao_basic_cuda.h:258-267)
 __global__ __launch_bounds__(256) void k_rgb_to_rgba(uint32_t* __restrict__ out_, int pitch, const uint8_t* __restrict__ rgb_, int h, int w, size_t pstride)
 {

@@ -101,6 +101,8 @@ static struct { int sweep_order, post_inplace, exp_mode, seed_variant; } g_var =
  *         bit 2: cost_sum advances by fmaf(cost, weight, cost_sum)
  *         bit 4: the S*S terms are summed as S row sums (each in j order) added in i order, instead of one chain
  *         bit 8: hardware-exp class: expf() wherever the table form does not apply (smoothing, weighted median)
+ *         bit 16: (refine scope only) the weight as ONE hardware exp2 of a summed argument, exp2(log2(gs_j gs_i) - c (ka^2 + kb^2)),
+ *                 c = log2(e) / (255^2 s) in float: the form the tolerance library's refine kernel uses (LDS bound otherwise)
  *   scope bit 1: PatchMatch (cost field, sweeps, search)   bit 2: candidate refine   bit 4: smoothing / weighted median weights */
 static struct { int mode, scope; } g_tol = {0, 0};
 static float g_tol_td[256], g_tol_ta[256], g_tol_tw[256];
@@ -480,6 +482,8 @@ static inline orc_uchar4 tex_u8x4(const orc_uchar4* img, int w, int h, int x, in
     x = iclamp(x, 0, w - 1); y = iclamp(y, 0, h - 1);
     return img[(size_t)y * w + x];
 }
+static int g_tol_exp2_now = 0;
+#pragma omp threadprivate(g_tol_exp2_now)
 static inline void patch_sample_tol(const orc_uchar4* img1, const orc_uchar4* img2, const uint8_t* c1, const uint8_t* c2,
                                     int w, int h, orc_uchar4 center1, orc_uchar4 center2, int sx1, int sy1, int sx2, int sy2,
                                     float gs_j, float gs_i, const float* cn, float* cost_sum, float* weight_sum)
@@ -487,8 +491,16 @@ static inline void patch_sample_tol(const orc_uchar4* img1, const orc_uchar4* im
     const orc_uchar4 p1 = tex_u8x4(img1, w, h, sx1, sy1), p2 = tex_u8x4(img2, w, h, sx2, sy2);
     const int hamming = popcount8(tex_u8(c1, w, h, sx1, sy1) ^ tex_u8(c2, w, h, sx2, sy2));
     const float cost = g_tol_td[max_abs_diff_u8(p1, p2)] + cn[hamming];
-    const float wa = g_tol_ta[max_abs_diff_u8(center1, p1)] * (gs_j * gs_i);      /* the source half, hoisted on the GPU */
-    const float weight = wa * g_tol_ta[max_abs_diff_u8(center2, p2)];
+    float weight;
+    if (g_tol_exp2_now) {
+        const float c = (float)(1.4426950408889634 / (255.0 * 255.0 * (double)(LAMBDA_AD * LAMBDA_AD)));
+        const float ka = (float)max_abs_diff_u8(center1, p1), kb = (float)max_abs_diff_u8(center2, p2);
+        const float lsrc = fmaf(-c, ka * ka, log2f(gs_j * gs_i));                 /* once per source sample on the GPU */
+        weight = exp2f(fmaf(-c, kb * kb, lsrc));
+    } else {
+        const float wa = g_tol_ta[max_abs_diff_u8(center1, p1)] * (gs_j * gs_i);      /* the source half, hoisted on the GPU */
+        weight = wa * g_tol_ta[max_abs_diff_u8(center2, p2)];
+    }
     if (g_tol.mode & 2) *cost_sum = fmaf(cost, weight, *cost_sum); else *cost_sum += cost * weight;
     *weight_sum += weight;
 }
@@ -531,6 +543,7 @@ float orc_patch_dist_planefit(const orc_uchar4* img1, const orc_uchar4* img2, co
     const float uu = (float)(x2 - x1);
     const float vv = (float)(y2 - y1);
     const int tol = (g_tol.mode & 1) && (g_tol.scope & 2);
+    g_tol_exp2_now = tol && (g_tol.mode & 16);
     const orc_uchar4 k1 = tex_u8x4(img1, w, h, x1, y1), k2 = tex_u8x4(img2, w, h, x2, y2);
     float rows_c[64] = {0}, rows_w[64] = {0};
     float c4[4];
@@ -562,6 +575,7 @@ float orc_patch_dist_planefit(const orc_uchar4* img1, const orc_uchar4* img2, co
     }
     /* __min(cost1,__min(cost2,__min(cost3,cost4))) :512 with __min(a,b) = (a<b)?a:b
      * (basic/bao_basic_cuda.h:45); the nesting is kept because it decides what a NaN does */
+    g_tol_exp2_now = 0;
     float m34 = (c4[2] < c4[3]) ? c4[2] : c4[3];
     float m234 = (c4[1] < m34) ? c4[1] : m34;
     return (c4[0] < m234) ? c4[0] : m234;

@@ -263,7 +263,17 @@ __device__ __forceinline__ void patch_terms(const float4 q1, const float4 q2, co
     const rgbf p1 = texel_rgb(q1);
     const rgbf p2 = texel_rgb(q2);
     cost_term = tol_cost(T, p1, p2, __float_as_uint(q1.w), __float_as_uint(q2.w));
+#ifndef EPPM_TOL_PM_WEIGHT
+#define EPPM_TOL_PM_WEIGHT 0
+#endif
+#if EPPM_TOL_PM_WEIGHT == 0            // two table reads (LDS: ~5 cycles each with their bank conflicts)
     weight_term = (tol_at(T.ta, linf_off(c1, p1)) * gsp) * tol_at(T.ta, linf_off(c2, p2));
+#elif EPPM_TOL_PM_WEIGHT == 1          // source half from the table, target half by the hardware exp2
+    weight_term = (tol_at(T.ta, linf_off(c1, p1)) * gsp) * __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2, p2), 0.0f));
+#else                                  // one hardware exp2 of the summed argument (gsp must then hold log2 of the product: refine kernels only)
+    const float ka = (float)linf_off(c1, p1);
+    weight_term = gsp * __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2, p2), -kTolExpC * (ka * ka)));
+#endif
 }
 __device__ __forceinline__ void patch_accum(float& cost_sum, float& weight_sum, float cost_term, float weight_term)
 {

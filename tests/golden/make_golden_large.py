@@ -8,6 +8,8 @@ For every case the CPU oracle computes the full flow of the synthetic pair (eppm
 and MANIFEST_large.json keeps: sha256 of the two input images (so a test can tell "inputs differ on this host" from "flow
 differs"), sha256 of u || v (float32 LE, row-major), the per-16-row-band sha256 list (localises a mismatch), the mean of u
 and v, and large_crops.npz a 64x64 crop of u and v around the image centre.
+Natural pairs (round 6): `bundled_640x480` = the reference's frame10/frame11 (BASELINE configs[0], the default three levels) and
+`natural_1024x436` = the same frames scaled x1.6 and centre-cropped to the Sintel shape (eppm_amd/synth.py: natural_pair).
 Cases: BASELINE configs[1] = `sintel_1234`; configs[2] = `sintel_1234 .. sintel_1241` (the 8 pairs one GPU of the 8-GPU
 batch processes); configs[3] = `hd_1234`; configs[4] = `uhd_r17_1234` (3840x2160, patch radius 17).
 """
@@ -27,6 +29,8 @@ from eppm_amd import synth  # noqa: E402
 CASES = [dict(name=f"sintel_{s}", h=436, w=1024, seed=s, max_flow=20.0, patch_r=9) for s in range(1234, 1242)]
 CASES += [dict(name="hd_1234", h=1080, w=1920, seed=1234, max_flow=40.0, patch_r=9),
           dict(name="uhd_r17_1234", h=2160, w=3840, seed=1234, max_flow=60.0, patch_r=17)]
+NATURAL = [dict(name="bundled_640x480", h=480, w=640, patch_r=9, source="tests/golden/frame10.ppm, frame11.ppm"),
+           dict(name="natural_1024x436", h=436, w=1024, patch_r=9, source="synth.natural_pair(): the bundled frames x1.6 (bilinear, float64), rows 166..601")]
 BAND = 16
 
 
@@ -49,14 +53,18 @@ def main():
     mpath, cpath = os.path.join(HERE, "MANIFEST_large.json"), os.path.join(HERE, "large_crops.npz")
     man = json.load(open(mpath)) if os.path.exists(mpath) else {}
     crops = dict(np.load(cpath)) if os.path.exists(cpath) else {}
-    for c in CASES:
+    for c in CASES + NATURAL:
         if only and c["name"] not in only:
             continue
-        a, b, _, _ = synth.make_pair(c["h"], c["w"], seed=c["seed"], max_flow=c["max_flow"])
+        if "seed" in c:
+            a, b, _, _ = synth.make_pair(c["h"], c["w"], seed=c["seed"], max_flow=c["max_flow"])
+        else:
+            a, b = synth.bundled_pair() if c["name"].startswith("bundled") else synth.natural_pair(c["h"], c["w"])
+            assert a.shape == (c["h"], c["w"], 3)
         t = time.time()
         u, v = O.compute_flow(a, b, O.default_params(patch_r=c["patch_r"]))
         rec, cu, cv = flow_record(u, v)
-        rec.update({k: c[k] for k in ("h", "w", "seed", "max_flow", "patch_r")})
+        rec.update({k: c[k] for k in ("h", "w", "seed", "max_flow", "patch_r", "source") if k in c})
         rec.update({"img1_sha256": sha(a), "img2_sha256": sha(b), "oracle_seconds": round(time.time() - t, 1), "oracle_threads": O.num_threads()})
         man[c["name"]] = rec
         crops[c["name"] + "_u"], crops[c["name"] + "_v"] = cu, cv

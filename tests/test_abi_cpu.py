@@ -32,13 +32,14 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         getattr(P, s)          # raises AttributeError if not exported
     P.eppm_version.restype = C.c_char_p
-    assert b"approx" not in P.eppm_version()
-    if os.path.exists(eppm_amd.lib_path("approx")):   # the opt-in approx-exp build (`make approx`; not part of the default build) exports the same ABI and names itself
-        A = C.CDLL(eppm_amd.lib_path("approx"))
-        for s in declared:
-            getattr(A, s)
-        A.eppm_version.restype = C.c_char_p
-        assert b"approx-exp" in A.eppm_version()
+    assert b"tolerance" not in P.eppm_version()
+    # the tolerance library (same sources, -DEPPM_TOL; never loaded by default) exports the same ABI and names itself
+    A = C.CDLL(eppm_amd.lib_path("tol"))
+    for s in declared:
+        getattr(A, s)
+    A.eppm_version.restype = C.c_char_p
+    assert b"tolerance arithmetic" in A.eppm_version() and b"not bit-identical" in A.eppm_version()
+    assert not set(_exported(eppm_amd.lib_path("tol"))) & set(_lib.TEST_SYMBOLS)          # no test hooks in it either
 
 
 def test_test_hooks_live_in_the_test_library_only():

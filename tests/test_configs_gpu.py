@@ -752,10 +752,23 @@ def test_bench_default_line_is_self_verifying():
     assert tv["of"] == 20 and tv["ok"] == 20 and tv["all_ok"], tv
     assert 0 < d["ms_per_step"] < d["latency_ms_per_pair"] < 20
     oc = d["other_configs"]
-    for key, ctxs in (("hd", 3), ("uhd_r17", 2)):
+    for key, ctxs in (("bundled", 3), ("natural_1024x436", 3), ("hd", 3), ("uhd_r17", 2)):
         assert "error" not in oc[key], oc[key]
         assert oc[key]["verified"] == dict(oc[key]["verified"], ok=ctxs, of=ctxs, state="verified"), oc[key]
         assert oc[key]["value"] > 0 and oc[key]["ms_per_step"] > 0
+    for key in ("bundled", "natural_1024x436"):         # BASELINE configs[0] and a natural pair of the headline shape: the reference's own window too
+        assert 0 < oc[key]["ms_per_step"] < oc[key]["latency_ms_per_pair"] < oc[key]["cold_ms"] < 50, oc[key]
+        assert oc[key]["cpu_oracle"]["ms_per_pair"] > 100 * oc[key]["latency_ms_per_pair"] and "patchmatch" in oc[key]["stage_ms"]
+    assert oc["bundled"]["levels_1_ms_per_pair"] > 0
+    # the tolerance library beside the exact one, never instead of it: `value` above is the exact library's, every flow verified
+    assert d["library"].startswith("exact")
+    tm = d["tolerance_mode"]
+    assert "error" not in tm and tm["value"] > 1.2 * d["value"] and tm["ms_per_step"] < d["ms_per_step"], (tm.get("error"), tm.get("value"), d["value"])
+    assert 0 < tm["latency_ms_per_pair"] < d["latency_ms_per_pair"] and tm["roofline"]["frac"] > 0
+    ep = tm["epe_vs_oracle_px"]["cases"]
+    assert ep["bundled_640x480"]["mean"] <= 1e-3 and ep["bundled_640x480_backwards"]["mean"] <= 1e-3, ep
+    assert all(c["mean"] <= 3e-2 for c in ep.values()) and {"config2_1024x436", "config4_1920x1080", "config5_3840x2160_r17"} <= set(ep), ep
+    assert all("error" not in tm["other_configs"][k] and tm["other_configs"][k]["value"] > 0 for k in ("bundled", "natural_1024x436", "hd", "uhd_r17")), tm["other_configs"]
     assert d["roofline"]["frac"] > 0 and d["roofline"]["hbm"]["frac"] > 0 if d["roofline"].get("hbm") else d["roofline"]["frac"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
@@ -765,32 +778,81 @@ def test_bench_default_line_is_self_verifying():
     assert sum(wh["round_s"]) < 60, wh              # bounded: the default bench line finishes within minutes
     assert cb["value"] == wh["value"] and cb["single_pair_16_threads"]["value"] > 0
     assert d["config"]["host_binding"]["ranks"][0]["pci"]
-    assert "approx_exp_variant" not in d and d["vs_baseline"] is None
+    assert d["vs_baseline"] is None
     hb = d["host_boundary"]
     assert "error" not in hb and hb["pipelined"] > 0 and hb["sync"] > 0
 
 
 # ---------------------------------------------------------------------------------------------------
-# opt-in approx-exp library (libeppm_hip_approx.so: v_exp_f32 instead of the shared exp formula)
+# the tolerance library (libeppm_hip_tol.so: integer-domain tables / one hardware exp2 instead of the two software exp of the patch
+# term, free summation order).  Default-on: north_star's floating-point bar is "within 1e-3 px EPE on the bundled
+# Middlebury pair"; these tests hold the library to it against the exact library, which the rest of this suite pins to the oracle bit
+# for bit -- so the numbers are end-point errors against the CPU oracle at sizes it cannot be re-run at on the GPU box.
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.skipif(os.environ.get("EPPM_TEST_APPROX") != "1", reason="opt-in: EPPM_TEST_APPROX=1 builds libeppm_hip_approx.so (make approx) and measures it")
-def test_approx_exp_variant_within_tolerance():
-    """Opt-in (the library is not part of the default build, of bench.py or of the other tests' processes).
-    The opt-in libeppm_hip_approx.so is NOT bit-identical by design.  north_star's tolerance is 1e-3 px mean EPE on the bundled
-    Middlebury pair: the variant must stay inside it there, forwards and backwards.  On the synthetic shapes of BASELINE
-    configs[1], [3] and on the small fuzz images it does NOT (1e-2 .. 4e-2 px: a 1-ulp difference in a cost flips a strict `<`
-    between near-equal candidates and the flipped match propagates) -- recorded here with a regression bound of 5e-2 px and
-    reported per case by tools/approx_exp_epe.py; which is why the variant is never measured by bench.py and why nothing
-    further was built inside "the tolerance".  For scale: another ORDER of the reference's own races moves the flow by
-    0.07 - 0.9 px on the same shape (tools/parity_envelope.py).  Measured against the exact library, which the other tests pin
-    to the oracle bit for bit."""
-    import eppm_amd
-    eppm_amd.build(approx=True)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "approx_exp_epe.py")], capture_output=True, text=True, timeout=1200)
+TOL_BUNDLED_PX = 1e-3          # north_star: frame10/frame11, full size, both directions
+TOL_ENVELOPE_PX = 3e-2         # every other configuration: mean EPE inside the envelope of DESIGN.md section 3.6 (measured: <= 1e-5)
+
+
+@pytest.fixture(scope="module")
+def tolerance_report():
+    """tools/tolerance_epe.py in child processes (this process holds the parity tests' library): one for the tolerance library, the
+    parent for the exact one; configs[4] (3840x2160, radius 17) included."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tolerance_epe.py"), "--all"], capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert "approx-exp" in d["library"] and "approx" not in d["against"].split("(")[0], d
-    for name, c in d["cases"].items():
-        limit = 1e-3 if name.startswith("bundled") else 5e-2
-        assert c["epe_mean_px"] <= limit, (name, c)
-    assert d["cases"]["bundled_640x480"]["epe_mean_px"] > 0          # the variant really is a different arithmetic
+    assert "tolerance arithmetic" in d["library"] and "tolerance" not in d["against"].split("(")[0], d
+    return d
+
+
+def test_tolerance_library_within_1e3_px_on_the_bundled_pair(tolerance_report):
+    """frame10/frame11 640x480, the default three levels, forwards and backwards: mean EPE against the oracle <= 1e-3 px."""
+    for name in ("bundled_640x480", "bundled_640x480_backwards"):
+        c = tolerance_report["cases"][name]
+        assert c["pixels"] == 640 * 480
+        assert c["epe_mean_px"] <= TOL_BUNDLED_PX, (name, c)
+        assert c["frac_over_1px"] <= 1e-4, (name, c)
+
+
+def test_tolerance_library_inside_the_parity_envelope_on_every_configuration(tolerance_report):
+    """configs[1] 1024x436, configs[3] 1920x1080, configs[4] 3840x2160 radius 17 and the eight fuzz cases (odd sizes, radii, levels):
+    mean EPE and the fraction of pixels off by more than 1 px are reported per case and must stay inside DESIGN.md section 3.6's
+    envelope (what ANOTHER legal order of the reference's own races does is 0.04 - 0.9 px)."""
+    cases = tolerance_report["cases"]
+    assert {"config2_1024x436", "config4_1920x1080", "config5_3840x2160_r17"} <= set(cases) and sum(k.startswith("fuzz_") for k in cases) == 8
+    for name, c in cases.items():
+        assert c["epe_mean_px"] <= TOL_ENVELOPE_PX and c["frac_over_1px"] <= 1e-3, (name, c)
+    print(json.dumps({k: (c["epe_mean_px"], c["frac_over_1px"]) for k, c in cases.items()}))
+
+
+def test_tolerance_library_integer_stages_stay_bit_exact(frames):
+    """The stages that do not depend on a float comparison of patch costs are the exact library's code and stay bit-identical in the
+    tolerance library: prepare (prefilter, pyramid), census, and the final flow's smoothing given the same input.  Checked through the
+    C ABI of the tolerance library in a child process: image pyramid + census planes of the bundled pair against the oracle's."""
+    code = r"""
+import os, sys, json, hashlib
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from conftest import read_ppm, GOLDEN
+import eppm_amd
+eppm_amd.select_library("tol")
+from oracle import oracle as O
+a, b = read_ppm(os.path.join(GOLDEN, "frame10.ppm")), read_ppm(os.path.join(GOLDEN, "frame11.ppm"))
+e = eppm_amd.EPPM(); e.init(a, b, 480, 640); e.compute_flow()
+_, _, st = O.compute_flow(a, b, dump=True)
+ok = {}
+for l in range(3):
+    for name, key in (("img1", "img1"), ("img2", "img2"), ("census1", "cen1"), ("census2", "cen2")):
+        got, want = e.plane(name, l), st[f"{key}_L{l}"]
+        ok[f"{name}_L{l}"] = bool(np.array_equal(np.ascontiguousarray(got).view(np.uint8).reshape(-1), np.ascontiguousarray(want).view(np.uint8).reshape(-1)))
+nn = np.ascontiguousarray(e.plane("nnf1", 2)); ok["nnf1_after_fill_equal_frac"] = float((nn.view(np.int16).reshape(-1) == np.ascontiguousarray(st["nnf1_fill"]).view(np.int16).reshape(-1)).mean())
+print(json.dumps({"version": eppm_amd.lib().eppm_version().decode(), "ok": ok}))
+""" % (ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "tolerance arithmetic" in d["version"]
+    for k, v in d["ok"].items():
+        if k.endswith("_frac"):
+            assert v >= 0.9999, d            # the NNF after hole filling: integer decisions on tolerance costs (measured: identical)
+        else:
+            assert v is True, d

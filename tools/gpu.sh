@@ -21,12 +21,15 @@ mkdir -p $O
 MODE=$1
 TAG=${TAG:-r05}
 QUIET="--no-cpu-baseline --no-extras"
-# a variant that is missing or misspelt must stop the job, not benchmark the previous library under the new label
-swap_in() { cp $R/gpurun_variants/$1/libeppm_hip.so $R/eppm_amd/lib/libeppm_hip.so || { echo "swap_in: no variant '$1'" >&2; exit 1; }
-            if [ -f $R/gpurun_variants/$1/libeppm_hip_test.so ]; then cp $R/gpurun_variants/$1/libeppm_hip_test.so $R/eppm_amd/lib/libeppm_hip_test.so || exit 1; fi; }
+# a variant that is missing or misspelt must stop the job, not benchmark the previous library under the new label; the test library
+# travels with the product library (the pytest process computes with it) and a variant without one is an error for the modes that need it.
+# LIB=tol: the variants are builds of the tolerance library (tools/build_variant.sh with TOL=1), run with EPPM_HIP_VARIANT=tol
+LIBS="libeppm_hip.so libeppm_hip_test.so"
+if [ "$LIB" = tol ]; then LIBS="libeppm_hip_tol.so"; export EPPM_HIP_VARIANT=tol; fi
+swap_in() { for l in $LIBS; do cp $R/gpurun_variants/$1/$l $R/eppm_amd/lib/$l || { echo "swap_in: variant '$1' has no $l" >&2; exit 1; }; done; }
 # the saved original is this job's own (mktemp): two A/B jobs on one box never restore each other's variant
-keep_orig() { ORIG=$(mktemp -d /tmp/eppm_orig.XXXXXX) || exit 1; cp $R/eppm_amd/lib/libeppm_hip.so $R/eppm_amd/lib/libeppm_hip_test.so $ORIG/ || exit 1
-              trap 'cp $ORIG/libeppm_hip.so $ORIG/libeppm_hip_test.so $R/eppm_amd/lib/; rm -rf $ORIG' EXIT; }
+keep_orig() { ORIG=$(mktemp -d /tmp/eppm_orig.XXXXXX) || exit 1; for l in $LIBS; do cp $R/eppm_amd/lib/$l $ORIG/ || exit 1; done
+              trap 'for l in $LIBS; do cp $ORIG/$l $R/eppm_amd/lib/; done; rm -rf $ORIG' EXIT; }
 # rocprofv3 runs: the synthetic pairs come from the file cache (filled here, by plain child processes), so that the profiled bench.py
 # starts no `python -m eppm_amd.synth` workers under the profiler's preload (each would add an output directory of its own)
 warm_synth() { (cd $R && python3 - <<'PY'

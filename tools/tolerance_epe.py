@@ -28,9 +28,10 @@ def cases(all_sizes):
            ("config4_1920x1080", *synth.make_pair(1080, 1920, seed=1234, max_flow=40.0)[:2], {})]
     if all_sizes:
         out.append(("config5_3840x2160_r17", *synth.make_pair(2160, 3840, seed=1234, max_flow=60.0)[:2], dict(patch_r=17)))
-    for seed in T.FUZZ_SEEDS:
-        fa, fb, params = T._fuzz_case(seed, 0)
-        out.append((f"fuzz_seed{seed}", fa, fb, params))
+    if "--no-fuzz" not in sys.argv:
+        for seed in T.FUZZ_SEEDS:
+            fa, fb, params = T._fuzz_case(seed, 0)
+            out.append((f"fuzz_seed{seed}", fa, fb, params))
     return out
 
 
@@ -59,7 +60,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         f = os.path.join(td, "tol.npz")
         env = dict(os.environ, EPPM_HIP_VARIANT="tol")
-        subprocess.run([sys.executable, os.path.abspath(__file__), "--dump", f] + (["--all"] if all_sizes else []), env=env, check=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--dump", f] + [x for x in ("--all", "--no-fuzz") if x in sys.argv], env=env, check=True)
         ap = np.load(f)
         approx = {k: ap[k] for k in ap.files}
     os.environ.pop("EPPM_HIP_VARIANT", None)

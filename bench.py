@@ -476,7 +476,7 @@ def worker(args):
                 for e in engs + bengs:          # the 4K context needs no room, but the timings should not share the chip with idle-but-resident contexts' streams
                     e.synchronize()
                 if not args.no_cpu_baseline:
-                    os.sched_setaffinity(0, host_cpus)     # the oracle legs get the job's CPUs, not the GPU's NUMA node
+                    unbind_all_threads(host_cpus)          # the oracle legs get the job's CPUs, not the GPU's NUMA node
                 out["other_configs"] = other_configs(plan, local_rank, dev, with_cpu=not args.no_cpu_baseline)
             if args.library == "exact" and not args.no_tolerance_mode:
                 for e in engs + bengs:
@@ -484,13 +484,29 @@ def worker(args):
                 out["tolerance_mode"] = tolerance_mode(args)
         out["library"] = "exact (libeppm_hip.so: every flow bit-identical to the CPU oracle)" if args.library == "exact" else "tol (libeppm_hip_tol.so: NOT bit-identical)"
         if world == 1 and not args.no_cpu_baseline:
-            os.sched_setaffinity(0, host_cpus)     # the CPU baseline gets the whole host, not the GPU's NUMA node
+            unbind_all_threads(host_cpus)          # the CPU baseline gets the whole host, not the GPU's NUMA node
             out["cpu_baseline"] = cpu_baseline(w, h)
         data = (json.dumps(out) + "\n").encode()
         while data:
             data = data[os.write(json_fd, data):]
     if world > 1:
         dist.destroy_process_group()
+
+
+def unbind_all_threads(cpus):
+    """Give EVERY thread of this process the CPU set `cpus`: the threads created while the rank was bound to its GPU's NUMA node (torch's
+    intra-op pool, an OpenMP pool, gloo, the HIP runtime's) inherited the narrow mask, and sched_setaffinity(0, ..) alone widens only the
+    caller -- an oracle run on a pool thread would otherwise be timed on the node's CPUs."""
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = [0]
+    for t in tids:
+        try:
+            os.sched_setaffinity(t, cpus)
+        except OSError:
+            pass                    # a thread that has exited meanwhile
+    os.sched_setaffinity(0, cpus)
 
 
 def bind_to_gpu_numa(device):

@@ -1,0 +1,445 @@
+// launchers_ref_abi.cpp -- the reference's live extern "C" stage launchers with their exact argument lists (driver :40-62) and the
+// sub-stage entry points the parity tests drive, all on per-device state kept here (the reference keeps the equivalent in file-scope
+// textures, __constant__ tables and g_d_rand_states: SURVEY F12).
+#include "api_internal.h"
+
+using namespace eppm;
+
+// ---------------------------------------------------------------------------------------------------
+// state of the context-less, reference-signature launchers (the reference keeps the equivalent in
+// file-scope textures, __constant__ tables and g_d_rand_states: SURVEY F12)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct DevState {
+    float *lut_pm = nullptr, *lut_wmf = nullptr, *lut_blf = nullptr;
+    int lut_R = -1;
+    void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+    std::map<std::tuple<int, int, int, unsigned long long>, eppm_pm_rng*> rngs;
+};
+std::mutex g_mu;
+std::map<int, DevState> g_dev;
+hipStream_t g_stream = nullptr;
+eppm_params g_prm = {9, 10, 30, 6, 10, 20, 1234ULL, 0, kNumLevels};
+int g_launch_status = EPPM_OK;
+
+int dev_state(DevState** out)
+{
+    int d = 0;
+    HIPCHK(hipGetDevice(&d));
+    DevState& s = g_dev[d];
+    if (s.lut_R != g_prm.patch_r) {
+        (void)hipFree(s.lut_pm); s.lut_pm = nullptr;
+        std::vector<float> v;
+        host_pm_lut(g_prm.patch_r, v);
+        CHK(upload_lut(&s.lut_pm, v));
+        s.lut_R = g_prm.patch_r;
+    }
+    if (!s.lut_wmf) { std::vector<float> v; host_wmf_lut(v); CHK(upload_lut(&s.lut_wmf, v)); }
+    if (!s.lut_blf) { std::vector<float> v; host_blf_lut(v); CHK(upload_lut(&s.lut_blf, v)); }
+    *out = &s;
+    return EPPM_OK;
+}
+int get_scratch(DevState* s, size_t bytes, void** out, int slot = 0)
+{
+    if (s->scratch_bytes[slot] < bytes) {
+        (void)hipStreamSynchronize(g_stream);
+        (void)hipFree(s->scratch[slot]);
+        s->scratch[slot] = nullptr; s->scratch_bytes[slot] = 0;
+        HIPCHK(hipMalloc(&s->scratch[slot], bytes));
+        s->scratch_bytes[slot] = bytes;
+    }
+    *out = s->scratch[slot];
+    return EPPM_OK;
+}
+int get_rng(DevState* s, int w, int h, eppm_pm_rng** out)
+{
+    auto key = std::make_tuple(w, h, g_prm.num_guess, g_prm.seed);
+    auto it = s->rngs.find(key);
+    if (it == s->rngs.end()) {
+        eppm_pm_rng* r = nullptr;
+        CHK(rng_create(&r, w, h, g_prm));
+        it = s->rngs.emplace(key, r).first;
+    }
+    *out = it->second;
+    return EPPM_OK;
+}
+// The reference-signature launchers receive image and census planes apart (they were separate textures,
+// kernel.cu:1770-1781); the kernels read the packed plane, built here into per-device scratch (slots 2,3).
+int mk_planes(DevState* ds, PlanesH* out, const void* i1, const void* i2, const void* c1, const void* c2, int w, int h, size_t ip, size_t cp)
+{
+    void *a = nullptr, *b = nullptr;
+    CHK(get_scratch(ds, (size_t)w * h * 16, &a, 2));
+    CHK(get_scratch(ds, (size_t)w * h * 16, &b, 3));
+    launch_pack(a, w, (const uint32_t*)i1, (int)(ip / 4), (const uint8_t*)c1, (int)cp, w, h, g_stream);
+    launch_pack(b, w, (const uint32_t*)i2, (int)(ip / 4), (const uint8_t*)c2, (int)cp, w, h, g_stream);
+    out->pk1 = a; out->pk2 = b; out->w = w; out->h = h; out->pitch = w;
+    return EPPM_OK;
+}
+int finish() { HIPCHK(hipGetLastError()); return EPPM_OK; }
+// device-to-device copy on the launcher stream whose failure reaches eppm_launcher_status()
+int copy_d2d(void* dst, const void* src, size_t bytes)
+{
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
+    return EPPM_OK;
+}
+}  // namespace
+
+#define LAUNCHER_BEGIN std::lock_guard<std::mutex> lk_(g_mu); DevState* ds = nullptr; g_launch_status = dev_state(&ds); if (g_launch_status != EPPM_OK) return
+#define LAUNCHER_BEGIN_INT std::lock_guard<std::mutex> lk_(g_mu); DevState* ds = nullptr; CHK(dev_state(&ds))
+
+extern "C" int eppm_set_launcher_stream(void* s) { std::lock_guard<std::mutex> lk(g_mu); g_stream = (hipStream_t)s; return EPPM_OK; }
+extern "C" int eppm_set_launcher_params(const eppm_params* p)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!p) return eppm_default_params(&g_prm);
+    CHK(check_params(*p));
+    g_prm = *p;
+    return EPPM_OK;
+}
+
+// ---- PatchMatch sub-stages ----
+extern "C" int eppm_pm_rng_create(eppm_pm_rng** out, int w, int h, const eppm_params* p)
+{
+    if (!out || w < 1 || h < 1) return set_err(EPPM_ERR_ARG, "eppm_pm_rng_create: bad argument");
+    eppm_params q;
+    eppm_default_params(&q);
+    if (p) q = *p;
+    CHK(check_params(q));
+    return rng_create(out, w, h, q);
+}
+extern "C" int eppm_pm_rng_reset(eppm_pm_rng* r)
+{
+    if (!r) return set_err(EPPM_ERR_ARG, "NULL rng");
+    const size_t bytes = (size_t)r->gx * r->gy * 64 * 6 * 4;
+    HIPCHK(hipMemcpy(r->work[0][r->cur[0]], r->iter_tab, bytes, hipMemcpyDeviceToDevice));
+    return EPPM_OK;
+}
+extern "C" int eppm_pm_rng_destroy(eppm_pm_rng* r) { rng_free(r); return EPPM_OK; }
+extern "C" int eppm_pm_rng_block_states(eppm_pm_rng* r, uint32_t* dst, size_t dst_words)
+{
+    if (!r || !dst) return set_err(EPPM_ERR_ARG, "NULL argument");
+    const int nb = r->gx * r->gy;
+    if (dst_words < (size_t)nb * 6) return set_err(EPPM_ERR_ARG, "dst too small");
+    HIPCHK(hipDeviceSynchronize());
+    // lane 0 of each block sits at the block's sequential stream position
+    HIPCHK(hipMemcpy2D(dst, 24, r->work[0][r->cur[0]], 64 * 24, 24, nb, hipMemcpyDeviceToHost));
+    return EPPM_OK;
+}
+extern "C" int eppm_pm_gen_rand_field(eppm_pm_rng* r, eppm_short2* d_nnf, int w, int h, size_t disp_pitch)
+{
+    if (!r || !d_nnf || w != r->w || h != r->h) return set_err(EPPM_ERR_ARG, "eppm_pm_gen_rand_field: bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    PmBatch b;
+    b.n = 1; b.cpitch = w; b.npitch = (int)(disp_pitch / 4);
+    PlanesH P0;
+    P0.pk1 = P0.pk2 = nullptr; P0.w = w; P0.h = h; P0.pitch = w;
+    b.p[0] = mk_problem(P0, nullptr, (int16_t*)d_nnf, nullptr, r, 0);
+    launch_pm_init_field(b, r->dev(), g_stream);
+    return finish();
+}
+extern "C" int eppm_pm_cost_field(float* d_cost, const eppm_short2* d_nnf, const eppm_uchar4* i1, const eppm_uchar4* i2,
+                                  const unsigned char* c1, const unsigned char* c2, int w, int h, size_t img_pitch,
+                                  size_t cost_pitch, size_t disp_pitch, size_t census_pitch)
+{
+    LAUNCHER_BEGIN_INT;
+    PmBatch b;
+    b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
+    PlanesH P;
+    CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, nullptr, nullptr, 0);
+    launch_pm_cost_field(b, ds->lut_pm, g_prm.patch_r, g_stream);
+    return finish();
+}
+extern "C" int eppm_pm_seg_propagate(float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* i1, const eppm_uchar4* i2,
+                                     const unsigned char* c1, const unsigned char* c2, int w, int h, size_t img_pitch,
+                                     size_t cost_pitch, size_t disp_pitch, size_t census_pitch, int dir)
+{
+    LAUNCHER_BEGIN_INT;
+    void* tmp = nullptr;
+    CHK(get_scratch(ds, disp_pitch * h, &tmp));
+    PmBatch b;
+    b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
+    PlanesH P;
+    CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
+    void* spec = nullptr;
+    const bool speculative = opt_sweep_spec() >= 1;         // the stand-alone entry point has no iteration count: classic unless forced
+    // the evaluation cache of the sweeps lives for ONE call here (the planes of the next call may be other images): emptied first
+    const size_t plane_bytes = cost_pitch * h;
+    CHK(get_scratch(ds, plane_bytes * 8, &spec, 4));
+    HIPCHK(hipMemsetAsync((char*)spec + plane_bytes * 4, 0xff, plane_bytes * 4, g_stream));
+    b.cache_plane = plane_bytes / 4;
+    void* wl = nullptr;                                        // work list of the speculative form: lengths and stamps cleared per call
+    if (speculative && sweep_list_on(opt_sweep_spec())) {
+        b.wl_units = pm_worklist_units(w, h, g_prm.seg_len);
+        const size_t wl_bytes = pm_worklist_words(w, h, g_prm.seg_len) * 4;
+        CHK(get_scratch(ds, wl_bytes, &wl, 5));
+        HIPCHK(hipMemsetAsync(wl, 0, wl_bytes, g_stream));
+    }
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0, (float*)spec, (int32_t*)((char*)spec + plane_bytes * 4), (uint32_t*)wl);
+    for (int d = 0; d < 4; d++)
+        if (dir < 0 || dir == d) sweep(b, ds->lut_pm, g_prm, d, g_stream, speculative);
+    if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
+    return finish();
+}
+extern "C" int eppm_pm_jump_propagate(float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* i1, const eppm_uchar4* i2,
+                                      const unsigned char* c1, const unsigned char* c2, int w, int h, size_t img_pitch,
+                                      size_t cost_pitch, size_t disp_pitch, size_t census_pitch)
+{
+    LAUNCHER_BEGIN_INT;
+    void* tmp = nullptr;
+    CHK(get_scratch(ds, disp_pitch * h, &tmp));
+    PmBatch b;
+    b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
+    PlanesH P;
+    CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0);
+    jump(b, ds->lut_pm, g_prm, g_stream);
+    if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
+    return finish();
+}
+extern "C" int eppm_pm_parallel_propagate(float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* i1, const eppm_uchar4* i2,
+                                          const unsigned char* c1, const unsigned char* c2, int w, int h, size_t img_pitch,
+                                          size_t cost_pitch, size_t disp_pitch, size_t census_pitch)
+{
+    LAUNCHER_BEGIN_INT;
+    void* tmp = nullptr;
+    CHK(get_scratch(ds, disp_pitch * h, &tmp));
+    PmBatch b;
+    b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
+    PlanesH P;
+    CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, (int16_t*)tmp, nullptr, 0);
+    neighbor(b, ds->lut_pm, g_prm, 1, g_stream);
+    if (b.p[0].nnf != (int16_t*)d_nnf) HIPCHK(hipMemcpyAsync(d_nnf, b.p[0].nnf, disp_pitch * h, hipMemcpyDeviceToDevice, g_stream));
+    return finish();
+}
+extern "C" int eppm_pm_random_search(eppm_pm_rng* r, float* d_cost, eppm_short2* d_nnf, const eppm_uchar4* i1, const eppm_uchar4* i2,
+                                     const unsigned char* c1, const unsigned char* c2, int w, int h, size_t img_pitch,
+                                     size_t cost_pitch, size_t disp_pitch, size_t census_pitch)
+{
+    if (!r || w != r->w || h != r->h) return set_err(EPPM_ERR_ARG, "eppm_pm_random_search: bad rng");
+    LAUNCHER_BEGIN_INT;
+    if (r->G != g_prm.num_guess) return set_err(EPPM_ERR_ARG, "rng was created for num_guess=%d", r->G);
+    PmBatch b;
+    b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
+    PlanesH P;
+    CHK(mk_planes(ds, &P, i1, i2, c1, c2, w, h, img_pitch, census_pitch));
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_nnf, nullptr, r, 0);
+    search(b, r, ds->lut_pm, g_prm, g_stream);
+    return finish();
+}
+extern "C" int eppm_gauss_filter_rgba(eppm_uchar4* d_out, const eppm_uchar4* d_in, size_t pitch, int h, int w, float sigma, int radius)
+{
+    if (radius < 0 || radius > 6) return set_err(EPPM_ERR_ARG, "radius %d out of range [0,6]", radius);
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_gauss_rgba((uint32_t*)d_out, (const uint32_t*)d_in, (int)(pitch / 4), h, w, sigma, radius, g_stream);
+    return finish();
+}
+extern "C" int eppm_resize_rgba(eppm_uchar4* d_out, size_t out_pitch, int outH, int outW, const eppm_uchar4* d_in, size_t in_pitch,
+                                int h, int w, float ratio)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_resize_rgba((uint32_t*)d_out, (int)(out_pitch / 4), outH, outW, (const uint32_t*)d_in, (int)(in_pitch / 4), h, w, ratio, g_stream);
+    return finish();
+}
+extern "C" int eppm_resize_flow(eppm_float2* d_out, int outH, int outW, const eppm_float2* d_in, int h, int w, float ratio)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_resize_flow((float*)d_out, outH, outW, (const float*)d_in, h, w, ratio, 1.0f, g_stream);
+    return finish();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the reference's live extern "C" launchers (driver :40-62)
+// ---------------------------------------------------------------------------------------------------
+extern "C" void baoCudaCensusTransform(unsigned char* d_census1, unsigned char* d_census2, eppm_uchar4* d_img1, eppm_uchar4* d_img2,
+                                       int w, int h, size_t img_pitch, size_t census_pitch)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_census(d_census1, (int)census_pitch, nullptr, 0, (const uint32_t*)d_img1, (int)(img_pitch / 4), w, h, g_stream);
+    launch_census(d_census2, (int)census_pitch, nullptr, 0, (const uint32_t*)d_img2, (int)(img_pitch / 4), w, h, g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaPatchMatchMultiscalePrepare(eppm_uchar4** pImgPyr1, eppm_uchar4** pImgPyr2, unsigned char** pCensusPyr1,
+        unsigned char** pCensusPyr2, eppm_uchar4** pTempPyr1, eppm_uchar4** pTempPyr2, int* arrH, int* arrW,
+        size_t* arrPitchUchar4, size_t* arrPitchUchar1, int nLevels, eppm_uchar4* d_img1, eppm_uchar4* d_img2, int h, int w)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    hipStream_t s = g_stream;
+    const float ratio = 0.5f;
+    const float baseSigma = (1 / ratio - 1);
+    const int n = (int)(log(0.25) / (double)logf(ratio));   // C++ float overload in the reference: n = 1
+    const float nSigma = baseSigma * n;
+    for (int k = 0; k < 2; k++) {
+        uint32_t** pyr = (uint32_t**)(k ? pImgPyr2 : pImgPyr1);
+        uint32_t** tmp = (uint32_t**)(k ? pTempPyr2 : pTempPyr1);
+        const uint32_t* raw = (const uint32_t*)(k ? d_img2 : d_img1);
+        // NOTE: the reference allocates its temp pyramid unpitched (driver :155-156) yet addresses it with the
+        // pitched stride; here temp planes are addressed with arrPitchUchar4 as well, so they must be pitched.
+        launch_gauss_rgba(pyr[0], raw, (int)(arrPitchUchar4[0] / 4), h, w, .5f, 2, s);
+        for (int i = 1; i < nLevels; i++) {
+            if (i <= n) {
+                const float sigma = baseSigma * i;
+                launch_gauss_rgba(tmp[0], pyr[0], (int)(arrPitchUchar4[0] / 4), arrH[0], arrW[0], sigma, (int)(sigma * 3), s);
+                launch_resize_rgba(pyr[i], (int)(arrPitchUchar4[i] / 4), arrH[i], arrW[i], tmp[0], (int)(arrPitchUchar4[0] / 4), arrH[0], arrW[0], (float)pow(ratio, i), s);
+            } else {
+                const int j = i - n;
+                launch_gauss_rgba(tmp[j], pyr[j], (int)(arrPitchUchar4[j] / 4), arrH[j], arrW[j], nSigma, (int)(nSigma * 3), s);
+                launch_resize_rgba(pyr[i], (int)(arrPitchUchar4[i] / 4), arrH[i], arrW[i], tmp[j], (int)(arrPitchUchar4[j] / 4), arrH[j], arrW[j],
+                                   (float)pow(ratio, i) * arrW[0] / arrW[j], s);
+            }
+        }
+    }
+    for (int i = 0; i < nLevels; i++) {
+        launch_census(pCensusPyr1[i], (int)arrPitchUchar1[i], nullptr, 0, (const uint32_t*)pImgPyr1[i], (int)(arrPitchUchar4[i] / 4), arrW[i], arrH[i], s);
+        launch_census(pCensusPyr2[i], (int)arrPitchUchar1[i], nullptr, 0, (const uint32_t*)pImgPyr2[i], (int)(arrPitchUchar4[i] / 4), arrW[i], arrH[i], s);
+    }
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaPatchMatch(eppm_short2* d_disp_vec, float* d_cost, eppm_uchar4* d_img1, eppm_uchar4* d_img2,
+        unsigned char* d_census1, unsigned char* d_census2, int w, int h, size_t img_pitch, size_t cost_pitch,
+        size_t disp_pitch, size_t census_pitch)
+{
+    LAUNCHER_BEGIN;
+    eppm_pm_rng* r = nullptr;
+    g_launch_status = get_rng(ds, w, h, &r);
+    if (g_launch_status != EPPM_OK) return;
+    void* tmp = nullptr;
+    g_launch_status = get_scratch(ds, disp_pitch * h, &tmp);
+    if (g_launch_status != EPPM_OK) return;
+    PmBatch b;
+    b.n = 1; b.cpitch = (int)(cost_pitch / 4); b.npitch = (int)(disp_pitch / 4);
+    PlanesH P;
+    g_launch_status = mk_planes(ds, &P, d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch);
+    if (g_launch_status != EPPM_OK) return;
+    void* spec = nullptr;
+    const size_t plane_bytes = cost_pitch * h;
+    g_launch_status = get_scratch(ds, plane_bytes * 8, &spec, 4);
+    if (g_launch_status != EPPM_OK) return;
+    b.cache_plane = plane_bytes / 4;          // (k_pm_init_field empties the cache)
+    void* wl = nullptr;
+    b.wl_units = pm_worklist_units(w, h, g_prm.seg_len);
+    g_launch_status = get_scratch(ds, pm_worklist_words(w, h, g_prm.seg_len) * 4, &wl, 5);       // (k_pm_init_field clears it)
+    if (g_launch_status != EPPM_OK) return;
+    b.p[0] = mk_problem(P, d_cost, (int16_t*)d_disp_vec, (int16_t*)tmp, r, 0, (float*)spec, (int32_t*)((char*)spec + plane_bytes * 4), sweep_list_on(opt_sweep_spec()) ? (uint32_t*)wl : nullptr);
+    run_patchmatch(b, r, ds->lut_pm, g_prm, g_stream, opt_sweep_spec());
+    if (b.p[0].nnf != (int16_t*)d_disp_vec && (g_launch_status = copy_d2d(d_disp_vec, b.p[0].nnf, disp_pitch * h)) != EPPM_OK) return;
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaLeftRightCheck(eppm_short2* d_disp_vec, float* d_cost, eppm_short2* d_disp_vec2, float* d_cost2,
+        int w, int h, size_t cost_pitch, size_t disp_pitch)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_lr_check((int16_t*)d_disp_vec, d_cost, (const int16_t*)d_disp_vec2, w, h, (int)(cost_pitch / 4), (int)(disp_pitch / 4), g_stream);
+    launch_lr_check((int16_t*)d_disp_vec2, d_cost2, (const int16_t*)d_disp_vec, w, h, (int)(cost_pitch / 4), (int)(disp_pitch / 4), g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaOutlierRemoval(eppm_short2* d_disp_vec, float* d_cost, int w, int h, size_t cost_pitch, size_t disp_pitch)
+{
+    LAUNCHER_BEGIN;
+    void* tmp = nullptr;
+    g_launch_status = get_scratch(ds, disp_pitch * h, &tmp);
+    if (g_launch_status != EPPM_OK) return;
+    if ((g_launch_status = copy_d2d(tmp, d_disp_vec, disp_pitch * h)) != EPPM_OK) return;
+    launch_outlier((int16_t*)d_disp_vec, d_cost, (const int16_t*)tmp, w, h, (int)(cost_pitch / 4), (int)(disp_pitch / 4), g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaWeightedMedianFilter(eppm_short2* d_disp_vec, float* d_cost, eppm_uchar4* d_img, int w, int h,
+        size_t img_pitch, size_t cost_pitch, size_t disp_pitch, int num_iter, bool is_only_occlusion)
+{
+    (void)d_cost; (void)cost_pitch;
+    LAUNCHER_BEGIN;
+    void* tmp = nullptr;
+    g_launch_status = get_scratch(ds, disp_pitch * h, &tmp);
+    if (g_launch_status != EPPM_OK) return;
+    void* ws = nullptr;
+    g_launch_status = get_scratch(ds, wmf_workspace_words(w, h, num_iter) * 4, &ws, 1);
+    if (g_launch_status != EPPM_OK) return;
+    int16_t* res = launch_wmf((int16_t*)d_disp_vec, (int16_t*)tmp, (const uint32_t*)d_img, (int)(img_pitch / 4), w, h, (int)(disp_pitch / 4),
+                              ds->lut_wmf, num_iter, is_only_occlusion ? 1 : 0, (uint32_t*)ws, g_stream);
+    if (res != (int16_t*)d_disp_vec && (g_launch_status = copy_d2d(d_disp_vec, res, disp_pitch * h)) != EPPM_OK) return;
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaFillHole(eppm_short2* d_disp_vec, float* d_cost, eppm_uchar4* d_img, int w, int h,
+        size_t img_pitch, size_t cost_pitch, size_t disp_pitch)
+{
+    (void)d_cost; (void)cost_pitch;
+    LAUNCHER_BEGIN;
+    void* tmp = nullptr;
+    g_launch_status = get_scratch(ds, disp_pitch * h, &tmp);
+    if (g_launch_status != EPPM_OK) return;
+    if ((g_launch_status = copy_d2d(tmp, d_disp_vec, disp_pitch * h)) != EPPM_OK) return;
+    launch_fill_holes((int16_t*)d_disp_vec, (const int16_t*)tmp, (const uint32_t*)d_img, (int)(img_pitch / 4), w, h, (int)(disp_pitch / 4), g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaNNF2Flow(eppm_float2* d_flow, eppm_short2* d_disp_vec, int w, int h, size_t disp_pitch, size_t flow_pitch)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    launch_nnf2flow((float*)d_flow, (int)(flow_pitch / 8), (const int16_t*)d_disp_vec, (int)(disp_pitch / 4), w, h, g_stream);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaBLFCostFilterRefine(eppm_float2* d_flow_vec, eppm_uchar4* d_img1, eppm_uchar4* d_img2, unsigned char* d_census1,
+        unsigned char* d_census2, int w, int h, size_t img_pitch, size_t census_pitch)
+{
+    LAUNCHER_BEGIN;
+    PlanesH P;
+    g_launch_status = mk_planes(ds, &P, d_img1, d_img2, d_census1, d_census2, w, h, img_pitch, census_pitch);
+    if (g_launch_status != EPPM_OK) return;
+    launch_c2f_refine(P, (float*)d_flow_vec, ds->lut_pm, g_prm.patch_r, nullptr, g_stream, kOnePair, opt_no_split() != 0);
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaBLF_C2F(eppm_float2** pFlowPyr, eppm_uchar4** pImgPyr1, eppm_uchar4** pImgPyr2, unsigned char** pCensusPyr1,
+        unsigned char** pCensusPyr2, eppm_float2** pTempPyr1, eppm_float2** pTempPyr2, int* arrH, int* arrW,
+        size_t* arrPitchUchar4, size_t* arrPitchUchar1, int nLayerIdx)
+{
+    (void)pTempPyr1; (void)pTempPyr2;
+    LAUNCHER_BEGIN;
+    const int l = nLayerIdx;
+    launch_resize_flow((float*)pFlowPyr[l], arrH[l], arrW[l], (const float*)pFlowPyr[l + 1], arrH[l + 1], arrW[l + 1], 2.0f, 1.0f, g_stream);  // refine :1082
+    launch_mul_scalar((float*)pFlowPyr[l], 2.0f, arrH[l], arrW[l], g_stream);                                                                  // refine :1083
+    PlanesH P;
+    g_launch_status = mk_planes(ds, &P, pImgPyr1[l], pImgPyr2[l], pCensusPyr1[l], pCensusPyr2[l], arrW[l], arrH[l], arrPitchUchar4[l], arrPitchUchar1[l]);
+    if (g_launch_status != EPPM_OK) return;
+    launch_c2f_refine(P, (float*)pFlowPyr[l], ds->lut_pm, g_prm.patch_r, nullptr, g_stream, kOnePair, opt_no_split() != 0);                       // refine :1086
+    g_launch_status = finish();
+}
+
+extern "C" void baoCudaFlowSmoothing(eppm_float2* d_flow, eppm_uchar4* d_img, int w, int h, size_t img_pitch, size_t flow_pitch)
+{
+    LAUNCHER_BEGIN;
+    void* tmp = nullptr;
+    g_launch_status = get_scratch(ds, flow_pitch * h, &tmp);
+    if (g_launch_status != EPPM_OK) return;
+    if ((g_launch_status = copy_d2d(tmp, d_flow, flow_pitch * h)) != EPPM_OK) return;
+    launch_flow_blf((float*)d_flow, (const float*)tmp, (const uint32_t*)d_img, (int)(img_pitch / 4), w, h, (int)(flow_pitch / 8), ds->lut_blf, g_stream);
+    g_launch_status = finish();
+}
+
+// ---- flow colour coding (basic/bao_basic_cuda.cuh:776-845; driver :308-314) ----
+extern "C" int eppm_flow_to_color(eppm_uchar4* d_rgba, const eppm_float2* d_flow, int h, int w, float max_disp_x, float max_disp_y)
+{
+    if (!d_rgba || !d_flow || h < 1 || w < 1) return set_err(EPPM_ERR_ARG, "eppm_flow_to_color: bad argument");
+    LAUNCHER_BEGIN_INT;
+    (void)ds;
+    launch_flow_to_color((uint32_t*)d_rgba, (const float*)d_flow, h, w, max_disp_x, max_disp_y, g_stream);
+    return finish();
+}
+// the C++-linkage symbol the reference's driver declares at :64 (defaults 100,100 there; the live call passes 20,20)
+void bao_cuda_convert_flow_to_colorshow(uchar4* rgbflow, float2* flow_vec, int h, int w, float max_disp_x, float max_disp_y)
+{
+    g_launch_status = eppm_flow_to_color((eppm_uchar4*)rgbflow, (const eppm_float2*)flow_vec, h, w, max_disp_x, max_disp_y);
+}
+
+extern "C" int eppm_launcher_status(void) { return g_launch_status; }
+
+int launcher_finish() { return finish(); }

@@ -7,7 +7,7 @@
  * (oracle/Makefile, target runeppm_ref).
  *
  *   bao_timer_gpu      device time between start() and stop() on the null stream (hipEvent pair), in ms
- *   bao_timer_gpu_cpu  wall time with a device synchronisation on both sides (gettimeofday), in seconds
+ *   bao_timer_gpu_cpu  wall time with a device synchronisation on both sides (monotonic clock), in seconds
  *
  * The device-memory templates of the reference header (bao_cuda_alloc / bao_cuda_copy_*, :96-253) are
  * private plumbing of its driver; the C ABI of eppm.h offers the equivalents (eppm_malloc_device, ...).

@@ -23,7 +23,8 @@ extern "C" {
  * iterations >= 2 (the third on) run in the speculative two-launch form when a launch covers at least 100 000 pixels (two 1024x436 pairs,
  * one 1920x1080 pair), 0 never, 1 always (also in eppm_pm_seg_propagate, which otherwise runs the classic form), 2 always and without
  * the work list (phase B walks every chain), 3 always and in the merged form (one phase A for the four sweeps of an iteration, the form the
- * library takes by itself from the sixth iteration on).  "rand_table": 1 (default) a context's random searches read numbers drawn ahead per geometry,
+ * library takes by itself from the sixth iteration on -- from the eighth on problems of more than 65 536 pixels, i.e. the quarter-resolution
+ * level of 1920x1080 and 3840x2160 pairs).  "rand_table": 1 (default) a context's random searches read numbers drawn ahead per geometry,
  * 0 they draw while they search -- the form a context takes by itself when the table would exceed 512 MB. */
 int  eppm_test_set_option(const char* name, int value);
 /* admissible spread (max - min, pixels) of a 16x16 tile's candidate centres for which the LDS-window refine kernels stage the

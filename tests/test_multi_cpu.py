@@ -179,7 +179,12 @@ def test_cpu_whole_host_baseline_uses_every_cpu_once():
     tpp = max(1, ncpu // 2)
     r = bench.cpu_whole_host(96, 64, tpp, rounds=2)
     assert "error" not in r, r
-    assert r["physical_cores"] == ncpu and r["processes"] == ncpu // tpp and r["cores"] == r["processes"] * tpp and r["kind"] == "port"
+    # what the job may use is its cgroup's CPU quota when there is one (the pool's GPU boxes: 16 CPUs of a 128-core host -> one process of
+    # 16 threads), every physical core otherwise (this container)
+    usable = min(ncpu, int(bench.cpu_quota() or ncpu))
+    procs, threads = max(1, usable // tpp), min(tpp, usable)
+    assert r["physical_cores"] == ncpu and r["usable_cpus"] == usable and r["processes"] == procs and r["threads_per_process"] == threads
+    assert r["cores"] == procs * threads and r["kind"] == "port"
     assert r["value"] > 0 and len(r["round_s"]) == 2 and r["value"] == r["processes"] * 96 * 64 / sorted(r["round_s"])[1] / 1e6
 
 

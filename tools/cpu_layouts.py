@@ -1,13 +1,14 @@
 """GPU-box probe (CPU only): the whole-host rate of the CPU oracle by process layout -- bench.cpu_whole_host with one round each.
 Why bench.py's `cpu_baseline.whole_host` stays inside the cgroup's CPU quota (16 CPUs on this pool) and uses one hardware thread per
 physical core.  usage: cpu_layouts.py"""
-print("cgroup cpu quota (CPUs):", bench.cpu_quota(), flush=True)
 import json
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
+
+print("cgroup cpu quota (CPUs):", bench.cpu_quota(), flush=True)
 
 W, H = 1024, 436
 for name, kw in (("16 threads per process, physical cores only", dict(threads_per_proc=16)),

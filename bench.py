@@ -79,7 +79,7 @@ def parse_args(known_only=False):
                     help="BASELINE configs[2] with a correctness bit: this rank's share of the 64 pairs (pair i -> rank i mod N, seeds 1234+i) through the "
                          "host boundary, every flow checked against tests/golden/MANIFEST_config3.json.  Default: on when --gpus > 1")
     ap.add_argument("--no-verify-config3", dest="verify_config3", action="store_false")
-    ap.add_argument("--library", default="exact", choices=["exact", "tol"],
+    ap.add_argument("--library", default="tol" if os.environ.get("EPPM_HIP_VARIANT") == "tol" else "exact", choices=["exact", "tol"],
                     help="exact: libeppm_hip.so, bit-identical to the oracle (the default, and what `value` always is); tol: the tolerance library "
                          "libeppm_hip_tol.so (not bit-identical, <= 1e-3 px EPE on the bundled pair) -- the run the default line embeds as `tolerance_mode`")
     ap.add_argument("--no-tolerance-mode", action="store_true", help="skip the tolerance_mode leg (a child run of this script with --library tol)")
@@ -425,13 +425,21 @@ def worker(args):
             insts = dp["valu_insts"] / 2 * NB                      # wave64 VALU instructions per launch
             roof = {"bound": "valu", "kernel": kern, "achieved": insts / (dom_ms * 1e-3) / 1e9, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e9,
                     "unit": "G wave64-inst/s", "frac": insts / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S,
-                    "traffic": (2 * dp["fetch_size_kb"] + dp["write_size_kb"]) * 1024 / 2 * NB, "traffic_unit": "HBM-side bytes per launch",
-                    "wave64_valu_insts_per_launch": insts, "hbm": dict(hbm, traffic=(2 * dp["fetch_size_kb"] + dp["write_size_kb"]) * 1024 / 2 * NB),
+                    "traffic": (2 * (dp.get("fetch_size_kb") or 0) + (dp.get("write_size_kb") or 0)) * 1024 / 2 * NB, "traffic_unit": "HBM-side bytes per launch",
+                    "wave64_valu_insts_per_launch": insts, "hbm": dict(hbm, traffic=(2 * (dp.get("fetch_size_kb") or 0) + (dp.get("write_size_kb") or 0)) * 1024 / 2 * NB),
                     "source": pmc.get("source"),
                     "note": "the path has no dense contraction and is not HBM bound (3 600 patch samples x ~46 VALU instructions per pixel against 26 "
                             "algorithmic bytes): the bound that applies is vector-ALU issue, peak = 256 CUs x 4 SIMD x 2.4 GHz / 2 cycles per wave64 "
                             "instruction; the HBM form the contract names is in `hbm`; `traffic` = HBM bytes per launch from separate --pmc passes "
                             "(2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction)"}
+            if dp.get("fetch_size_kb") is None or dp.get("write_size_kb") is None:
+                roof["traffic"] = roof["hbm"]["traffic"] = None
+            if dp.get("lds"):
+                # the LDS array beside the VALU (separate --pmc pass): cycles in which it serves this kernel, per CU and launch, against the launch's duration
+                cyc = dp["lds"]["lds_idx_active"] / 2 * NB / 256
+                roof["lds"] = {"lds_array_cycles_per_cu_per_launch": cyc, "bank_conflict_frac_of_them": dp["lds"]["lds_bank_conflict"] / max(1.0, dp["lds"]["lds_idx_active"]),
+                               "busy_frac_at_2.4GHz": cyc / (dom_ms * 1e-3 * 2.4e9),
+                               "note": "SQ_LDS_IDX_ACTIVE summed over the CUs / 256; 1.0 = the LDS array of every CU busy every cycle of the launch"}
         else:
             roof = dict(hbm, kernel=kern, traffic=None,
                         note="profiles/pmc_constants.json has no entry measured on these device sources: VALU instruction count and HBM traffic unknown")

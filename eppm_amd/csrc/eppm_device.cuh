@@ -240,8 +240,10 @@ __device__ __forceinline__ float tol_cost(const TolTables& T, const rgbf p1, con
 constexpr float kTolExpC = (float)(1.4426950408889634 / (255.0 * 255.0 * (double)kPmSigR2) / (double)(kTolScale * kTolScale));
 __device__ __forceinline__ float tol_exp_arg(uint32_t off4k, float lsrc)
 {
-    const float kf = (float)off4k;
-    return __builtin_fmaf(kf * kf, -kTolExpC, lsrc);
+    // the integer 4k as a float: its bit pattern is the denormal 4k * 2^-149, and one full-rate multiplication by 2^100 makes it the
+    // normal number 4k * 2^-49 (exact) -- 2 issue cycles where v_cvt_f32_u32 takes 4; the scale is folded into the constant
+    const float kf = __uint_as_float(off4k) * 0x1p100f;
+    return __builtin_fmaf(kf * kf, -kTolExpC * 0x1p98f, lsrc);
 }
 // a word {R, G, B, census} of the 4-byte planes -> the texel make_texel builds from it: three SDWA shifts (byte k << 2) and a byte permute
 // (census into all four bytes), 16 issue cycles; `two` = a register holding 2 (an SDWA operand cannot be an inline constant)
@@ -270,9 +272,8 @@ __device__ __forceinline__ void patch_terms(const float4 q1, const float4 q2, co
     weight_term = (tol_at(T.ta, linf_off(c1, p1)) * gsp) * tol_at(T.ta, linf_off(c2, p2));
 #elif EPPM_TOL_PM_WEIGHT == 1          // source half from the table, target half by the hardware exp2
     weight_term = (tol_at(T.ta, linf_off(c1, p1)) * gsp) * __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2, p2), 0.0f));
-#else                                  // one hardware exp2 of the summed argument (gsp must then hold log2 of the product: refine kernels only)
-    const float ka = (float)linf_off(c1, p1);
-    weight_term = gsp * __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2, p2), -kTolExpC * (ka * ka)));
+#else                                  // one hardware exp2 of the summed argument
+    weight_term = gsp * __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2, p2), tol_exp_arg(linf_off(c1, p1), 0.0f)));
 #endif
 }
 __device__ __forceinline__ void patch_accum(float& cost_sum, float& weight_sum, float cost_term, float weight_term)

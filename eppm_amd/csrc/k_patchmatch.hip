@@ -142,6 +142,9 @@ template <int M> __device__ __forceinline__ float patch_dist_any(const Planes&, 
 // PK = 2 (tolerance library): the S samples of a patch row are S consecutive words of the target's column-parity plane (PlanesH::pp2):
 // 3 gathers per row of 10 samples (16 + 16 + 8 bytes) instead of 10, unpacked by unpack_texel.  With the patch term at a third of its
 // exact instruction count these kernels run at the L1's lane rate; this divides their gathers by 3.3.
+// (The source half of a sample's weight is the same for the six guesses of a pixel; forming it once per workgroup in LDS -- 26 KB,
+// [sample][pixel] -- and a barrier LOSES here as it did in the exact library: search 215 -> 234 us per 8-pair launch, bench 304 -> 298,
+// profiles/r06x_c_search_hoist.txt.)
 template <int RT, int PK = 0, class LUT>
 __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L, int R, const float4* __restrict__ s_src, int TW,
                                                    int tx, int ty, int x1, int y1, int x2, int y2, const PlanesH& PH)

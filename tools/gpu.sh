@@ -19,7 +19,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 MODE=$1
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 QUIET="--no-cpu-baseline --no-extras"
 # a variant that is missing or misspelt must stop the job, not benchmark the previous library under the new label; the test library
 # travels with the product library (the pytest process computes with it) and a variant without one is an error for the modes that need it.
@@ -125,19 +125,29 @@ round)
   SQ="SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_VMEM"
   SQ2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE"
   COMMON="--repeats 1 $QUIET"
+  # the PMC passes for both libraries: exact (labels single, batch8, hd, uhd17) and tolerance (tol_*); separate --pmc runs, never with a trace domain
+  for lib in exact tol; do
+    pre=""; [ $lib = tol ] && pre="tol_"
   while IFS='|' read -r label bargs; do
     [ -z "$label" ] && continue
+    label=$pre$label
     rm -rf $OT/pmc_sq_$label $OT/pmc_sq2_$label $OT/pmc_fetch_$label $OT/pmc_write_$label
-    rocprofv3 --kernel-trace --pmc $SQ GRBM_GUI_ACTIVE --output-format csv -d $OT/pmc_sq_$label -- python3 $R/bench.py $bargs $COMMON > /dev/null 2>&1
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OT/pmc_fetch_$label -- python3 $R/bench.py $bargs $COMMON > /dev/null 2>&1
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OT/pmc_write_$label -- python3 $R/bench.py $bargs $COMMON > /dev/null 2>&1
-    case $label in single|batch8) rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $OT/pmc_sq2_$label -- python3 $R/bench.py $bargs $COMMON > /dev/null 2>&1 ;; esac
+    rocprofv3 --kernel-trace --pmc $SQ GRBM_GUI_ACTIVE --output-format csv -d $OT/pmc_sq_$label -- python3 $R/bench.py --library $lib $bargs $COMMON > /dev/null 2>&1
+    case $label in single|batch8|tol_single|tol_batch8)
+      rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OT/pmc_fetch_$label -- python3 $R/bench.py --library $lib $bargs $COMMON > /dev/null 2>&1
+      rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OT/pmc_write_$label -- python3 $R/bench.py --library $lib $bargs $COMMON > /dev/null 2>&1
+      rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $OT/pmc_sq2_$label -- python3 $R/bench.py --library $lib $bargs $COMMON > /dev/null 2>&1 ;;
+    hd|uhd17)
+      rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OT/pmc_fetch_$label -- python3 $R/bench.py --library $lib $bargs $COMMON > /dev/null 2>&1
+      rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OT/pmc_write_$label -- python3 $R/bench.py --library $lib $bargs $COMMON > /dev/null 2>&1 ;;
+    esac
   done <<LIST
 single|--steps 8 --warmup 4 --batch 1 --inflight 1
 batch8|--steps 16 --warmup 8 --batch 8 --inflight 1
 hd|$HD --steps 4 --warmup 2
 uhd17|$UHD --steps 2 --warmup 1
 LIST
+  done
   # the constants the bench lines below report (valid for exactly these device sources), derived on the box from the passes above
   cd $R && python tools/store_profiles.py $T > $OT/pmc_constants_summary.json 2> $OT/store_profiles.err
   if [ -z "$PMC_ONLY" ]; then
@@ -150,6 +160,9 @@ LIST
     rocprofv3 --kernel-trace --stats --output-format csv -d $OT/stats_default -- python3 $R/bench.py $QUIET > $OT/bench_under_rocprof.json 2>/dev/null
     rocprofv3 --kernel-trace --stats --output-format csv -d $OT/stats_single -- python3 $R/bench.py --steps 30 --warmup 3 --batch 1 --inflight 1 $COMMON > /dev/null 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $OT/stats_batch8 -- python3 $R/bench.py --steps 32 --warmup 8 --batch 8 --inflight 1 $COMMON > /dev/null 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OT/stats_tol_batch8 -- python3 $R/bench.py --library tol --steps 32 --warmup 8 --batch 8 --inflight 1 $COMMON > /dev/null 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OT/stats_tol_default -- python3 $R/bench.py --library tol $QUIET > $OT/bench_tol_under_rocprof.json 2>/dev/null
+    python3 $R/tools/tolerance_epe.py --all > $OT/tolerance_epe.json 2>/dev/null
   fi
   ls $OT ;;
 *)

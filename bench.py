@@ -469,7 +469,7 @@ def worker(args):
             "epe_vs_synthetic_gt": epe_gt,
             "epe_vs_synthetic_gt_note": "flow QUALITY of the algorithm on the synthetic pair, not parity (the oracle's own flow has exactly this error): band-limited "
                                         "noise with two motion layers is hard for EPPM -- 43 % of the quarter-resolution matches fail the left-right check and 63 % are "
-                                        "holes after the outlier vote, against 24 % / 27 % on the natural pair of other_configs.natural_1024x436 (DESIGN.md section 5)",
+                                        "holes after the outlier vote, against 26 % / 33 % on the natural pair of other_configs.natural_1024x436 and 24 % / 27 % on the bundled pair (DESIGN.md section 5)",
         }
         out.update(extras)
         out["path_valu_roofline"] = path_valu_roofline(pmc, NB, dt / args.steps)

@@ -1006,3 +1006,39 @@ def test_speculative_sweep_form_and_evaluation_cache_equal_the_lockstep_sweeps(c
     visited = 12 * (h * w - min(h, w))          # roughly: every pixel but one per line, per sweep
     assert evals["A_cached"] > 0 and evals["B_fresh"] > 0
     assert evals["A"] + evals["B_fresh"] < visited      # fewer evaluations than the reference's one per visited pixel
+
+
+# ---------------------------------------------------------------- the tolerance library's arithmetic, on the CPU
+def test_tolerance_arithmetic_moves_no_match_on_the_bundled_pair(frames):
+    """tools/tolerance_envelope.py's finding, which libeppm_hip_tol.so is built on, on the full bundled pair: the
+    integer-domain table form of the patch term -- with fused accumulation, row-wise sums and the refine's weight as one exp2 of a summed
+    argument, i.e. what the tolerance kernels compute -- changes most bits of the PatchMatch cost plane and NOT ONE match; the final flow
+    stays three orders of magnitude inside north_star's 1e-3 px.  The same substitution in the smoothing alone moves ~88 % of the pixels
+    (mean ~5e-4 px): the smoothed mean of equal integer flows sits on the next level's truncation boundary, which is why the tolerance
+    library keeps the smoothing exact.  The oracle variants are test infrastructure; the parity oracle is the run with all of them off."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import tolerance_envelope as TE
+    a, b = frames
+    u0, v0, st0 = O.compute_flow(a, b, dump=True)
+    O.set_tol_variant(23, 3)                           # tables | fma | row sums | exp2 weights, in PatchMatch and the refine
+    try:
+        u1, v1, st1 = O.compute_flow(a, b, dump=True)
+    finally:
+        O.set_tol_variant()
+    c0, c1 = st0["cost1_pm"], st1["cost1_pm"]
+    assert (c0 != c1).mean() > 0.5                                     # a different arithmetic: most cost bits differ ...
+    assert np.abs(c1 - c0).max() <= 1e-5 * np.abs(c0).max()
+    assert np.array_equal(st0["nnf1_pm"], st1["nnf1_pm"]) and np.array_equal(st0["nnf2_pm"], st1["nnf2_pm"])      # ... and no decision does
+    e = TE.epe_stats(u1, v1, u0, v0)
+    assert e["mean_epe_px"] <= 1e-4 and e["frac_over_1px"] == 0.0, e
+    O.set_tol_variant(1, 4)                            # the same tables in the smoothing only
+    try:
+        u2, v2 = O.compute_flow(a, b)
+    finally:
+        O.set_tol_variant()
+    s = TE.epe_stats(u2, v2, u0, v0)
+    assert s["frac_differing"] > 0.5 and 1e-4 < s["mean_epe_px"] < 1e-3, s
+    u3, v3 = O.compute_flow(a, b)                      # the switch is back at the lockstep reading
+    eq(u3, u0, "u after the variants")
+    eq(v3, v0, "v after the variants")

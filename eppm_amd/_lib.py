@@ -40,7 +40,7 @@ SYMBOLS = [
 
 
 # what include/eppm_test.h adds, exported by libeppm_hip_test.so only (the parity tests' switches and arithmetic probes)
-TEST_SYMBOLS = ["eppm_test_set_option", "eppm_probe_c2f_window", "eppm_probe_fast_exp", "eppm_probe_div_const"]
+TEST_SYMBOLS = ["eppm_test_set_option", "eppm_probe_c2f_window", "eppm_probe_fast_exp", "eppm_probe_div_const", "eppm_probe_delta_table"]
 
 _variant = None
 

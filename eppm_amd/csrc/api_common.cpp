@@ -96,3 +96,77 @@ int upload_lut(float** dst, const std::vector<float>& v)
     HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
     return EPPM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// DeltaTab (eppm_device.cuh): f(d) by table for d = the L-inf distance of two unorm8 texels
+// ---------------------------------------------------------------------------------------------------
+const DeltaIndex& delta_index()
+{
+    static DeltaIndex D;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        float g[256];
+        for (int k = 0; k < 256; k++) g[k] = (float)k / 255.0f;            // unorm8 (cudaReadModeNormalizedFloat)
+        uint32_t lo[256], hi[256];
+        for (int k = 0; k < 256; k++) { lo[k] = 0xffffffffu; hi[k] = 0u; }
+        for (int a = 0; a < 256; a++)
+            for (int b = 0; b < 256; b++) {
+                const float d = fabsf(g[a] - g[b]);
+                uint32_t bits;
+                memcpy(&bits, &d, 4);
+                const int kd = abs(a - b);
+                if (bits < lo[kd]) lo[kd] = bits;
+                if (bits > hi[kd]) hi[kd] = bits;
+            }
+        uint32_t off = 0;
+        for (int kd = 0; kd < 256; kd++) {
+            D.t1[kd] = (int32_t)(off * 4u - (lo[kd] << 2));                  // entry of d: (bits(d) << 2) + t1[kd], modulo 2^32
+            for (uint32_t bits = lo[kd]; bits <= hi[kd]; bits++) {
+                float d;
+                memcpy(&d, &bits, 4);
+                D.dval.push_back(d);
+            }
+            off += hi[kd] - lo[kd] + 1;
+        }
+    });
+    return D;
+}
+
+int upload_lut_delta(float** dst, const std::vector<float>& head, int which)
+{
+    const DeltaIndex& D = delta_index();
+    if ((int)D.dval.size() > kDeltaSlots) return set_err(EPPM_ERR_STATE, "delta table needs %zu slots, the kernels hold %d", D.dval.size(), kDeltaSlots);
+    std::vector<float> v(head);
+    v.resize(head.size() + 256 + kDeltaSlots, 0.0f);
+    memcpy(&v[head.size()], D.t1, sizeof(D.t1));
+    memcpy(&v[head.size() + 256], D.dval.data(), D.dval.size() * sizeof(float));
+    CHK(upload_lut(dst, v));
+    launch_delta_values(*dst + head.size() + 256, (int)D.dval.size(), which, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return EPPM_OK;
+}
+
+// the three look-up tables as the kernels read them
+int upload_pm_lut(float** dst, int R)
+{
+    std::vector<float> v;
+    host_pm_lut(R, v);
+#ifdef EPPM_TOL
+    return upload_lut(dst, v);                  // gs, cn, td, ta: the tolerance library's patch term reads no DeltaTab
+#else
+    return upload_lut_delta(dst, v, 0);         // gs, cn, then 1 - exp(-d^2 / LAMBDA_AD^2) by table
+#endif
+}
+int upload_wmf_lut(float** dst)
+{
+    std::vector<float> v;
+    host_wmf_lut(v);
+    return upload_lut_delta(dst, v, 1);         // g[0..4], then exp(-d^2 / WMF_SIG_R^2) by table
+}
+int upload_blf_lut(float** dst)
+{
+    std::vector<float> v;
+    host_blf_lut(v);
+    return upload_lut_delta(dst, v, 1);         // g[0..10], then exp(-d^2 / POSTPROC_BLF_SIG_R^2) by table (the same constant)
+}

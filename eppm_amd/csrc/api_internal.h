@@ -58,6 +58,15 @@ EPPM_HIDDEN void host_wmf_lut(std::vector<float>& v);
 EPPM_HIDDEN void host_blf_lut(std::vector<float>& v);
 EPPM_HIDDEN int pyr_init_dim(int* arrH, int* arrW, int h, int w, int maxDepth, double ratio);
 EPPM_HIDDEN int upload_lut(float** dst, const std::vector<float>& v);
+// the two-level index of eppm_device.cuh: DeltaTab over the 598 distinct L-inf distances of unorm8 texels: t1[kd] and, per slot of t2, the
+// distance it stands for (gaps between the members of a group repeat a neighbour); built once, checked exhaustively
+struct DeltaIndex { int32_t t1[256]; std::vector<float> dval; };
+EPPM_HIDDEN const DeltaIndex& delta_index();
+// `head` followed by a DeltaTab whose values the device computes with the formula they replace (which: see launch_delta_values)
+EPPM_HIDDEN int upload_lut_delta(float** dst, const std::vector<float>& head, int which);
+EPPM_HIDDEN int upload_pm_lut(float** dst, int R);        // gs[0..R], cn[0..8], then the library's term tables (exact: DeltaTab; tolerance: td, ta)
+EPPM_HIDDEN int upload_wmf_lut(float** dst);              // g[0..WMF_RADIUS], DeltaTab of the range weight
+EPPM_HIDDEN int upload_blf_lut(float** dst);              // g[0..2*POSTPROC_BLF_SIG_S], DeltaTab of the range weight
 
 // ---- kernel-variant switches of the parity tests ----
 // The product library has none: the functions below are constants.  libeppm_hip_test.so (the same objects, with the translation units

@@ -150,10 +150,9 @@ static int shared_luts(int device, int R, float** pm, float** wmf, float** blf)
     for (const Entry& e : tab)
         if (e.device == device && e.R == R) { *pm = e.pm; *wmf = e.wmf; *blf = e.blf; return EPPM_OK; }
     Entry e{device, R, nullptr, nullptr, nullptr};
-    std::vector<float> v;
-    host_pm_lut(R, v);  CHK(upload_lut(&e.pm, v));
-    host_wmf_lut(v);    CHK(upload_lut(&e.wmf, v));
-    host_blf_lut(v);    CHK(upload_lut(&e.blf, v));
+    CHK(upload_pm_lut(&e.pm, R));
+    CHK(upload_wmf_lut(&e.wmf));
+    CHK(upload_blf_lut(&e.blf));
     tab.push_back(e);
     *pm = e.pm; *wmf = e.wmf; *blf = e.blf;
     return EPPM_OK;

@@ -158,6 +158,39 @@ __device__ __forceinline__ float4 make_texel(uint32_t rgba, uint32_t census)
 }
 #endif
 __device__ __forceinline__ float one_minus_fast_exp(float x) { return 1 - fast_exp(x); }
+
+// ---- f(d) for d = the L-inf distance of two unorm8 texels, by table: bit-identical to evaluating f ------------------------------
+// A channel is fl(k/255), so such a distance is |fl(a/255) - fl(b/255)| for two bytes a, b: one of only 598 distinct floats, and
+// any function of it -- 1 - exp(-d^2/s) of the patch term, exp(-d^2/s') of the smoothing and weighted-median weights -- has at most 598
+// values.  The table holds exactly what the formula returns for each of them (filled on the device BY that formula, k_delta_values,
+// once per device), so reading it is the same bits for 12 issue cycles instead of 34 (mul, exact division, exp polynomial, ldexp).
+// Two levels: kd = |a - b| = trunc(fma(d, 1020, 2)) / 4 names a group of neighbouring floats (the distances with the same byte
+// difference lie within 64 ulp of each other), t1[kd] = byte offset of the group in t2 minus 4 x the bits of its smallest member, so
+// the entry of d is at (bits(d) << 2) + t1[kd].  Built and checked exhaustively over the 65 536 byte pairs on the host
+// (api_common.cpp: delta_index; tests/test_abi_cpu.py::test_delta_index_covers_every_byte_pair).
+struct DeltaTab {
+    int t1[256];
+    float t2[kDeltaSlots];
+};
+#ifndef EPPM_DELTA_PATCH
+#define EPPM_DELTA_PATCH 1        // the patch data term by table (0: evaluate the formula)
+#endif
+#ifndef EPPM_DELTA_BLF
+#define EPPM_DELTA_BLF 1          // the smoothing / weighted-median range weight by table (0: evaluate the formula)
+#endif
+__device__ __forceinline__ float delta_lookup(const DeltaTab& D, float d)
+{
+    const uint32_t o1 = (uint32_t)__builtin_fmaf(d, 1020.0f, 2.0f) & ~3u;                   // 4 * kd: v_fma, v_cvt_u32, v_and
+    const int w = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(D.t1) + o1);
+    const uint32_t o2 = (__float_as_uint(d) << 2) + (uint32_t)w;                             // v_lshl_add_u32
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(D.t2) + o2);
+}
+// global layout behind a look-up table's own entries: t1[256] (int bits), then t2[kDeltaSlots]
+__device__ __forceinline__ void load_delta_tab(DeltaTab& D, const float* __restrict__ src, int tid, int nthreads)
+{
+    for (int t = tid; t < 256; t += nthreads) D.t1[t] = __float_as_int(src[t]);
+    for (int t = tid; t < kDeltaSlots; t += nthreads) D.t2[t] = src[256 + t];
+}
 __device__ __forceinline__ rgbf texel_rgb(const float4 t) { return rgbf{t.x, t.y, t.z}; }
 
 __device__ __forceinline__ float4 tex_px(const float4* img, int pitch, int w, int h, int x, int y)
@@ -194,13 +227,16 @@ __device__ __forceinline__ uint32_t tex_rgba(const uint32_t* img, int pitch, int
 // ---- one sample of the patch cost (bao_pmflow_kernel.cu:275-295), both texels already fetched ------
 // gsp = gs[|j|]*gs[|i|] (the product is formed first in the reference too: "weight *= a*b").
 #ifndef EPPM_TOL
+struct ExactTables { const float* cnx; const DeltaTab& D; };      // what PatchLutT::tab() hands to the term: both tables live in LDS
 __device__ __forceinline__ void patch_terms(const float4 q1, const float4 q2, const rgbf c1, const rgbf c2, float gsp,
-                                            const float* __restrict__ cnx, float& cost_term, float& weight_term)
+                                            const ExactTables T, float& cost_term, float& weight_term)
 {
+    const float* __restrict__ cnx = T.cnx;
+    const DeltaTab& D = T.D;
     const rgbf p1 = texel_rgb(q1);
     const rgbf p2 = texel_rgb(q2);
     float cost = max_abs_diff(p1, p2);
-    cost = one_minus_fast_exp(div_ad2(-(cost * cost)));
+    cost = EPPM_DELTA_PATCH ? delta_lookup(D, cost) : one_minus_fast_exp(div_ad2(-(cost * cost)));     // the same bits either way
     cost += census_cost(cnx, __float_as_uint(q1.w), __float_as_uint(q2.w));
     float weight = max_abs_diff(c1, p1);
     weight *= weight;
@@ -300,7 +336,8 @@ struct PatchLutT {
 #ifndef EPPM_TOL
     float gsp[MAXS * MAXS];
     float cnx[256];
-    __device__ __forceinline__ const float* tab() const { return cnx; }
+    DeltaTab D;                       // 1 - exp(-d^2 / LAMBDA_AD^2) of the data term, by table (delta_lookup)
+    __device__ __forceinline__ ExactTables tab() const { return ExactTables{cnx, D}; }
 #else
     TolTables T;
     float gsp[MAXS * MAXS];
@@ -314,7 +351,7 @@ using PatchLut = PatchLutT<kMaxS>;     // any radius the ABI accepts; kernels in
 #define EPPM_LUT_ALIGN
 #endif
 
-// lut_src layout in global memory: gs[0..R] then cn[0..8]; tolerance library: then td[0..255] = 1 - exp(-(k/255)^2/s) and
+// lut_src layout in global memory: gs[0..R] then cn[0..8]; exact library: then the data term's DeltaTab; tolerance library: then td[0..255] = 1 - exp(-(k/255)^2/s) and
 // ta[0..255] = exp(-(k/255)^2/s), s = LAMBDA_AD^2 = PM_SIG_R^2, formed in double on the host (eppm_api.cpp: host_pm_lut)
 // LOG2 (tolerance library's refine kernels): gsp[] holds log2 of the products -- the weight there is ONE exp2 of a summed argument
 template <bool LOG2 = false, int MAXS>
@@ -329,6 +366,7 @@ __device__ __forceinline__ void load_patch_lut(PatchLutT<MAXS>& L, const float* 
     }
 #ifndef EPPM_TOL
     for (int t = tid; t < 256; t += nthreads) L.cnx[t] = lut_src[R + 1 + __builtin_popcount(t)];
+    load_delta_tab(L.D, lut_src + R + 10, tid, nthreads);
 #else
     for (int t = tid; t < 256; t += nthreads) { L.T.td[t] = lut_src[R + 10 + t]; L.T.ta[t] = lut_src[R + 10 + 256 + t]; }
     for (int t = tid; t < 16; t += nthreads) L.T.cn[t] = (t < 9) ? lut_src[R + 1 + t] : 0.0f;

@@ -17,6 +17,7 @@ constexpr int kBlock = 16;       // BLOCK_DIM_X/Y, bao_pmflow_kernel.cu:42-43
 constexpr int kMaxS = 32;        // samples per patch row: patch_r + 1 <= 32
 constexpr int kWmfRadius = 4;    // defs.h:58
 constexpr int kBlfRadius = 10;   // 2*POSTPROC_BLF_SIG_S, refine :753
+constexpr int kDeltaSlots = 800; // entries of eppm_device.cuh: DeltaTab::t2 (799 are used: api_common.cpp delta_index)
 
 // Batch of independent pairs processed by ONE launch: every device plane of pair k lives at the same offset inside
 // pair k's slab, and the slabs are `stride` bytes apart, so a kernel finds pair k's planes by adding k*stride to the
@@ -66,6 +67,8 @@ void launch_resize_rgba(uint32_t* out, int out_pitch_px, int outH, int outW, con
 // census plane and (optionally, texels != NULL) the float4 texel plane the patch kernels read
 void launch_census(uint8_t* census, int cpitch, void* texels, int tpitch, const uint32_t* img, int ipitch, int w, int h, hipStream_t s);
 void launch_pack(void* texels, int tpitch, const uint32_t* img, int ipitch, const uint8_t* census, int cpitch, int w, int h, hipStream_t s);
+// DeltaTab values (eppm_device.cuh): t2[i] = f(t2[i]) on the device, which = 0 patch data term, 1 smoothing / weighted-median weight
+void launch_delta_values(float* t2, int n, int which, hipStream_t s);
 void launch_rgb_to_rgba(uint32_t* out, int pitch_px, const uint8_t* rgb, int h, int w, hipStream_t s, Batch bt = kOnePair);
 
 // ---- PatchMatch (k_patchmatch.hip) ----
@@ -175,6 +178,7 @@ void launch_split_flow(float* uv, const float* flow, int n, hipStream_t s, Batch
 void launch_flow_to_color(uint32_t* rgba, const float* flow, int h, int w, float max_disp_x, float max_disp_y, hipStream_t s, Batch bt = kOnePair);
 
 // ---- probes (k_prepare.hip) ----
+void launch_probe_delta(const float* x, float* y, int n, const float* delta_tab, hipStream_t s);
 void launch_probe(const float* x, float* y, int n, int which, hipStream_t s);
 
 // ---- host XORWOW (xorwow_host.cpp) ----

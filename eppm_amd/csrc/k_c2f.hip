@@ -252,7 +252,7 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
                 patch_accum(cs[n], ws[n], cost, __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2[n], p2), lsrc)));
 #else
                 float cost = max_abs_diff(p1, p2);
-                cost = one_minus_fast_exp(div_ad2(-(cost * cost)));
+                cost = EPPM_DELTA_PATCH ? delta_lookup(L.D, cost) : one_minus_fast_exp(div_ad2(-(cost * cost)));      // the same bits either way (eppm_device.cuh: DeltaTab)
                 cost += census_cost(L.cnx, k1, __float_as_uint(q2[n].w));
                 float temp = max_abs_diff(c2[n], p2);
                 temp *= temp;
@@ -397,7 +397,11 @@ struct C2fWinGeom {
     static constexpr int yhi() { int v = R; const auto T = make_c2f_tables<R>(); for (int p = 0; p < 3; p++) for (int i = 0; i <= R; i++) v = T.rowdy[p][i] + 1 > v ? T.rowdy[p][i] + 1 : v; return v; }
 };
 #ifndef EPPM_C2F_WIN_H
+#ifdef EPPM_TOL
 #define EPPM_C2F_WIN_H 50
+#else
+#define EPPM_C2F_WIN_H 48      // the data term's table (4.2 KB, eppm_device.cuh: DeltaTab) and two workgroups per CU: 48 window rows (admissible spread 21)
+#endif
 #endif
 #ifndef EPPM_C2F_PASS2
 #define EPPM_C2F_PASS2 1
@@ -461,7 +465,7 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
                 {
                     const rgbf p2 = texel_rgb(qa[n]);
                     float cost = max_abs_diff(p1, p2);
-                    cost = one_minus_fast_exp(div_ad2(-(cost * cost)));
+                    cost = EPPM_DELTA_PATCH ? delta_lookup(L.D, cost) : one_minus_fast_exp(div_ad2(-(cost * cost)));
                     cost += census_cost(L.cnx, k1, __float_as_uint(qa[n].w));
                     float temp = max_abs_diff(c2[n], p2);
                     temp *= temp;
@@ -474,7 +478,7 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
                 {
                     const rgbf p2 = texel_rgb(qb[n]);
                     float cost = max_abs_diff(p1, p2);
-                    cost = one_minus_fast_exp(div_ad2(-(cost * cost)));
+                    cost = EPPM_DELTA_PATCH ? delta_lookup(L.D, cost) : one_minus_fast_exp(div_ad2(-(cost * cost)));
                     cost += census_cost(L.cnx, k1, __float_as_uint(qb[n].w));
                     float temp = max_abs_diff(c2[n], p2);
                     temp *= temp;
@@ -902,9 +906,11 @@ __global__ __launch_bounds__(256) void k_flow_blf(float* __restrict__ out_, cons
     __shared__ float4 s_t[BTH * BTW];          // r, g, b (unorm), flow x
     __shared__ float s_fy[BTH * BTW];
     __shared__ float s_lut[BR + 1];
+    __shared__ DeltaTab s_D;                   // exp(-d^2 / POSTPROC_BLF_SIG_R^2) by table: the same bits as the formula (eppm_device.cuh)
     const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
     const int tid = threadIdx.y * BT_W + threadIdx.x;
     if (tid <= BR) s_lut[tid] = blf_lut[tid];
+    load_delta_tab(s_D, blf_lut + BR + 1, tid, 256);
     for (int t = tid; t < BTW * BTH; t += 256) {
         const int cy = y0 + t / BTW - BR, cx = x0 + t % BTW - BR;
         float4 e = make_float4(100.0f, 0.0f, 0.0f, 0.0f);
@@ -940,8 +946,9 @@ EPPM_UNROLL(EPPM_BLF_UNROLL)
             const rgbf pix = {tp.x, tp.y, tp.z};
             const float gx = s_lut[abs(dx - BR)];
             if (use_a) {
-                const float delta_r = max_abs_diff(ca, pix);
-                const float coef_r = fast_exp(div_wmf2(-(delta_r * delta_r)));
+                // (a skipped tap, r = 100, meets the entry of d = 1: exp(-2500) = 0 exactly, as the formula gives for d ~ 100)
+                const float delta_r = EPPM_DELTA_BLF ? fminf(max_abs_diff(ca, pix), 1.0f) : max_abs_diff(ca, pix);
+                const float coef_r = EPPM_DELTA_BLF ? delta_lookup(s_D, delta_r) : fast_exp(div_wmf2(-(delta_r * delta_r)));
                 const float coef_s = gx * gya;
                 const float wgt = coef_r * coef_s;
                 nxa += wgt * tp.w;
@@ -949,8 +956,8 @@ EPPM_UNROLL(EPPM_BLF_UNROLL)
                 wa += wgt;
             }
             if (use_b) {
-                const float delta_r = max_abs_diff(cb, pix);
-                const float coef_r = fast_exp(div_wmf2(-(delta_r * delta_r)));
+                const float delta_r = EPPM_DELTA_BLF ? fminf(max_abs_diff(cb, pix), 1.0f) : max_abs_diff(cb, pix);
+                const float coef_r = EPPM_DELTA_BLF ? delta_lookup(s_D, delta_r) : fast_exp(div_wmf2(-(delta_r * delta_r)));
                 const float coef_s = gx * gyb;
                 const float wgt = coef_r * coef_s;
                 nxb += wgt * tp.w;

@@ -146,10 +146,13 @@ __global__ __launch_bounds__(256) void k_wmf_iter(int16_t* __restrict__ nnf_out_
     // The remaining launches do nothing (their output count stays 0).
     if (only_occ && changed_prev && *changed_prev == 0u) return;
     __shared__ float s_lut[WR + 1];
+    __shared__ DeltaTab s_D;              // exp(-d^2 / WMF_SIG_R^2) by table: the same bits as the formula (eppm_device.cuh)
     __shared__ float4 s_tap[4][WN];       // {bilateral weight, flow x, flow y, -} of the valid taps, row-major order
     __shared__ uint32_t s_keep[kWmfBatch], s_nkeep, s_base;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     if (tid <= WR) s_lut[tid] = wmf_lut[tid];
+    load_delta_tab(s_D, wmf_lut + WR + 1, tid, blockDim.x);
+    __syncthreads();
     // A workgroup owns a contiguous chunk of the list and works through it in batches; the entries that stay on
     // the list are collected in LDS and appended with ONE global atomic per batch (one returning atomic per
     // item on the single counter made the first launches atomic-bound: 17 k items took 208 us).
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void k_wmf_iter(int16_t* __restrict__ nnf_out_
                             fy = (int)(int16_t)(dy - cy);
                             const rgbf pix = unpack_rgb(img[cy * ipitch + cx]);
                             const float delta_r = max_abs_diff(center, pix);
-                            const float coef_r = fast_exp(div_wmf2(-(delta_r * delta_r)));
+                            const float coef_r = EPPM_DELTA_BLF ? delta_lookup(s_D, delta_r) : fast_exp(div_wmf2(-(delta_r * delta_r)));     // the same bits either way
                             const float coef_s = s_lut[abs(dx2)] * s_lut[abs(dy2)];
                             wgt = coef_r * coef_s;                  // refine :198-204
                         }

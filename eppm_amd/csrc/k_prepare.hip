@@ -283,6 +283,20 @@ void launch_pack(void* texels, int tpitch, const uint32_t* img, int ipitch, cons
     hipLaunchKernelGGL(k_pack, grid, block, 0, s, (float4*)texels, tpitch, img, ipitch, census, cpitch, w, h);
 }
 
+// The values of a DeltaTab (eppm_device.cuh), computed BY the formula they replace, in place: t2[i] holds a distance d on entry and f(d)
+// on return.  which = 0: the patch term's 1 - exp(-d^2 / LAMBDA_AD^2); 1: the smoothing / weighted-median weight exp(-d^2 / SIG_R^2).
+__global__ __launch_bounds__(256) void k_delta_values(float* __restrict__ t2, int n, int which)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float d = t2[i];
+    t2[i] = (which == 0) ? one_minus_fast_exp(div_ad2(-(d * d))) : fast_exp(div_wmf2(-(d * d)));
+}
+void launch_delta_values(float* t2, int n, int which, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_delta_values, dim3((n + 255) / 256), dim3(256), 0, s, t2, n, which);
+}
+
 // column-parity planes of a 4-byte texel plane (eppm_internal.h: PlanesH::pp1): word [p][y][i] = pc[y][clamp(2i + p - pad, 0, w - 1)]
 __global__ __launch_bounds__(256) void k_parity_planes(uint32_t* __restrict__ pp_, int pp_pitch, int pad, const uint32_t* __restrict__ pc_,
                                                        int pc_pitch, int w, int h, size_t pstride)

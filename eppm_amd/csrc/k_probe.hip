@@ -21,6 +21,19 @@ __global__ void k_probe(const float* __restrict__ x, float* __restrict__ y, int 
     else r = unorm8(v);
     y[i] = r;
 }
+// y[i] = delta_lookup(the DeltaTab at `tab`, x[i]): the table form of a range term against the formula it stands for
+__global__ __launch_bounds__(256) void k_probe_delta(const float* __restrict__ x, float* __restrict__ y, int n, const float* __restrict__ tab)
+{
+    __shared__ DeltaTab s_D;
+    load_delta_tab(s_D, tab, threadIdx.x, 256);
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = delta_lookup(s_D, x[i]);
+}
+void launch_probe_delta(const float* x, float* y, int n, const float* tab, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_probe_delta, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n, tab);
+}
 void launch_probe(const float* x, float* y, int n, int which, hipStream_t s)
 {
     hipLaunchKernelGGL(k_probe, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n, which);

@@ -30,13 +30,11 @@ int dev_state(DevState** out)
     DevState& s = g_dev[d];
     if (s.lut_R != g_prm.patch_r) {
         (void)hipFree(s.lut_pm); s.lut_pm = nullptr;
-        std::vector<float> v;
-        host_pm_lut(g_prm.patch_r, v);
-        CHK(upload_lut(&s.lut_pm, v));
+        CHK(upload_pm_lut(&s.lut_pm, g_prm.patch_r));
         s.lut_R = g_prm.patch_r;
     }
-    if (!s.lut_wmf) { std::vector<float> v; host_wmf_lut(v); CHK(upload_lut(&s.lut_wmf, v)); }
-    if (!s.lut_blf) { std::vector<float> v; host_blf_lut(v); CHK(upload_lut(&s.lut_blf, v)); }
+    if (!s.lut_wmf) CHK(upload_wmf_lut(&s.lut_wmf));
+    if (!s.lut_blf) CHK(upload_blf_lut(&s.lut_blf));
     *out = &s;
     return EPPM_OK;
 }

@@ -80,6 +80,14 @@ def probe_div_const(x, which):
     return y
 
 
+def probe_delta_table(d, which):
+    """the table form of a range term at the distances d (test library; include/eppm_test.h)"""
+    x = np.ascontiguousarray(d, np.float32)
+    y = np.empty_like(x)
+    check(lib().eppm_probe_delta_table(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size, which), "probe_delta_table")
+    return y
+
+
 def gauss_filter_rgba(img, sigma, radius):
     h, w = img.shape
     a, b = Dev(img, pitched=True), Dev(shape=(h, w), dtype=uchar4, pitched=True)

@@ -33,6 +33,10 @@ int  eppm_probe_c2f_window(int patch_r, int* span_x, int* span_y);
 /* device-side arithmetic probes (parity of the shared float formulas): y[i] = f(x[i]) for n host floats */
 int  eppm_probe_fast_exp(const float* x, float* y, int n);
 int  eppm_probe_div_const(const float* x, float* y, int n, int which); /* 0: /(.1f*.1f) 1: /(.02f*.02f) 2: unorm8 (x = 0..255) */
+/* the range terms that are read from a table of the 598 possible L-inf distances of unorm8 texels instead of being evaluated
+ * (eppm_device.cuh: DeltaTab): y[i] = table(x[i]); which = 0: 1 - exp(-d^2/(.1f*.1f)) of the patch data term, 1: exp(-d^2/(.02f*.02f)) of
+ * the smoothing and weighted-median weights.  x must be such distances (|a/255 - b/255| of two bytes, as floats). */
+int  eppm_probe_delta_table(const float* x, float* y, int n, int which);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,22 @@ def test_div_const_bits(S):
     eq(S.probe_div_const(c, 2), (c / np.float32(255)).astype(np.float32), "unorm8")
 
 
+def test_range_terms_by_table_equal_the_formula_for_every_byte_pair(S, O):
+    """The patch data term 1 - exp(-d^2 / LAMBDA_AD^2) and the smoothing / weighted-median weight exp(-d^2 / SIG_R^2) are READ from a table
+    of the possible L-inf distances of unorm8 texels (eppm_device.cuh: DeltaTab; 598 distinct floats over the 65 536 byte pairs) instead of
+    being evaluated.  For every byte pair the table must return the bits the oracle's formula returns."""
+    g = (np.arange(256, dtype=np.float32) / np.float32(255)).astype(np.float32)
+    a, b = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    d = np.abs(g[a] - g[b]).astype(np.float32).reshape(-1)
+    assert len(np.unique(d)) == 598
+    uniq, inv = np.unique(d, return_inverse=True)
+    for which, s in ((0, np.float32(0.1) * np.float32(0.1)), (1, np.float32(0.02) * np.float32(0.02))):
+        arg = (-(uniq * uniq) / s).astype(np.float32)                      # IEEE float32, as the oracle forms it
+        e = O.fast_exp(arg)
+        want = ((np.float32(1) - e) if which == 0 else e).astype(np.float32)[inv]
+        eq(S.probe_delta_table(d, which), want, f"range term {which} by table")
+
+
 def test_prepare_stages(S, O, crop):
     raw = O.rgb2rgba(crop[0])
     eq(S.gauss_filter_rgba(raw, 0.5, 2), O.gauss_filter_rgba(raw, 0.5, 2), "gauss s=.5 r=2")

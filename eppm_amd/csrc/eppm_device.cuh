@@ -125,14 +125,17 @@ struct Planes {
 // The census byte is stored shifted left by 2, so that w1 ^ w2 is the byte offset of entry (c1 ^ c2) in a
 // 256-entry table cnx[b] = cn[popcount(b)]: xor + LDS read + add (4 VALU cycles fewer per sample than
 // xor + v_bcnt (half rate) + the 9-entry table).
+#ifndef EPPM_CENSUS_POPCNT
+#define EPPM_CENSUS_POPCNT 1      // 1: the census byte replicated into its word, cn[hamming] by popcount (9 entries, conflict free) instead of cnx[xor]
+#endif
 __device__ __forceinline__ float4 make_texel(uint32_t rgba, uint32_t census)
 {
     const rgbf c = unpack_rgb(rgba);
-    return make_float4(c.x, c.y, c.z, __uint_as_float((census & 0xffu) << 2));
+    return make_float4(c.x, c.y, c.z, __uint_as_float(EPPM_CENSUS_POPCNT ? (census & 0xffu) * 0x01010101u : (census & 0xffu) << 2));
 }
 __device__ __forceinline__ float census_cost(const float* __restrict__ cnx, uint32_t w1, uint32_t w2)
 {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cnx) + (w1 ^ w2));
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(cnx) + (EPPM_CENSUS_POPCNT ? (uint32_t)__builtin_popcount(w1 ^ w2) : (w1 ^ w2)));
 }
 #else
 // ---- the tolerance library (libeppm_hip_tol.so, -DEPPM_TOL) ------------------------------------------------
@@ -335,7 +338,7 @@ template <int MAXS>
 struct PatchLutT {
 #ifndef EPPM_TOL
     float gsp[MAXS * MAXS];
-    float cnx[256];
+    float cnx[EPPM_CENSUS_POPCNT ? 16 : 256];
     DeltaTab D;                       // 1 - exp(-d^2 / LAMBDA_AD^2) of the data term, by table (delta_lookup)
     __device__ __forceinline__ ExactTables tab() const { return ExactTables{cnx, D}; }
 #else
@@ -365,7 +368,8 @@ __device__ __forceinline__ void load_patch_lut(PatchLutT<MAXS>& L, const float* 
         L.gsp[i * S + j] = LOG2 ? log2f(g) : g;
     }
 #ifndef EPPM_TOL
-    for (int t = tid; t < 256; t += nthreads) L.cnx[t] = lut_src[R + 1 + __builtin_popcount(t)];
+    if (EPPM_CENSUS_POPCNT) { for (int t = tid; t < 16; t += nthreads) L.cnx[t] = (t < 9) ? lut_src[R + 1 + t] : 0.0f; }
+    else for (int t = tid; t < 256; t += nthreads) L.cnx[t] = lut_src[R + 1 + __builtin_popcount(t)];
     load_delta_tab(L.D, lut_src + R + 10, tid, nthreads);
 #else
     for (int t = tid; t < 256; t += nthreads) { L.T.td[t] = lut_src[R + 10 + t]; L.T.ta[t] = lut_src[R + 10 + 256 + t]; }

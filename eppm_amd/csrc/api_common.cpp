@@ -63,7 +63,7 @@ void host_pm_lut(int R, std::vector<float>& v)
     for (int k = 0; k < 256; k++) {
         const double d = double(k) / 255.0, e = exp(-(d * d) / s);
         v[R + 10 + k] = float(1.0 - e);
-        v[R + 10 + 256 + k] = float(e);
+        v[R + 10 + 256 + k] = float(e * 16777216.0);          // 2^24 per factor of a weight (eppm_device.cuh: kTolWeightBias): exp(-100) stays a normal float
     }
 #endif
 }

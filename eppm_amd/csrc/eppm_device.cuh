@@ -277,6 +277,11 @@ __device__ __forceinline__ float tol_cost(const TolTables& T, const rgbf p1, con
 // exp2(lsrc - c k^2) by the hardware v_exp_f32, for an L-inf distance given as its byte offset 4k; c = log2(e) / (255^2 s).  Results
 // below 2^-126 are 0 (the instruction flushes; the exact library keeps them down to 2^-150).
 constexpr float kTolExpC = (float)(1.4426950408889634 / (255.0 * 255.0 * (double)kPmSigR2) / (double)(kTolScale * kTolScale));
+// Every weight of a patch may carry a common factor: it cancels in cost_sum / weight_sum.  The refine's exp2 argument starts at +24
+// (load_patch_lut<true>: log2(gs_j gs_i) + kTolWeightBias): v_exp_f32 flushes results below 2^-126, so the weights that vanish are those
+// below 2^-150 -- exactly the ones the exact formula rounds to 0 -- and everything above keeps full precision (the exact library's own
+// weights between 2^-150 and 2^-126 are denormals with 1-23 bits).  The PatchMatch tables carry 2^24 per factor for the same reason.
+constexpr float kTolWeightBias = 24.0f;
 __device__ __forceinline__ float tol_exp_arg(uint32_t off4k, float lsrc)
 {
     // the integer 4k as a float: its bit pattern is the denormal 4k * 2^-149, and one full-rate multiplication by 2^100 makes it the
@@ -304,16 +309,9 @@ __device__ __forceinline__ void patch_terms(const float4 q1, const float4 q2, co
     const rgbf p1 = texel_rgb(q1);
     const rgbf p2 = texel_rgb(q2);
     cost_term = tol_cost(T, p1, p2, __float_as_uint(q1.w), __float_as_uint(q2.w));
-#ifndef EPPM_TOL_PM_WEIGHT
-#define EPPM_TOL_PM_WEIGHT 0
-#endif
-#if EPPM_TOL_PM_WEIGHT == 0            // two table reads (LDS: ~5 cycles each with their bank conflicts)
+    // ta[] holds 2^24 * exp(-(k/255)^2/s) (kTolWeightBias per factor): weights down to exp(-100) -- a saturated edge -- stay normal floats
+    // with full precision where the unscaled product would be a denormal with a few bits; the common factor 2^48 cancels in cost / weight.
     weight_term = (tol_at(T.ta, linf_off(c1, p1)) * gsp) * tol_at(T.ta, linf_off(c2, p2));
-#elif EPPM_TOL_PM_WEIGHT == 1          // source half from the table, target half by the hardware exp2
-    weight_term = (tol_at(T.ta, linf_off(c1, p1)) * gsp) * __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2, p2), 0.0f));
-#else                                  // one hardware exp2 of the summed argument
-    weight_term = gsp * __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2, p2), tol_exp_arg(linf_off(c1, p1), 0.0f)));
-#endif
 }
 __device__ __forceinline__ void patch_accum(float& cost_sum, float& weight_sum, float cost_term, float weight_term)
 {
@@ -365,7 +363,11 @@ __device__ __forceinline__ void load_patch_lut(PatchLutT<MAXS>& L, const float* 
         const int i = t / S, j = t % S;
         const int ai = abs(2 * i - R), aj = abs(2 * j - R);
         const float g = lut_src[aj] * lut_src[ai];
+#ifdef EPPM_TOL
+        L.gsp[i * S + j] = LOG2 ? log2f(g) + kTolWeightBias : g;
+#else
         L.gsp[i * S + j] = LOG2 ? log2f(g) : g;
+#endif
     }
 #ifndef EPPM_TOL
     if (EPPM_CENSUS_POPCNT) { for (int t = tid; t < 16; t += nthreads) L.cnx[t] = (t < 9) ? lut_src[R + 1 + t] : 0.0f; }

@@ -291,26 +291,6 @@ __device__ __forceinline__ float dpp_prev_lane(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
-// The sums of the lanes' chunks.  Exact library: the two running sums hop lane to lane while every lane adds its chunk -- the
-// reference's order of additions; the complete sums end in lane NL - 1 of the group.  Tolerance library (the order of the additions is
-// free): every lane sums its own chunk, then log2(LPC) DPP / swizzle steps add the lanes of the group; every lane of the group ends
-// with the complete sums.
-template <int LPC>
-__device__ __forceinline__ float dpp_group_sum(float v)
-{
-    static_assert(LPC == 4 || LPC == 16 || LPC == 32 || LPC == 64, "lanes per group");
-    // quad_perm [1,0,3,2], [2,3,0,1]: the sum of each quad in all four lanes
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));
-    if (LPC >= 16) {
-        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
-        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
-    }
-    if (LPC >= 32) v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401f /* xor 16: the other row of the 32-lane half */));
-    if (LPC >= 64) v += __shfl_xor(v, 32, 64);
-    return v;
-}
-
 // One patch evaluation spread over the LPC lanes of a DPP row (16) or of a whole wave (64), for kernels whose source samples lie in
 // the (kBlock + 2 RT)^2 LDS tile of a 16x16 block: the S*S samples are dealt to the lanes in contiguous chunks, each lane forms the
 // terms of its chunk, and the two running sums hop lane to lane while every lane adds its chunk -- the reference's order of additions,
@@ -338,24 +318,22 @@ __device__ __forceinline__ float coop_patch_dist(const Planes& P, const LUT& L, 
         tc[k] = 0.0f; tw[k] = 0.0f;
         if (t0 + k < NS) patch_terms(s_src[so[k]], q2[k], c1, c2, L.gsp[t0 + k], L.tab(), tc[k], tw[k]);
     }
+    // The sums advance in the reference's sample order in BOTH libraries: the two running sums hop lane to lane while every lane adds
+    // its chunk (the tolerance library with fused multiply-adds, patch_accum).  A tolerance build with per-lane partial sums and a DPP
+    // tree was 8 % cheaper per evaluation and WRONG in a way only tie-heavy images show: the cost of a (pixel, candidate) pair must be the
+    // same bits whichever kernel evaluates it -- the search sums serially, a sweep cooperatively -- or equal-cost candidates of flat
+    // regions are accepted by one kernel and rejected by the other (mean EPE 0.34 px on a saturated-blocks fuzz case).
     float ac = 0.0f, aw = 0.0f;
-#ifdef EPPM_TOL
-#pragma unroll
-    for (int q = 0; q < CH; q++) patch_accum(ac, aw, tc[q], tw[q]);           // (a lane past the last sample holds zeros)
-    (void)NL;
-    return dpp_group_sum<LPC>(ac) / dpp_group_sum<LPC>(aw);
-#else
 #pragma unroll
     for (int ln = 0; ln < NL; ln++) {
         if (ln > 0) { ac = dpp_prev_lane<LPC>(ac); aw = dpp_prev_lane<LPC>(aw); }
 #pragma unroll
         for (int q = 0; q < CH; q++) {
-            if (ln * CH + q < NS) { ac += tc[q]; aw += tw[q]; }
+            if (ln * CH + q < NS) patch_accum(ac, aw, tc[q], tw[q]);
         }
     }
     const int src = ((threadIdx.x & 63) / LPC) * LPC + (NL - 1);      // lane holding the complete sums (wave-relative)
     return __shfl(ac, src, 64) / __shfl(aw, src, 64);
-#endif
 }
 
 // LPC = lanes per chain (16, 32 or 64)
@@ -599,27 +577,20 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
                     }
                 }
             }
+            // sequential sums in sample order: lane 0's chunk first, then the partial sums move one lane right (both libraries: see coop_patch_dist)
             float ac = 0.0f, aw = 0.0f;
-#ifdef EPPM_TOL
-            // free summation order: every lane its own chunk, then the lanes of the chain (dpp_group_sum)
-#pragma unroll
-            for (int q = 0; q < CH; q++) patch_accum(ac, aw, tc[q], tw[q]);
-            cv = dpp_group_sum<LPC>(ac) / dpp_group_sum<LPC>(aw);
-#else
-            // sequential sums in sample order: lane 0's chunk first, then the partial sums move one lane right
             constexpr int NL = (NS + CH - 1) / CH;       // lanes that own samples
 #pragma unroll
             for (int ln = 0; ln < NL; ln++) {
                 if (ln > 0) { ac = dpp_prev_lane<LPC>(ac); aw = dpp_prev_lane<LPC>(aw); }
 #pragma unroll
                 for (int q = 0; q < CH; q++) {
-                    if (ln * CH + q < NS) { ac += tc[q]; aw += tw[q]; }
+                    if (ln * CH + q < NS) patch_accum(ac, aw, tc[q], tw[q]);
                 }
             }
             const int src = ((threadIdx.x & 63) / LPC) * LPC + (NL - 1);   // lane holding the complete sums (wave-relative)
             const float cs = __shfl(ac, src, 64), ws = __shfl(aw, src, 64);
             cv = cs / ws;
-#endif
             if (!SPEC && ccand && r == 0) { ccand[cidx] = cpack; cval[cidx] = cv; }
             }
             if (cv < cur_best) {
@@ -1285,8 +1256,13 @@ void launch_pm_rand_table(const PmRngDev& rng, uint32_t* work, int16_t* tab, int
 // ROWS = 2 (numbers drawn ahead only): a workgroup covers an EIGHTH of the block (2 rows, 32 pixels; a wave = two guesses of them) -- for
 // launches of so few workgroups that their count per CU quantises badly (one 1024x436 pair: 872 quarter-workgroups on 256 CUs run as 4
 // per CU where 3.4 are needed; the kernel runs at its CU's L1 rate, so the launch lasts as long as the fullest CU).
+#ifdef EPPM_SEARCH_WAVES
+#define EPPM_SEARCH_OCC __attribute__((amdgpu_waves_per_eu(EPPM_SEARCH_WAVES, EPPM_SEARCH_WAVES)))
+#else
+#define EPPM_SEARCH_OCC
+#endif
 template <int RT, int PK = 0, bool TAB = false, int ROWS = 4>
-__global__ __launch_bounds__(576) void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
+__global__ __launch_bounds__(576) EPPM_SEARCH_OCC void k_pm_random_search(PmBatch B, PmRngDev rng, const float* __restrict__ lut, int R,
                                                           int search_range, int G)
 {
     static_assert(ROWS == 4 || (ROWS == 2 && TAB && RT != 0), "eighth-block workgroups read their numbers from the table");

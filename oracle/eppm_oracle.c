@@ -113,7 +113,7 @@ void orc_set_tol_variant(int mode, int scope)
     for (int k = 0; k < 256; k++) {
         const double d = (double)k / 255.0;
         g_tol_td[k] = (float)(1.0 - exp(-(d * d) / s));
-        g_tol_ta[k] = (float)exp(-(d * d) / s);
+        g_tol_ta[k] = (float)(exp(-(d * d) / s) * 16777216.0);     /* 2^24 per factor: the common scale cancels in cost_sum / weight_sum */
         g_tol_tw[k] = (float)exp(-(d * d) / (double)(WMF_SIG_R * WMF_SIG_R));      /* == POSTPROC_BLF_SIG_R^2 */
     }
 }
@@ -495,8 +495,9 @@ static inline void patch_sample_tol(const orc_uchar4* img1, const orc_uchar4* im
     if (g_tol_exp2_now) {
         const float c = (float)(1.4426950408889634 / (255.0 * 255.0 * (double)(LAMBDA_AD * LAMBDA_AD)));
         const float ka = (float)max_abs_diff_u8(center1, p1), kb = (float)max_abs_diff_u8(center2, p2);
-        const float lsrc = fmaf(-c, ka * ka, log2f(gs_j * gs_i));                 /* once per source sample on the GPU */
+        const float lsrc = fmaf(-c, ka * ka, log2f(gs_j * gs_i) + 24.0f);         /* once per source sample on the GPU; +24: common scale */
         weight = exp2f(fmaf(-c, kb * kb, lsrc));
+        if (weight < 0x1p-126f) weight = 0.0f;                                    /* v_exp_f32 flushes: what vanishes is what the exact formula rounds to 0 */
     } else {
         const float wa = g_tol_ta[max_abs_diff_u8(center1, p1)] * (gs_j * gs_i);      /* the source half, hoisted on the GPU */
         weight = wa * g_tol_ta[max_abs_diff_u8(center2, p2)];

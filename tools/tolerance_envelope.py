@@ -2,7 +2,7 @@
 """How far does the tolerance arithmetic of libeppm_hip_tol.so move the flow?  (CPU only; test infrastructure.)
 
 north_star allows floating-point work "within 1e-3 px EPE on the bundled Middlebury pair".  The tolerance library replaces the two
-software exp of the patch term by integer-domain tables and frees the summation order; this script runs the CPU oracle with the
+software exp of the patch term by integer-domain tables / one hardware exp2 and fuses its sums; this script runs the CPU oracle with the
 same substitutions (oracle/eppm_oracle.c: orc_set_tol_variant) and reports the end-point error of each against the lockstep
 oracle, per stage scope, so that a step which would leave the tolerance is known before a kernel is written.
 
@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # (name, mode, scope)
 VARIANTS = [("tables_pm", 1, 1), ("tables_refine", 1, 2), ("tables_smoothing", 1, 4),
-            ("tables_fma_pm_refine", 3, 3), ("tables_fma_rowsums_pm_refine", 7, 3), ("tables_pm_exp2_weights_refine", 23, 3), ("tables_fma_rowsums_all", 7, 7)]
+            ("tables_fma_pm_refine", 3, 3), ("tables_fma_rowsums_pm_refine", 7, 3), ("kernel_form_tables_fma_exp2_refine", 19, 3), ("tables_fma_rowsums_all", 7, 7)]
 
 
 def epe_stats(u, v, u0, v0):

@@ -1,5 +1,5 @@
 """End-point error of the tolerance library libeppm_hip_tol.so (integer-domain tables instead of the two software exp of the patch
-term, free summation order; NOT bit-identical) against the exact library -- which equals the CPU oracle bit for bit (tests/), so
+term, fused sums; NOT bit-identical) against the exact library -- which equals the CPU oracle bit for bit (tests/), so
 this is the EPE against the oracle at sizes the oracle cannot be re-run at on the GPU box.  Cases: the bundled frame10/frame11
 pair forwards (north_star's tolerance case: <= 1e-3 px mean EPE) and backwards, BASELINE configs[1] (1024x436), configs[3]
 (1920x1080), configs[4] (3840x2160, radius 17; only with --all) and the eight fixed-seed fuzz cases of tests/test_configs_gpu.py.
@@ -29,9 +29,13 @@ def cases(all_sizes):
     if all_sizes:
         out.append(("config5_3840x2160_r17", *synth.make_pair(2160, 3840, seed=1234, max_flow=60.0)[:2], dict(patch_r=17)))
     if "--no-fuzz" not in sys.argv:
+        # the fixed-seed fuzz cases of the parity suite, all eight kinds per seed: synthetic motion, unrelated noise, flat regions with
+        # saturated blocks (costs that tie exactly, weights that underflow), low contrast; odd sizes, radii 4 / 5 / 9 / 17, 1-4 iterations,
+        # 1-8 guesses, every propagation mode and pyramid depth
         for seed in T.FUZZ_SEEDS:
-            fa, fb, params = T._fuzz_case(seed, 0)
-            out.append((f"fuzz_seed{seed}", fa, fb, params))
+            for t in range(8):
+                fa, fb, params = T._fuzz_case(seed, t)
+                out.append((f"fuzz_seed{seed}_case{t}", fa, fb, params))
     return out
 
 

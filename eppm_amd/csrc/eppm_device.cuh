@@ -330,6 +330,28 @@ __device__ __forceinline__ void patch_sample(const Planes& P, const rgbf c1, con
     patch_terms(q1, q2, c1, c2, gsp, cnx, cost_term, weight_term);
 }
 
+// ---- the order in which a PatchMatch cost is summed --------------------------------------------------------------------------------
+// Exact library: the reference's, one chain over the S*S samples (i outer, j inner).  Tolerance library: the same row-major sample order
+// cut into CHUNKS -- half rows at radius 9 (5 samples), thirds of a row at radius 17 (6), halves in general --, each chunk summed from
+// zero by fused multiply-adds, the chunk sums added one after the other.  Every kernel forms exactly this sum: a lane that evaluates
+// alone closes a chunk every few samples (PatchSum::flush), a cooperative evaluation gives every lane one chunk and lets the total hop
+// lane to lane with ONE addition per hop (the exact library adds a whole chunk per hop on every lane: 16 x 16 instructions against
+// 20 x 4).  The cost of a (pixel, candidate) pair is thus the same bits whichever kernel evaluates it -- which strict "<" between
+// equal-cost candidates requires.
+__host__ __device__ constexpr int tol_chunk(int R) { return R == 17 ? 6 : (R + 2) / 2; }
+struct PatchSum {
+    float cs = 0.0f, ws = 0.0f;
+#ifdef EPPM_TOL
+    float cc = 0.0f, cw = 0.0f;
+    __device__ __forceinline__ void add(float cost_term, float weight_term) { patch_accum(cc, cw, cost_term, weight_term); }
+    __device__ __forceinline__ void flush() { cs += cc; ws += cw; cc = 0.0f; cw = 0.0f; }          // the end of a chunk
+#else
+    __device__ __forceinline__ void add(float cost_term, float weight_term) { patch_accum(cs, ws, cost_term, weight_term); }
+    __device__ __forceinline__ void flush() {}
+#endif
+    __device__ __forceinline__ float result() const { return cs / ws; }
+};
+
 // LUTs staged in LDS by every patch kernel: gsp[i*S + j] = gs[|2j-R|]*gs[|2i-R|], and the table(s) of the per-sample terms -- tab():
 // exact library cnx[b] = cn[popcount(b)]; tolerance library td[], ta[], cn[] (TolTables, FIRST: low LDS addresses)
 template <int MAXS>
@@ -387,12 +409,13 @@ __device__ __forceinline__ float patch_dist(const Planes& P, const PatchLut& L, 
     const int pitch16 = P.pitch << 4;
     const rgbf c1 = texel_rgb(texel_at(P.pk1, texel_off(pitch16, P.w, P.h, x1, y1)));
     const rgbf c2 = texel_rgb(texel_at(P.pk2, texel_off(pitch16, P.w, P.h, x2, y2)));
-    float cost_sum = 0.0f, weight_sum = 0.0f;
-    const int S = R + 1;
+    PatchSum sum;
+    const int S = R + 1, CS = tol_chunk(R);
     for (int ii = 0; ii < S; ii++) {
         const int i = 2 * ii - R;
         const unsigned r1 = __umul24((unsigned)iclamp(y1 + i, 0, P.h - 1), (unsigned)pitch16);
         const unsigned r2 = __umul24((unsigned)iclamp(y2 + i, 0, P.h - 1), (unsigned)pitch16);
+        int left = CS;                         // samples to the end of the chunk (a row starts a chunk)
         for (int j0 = 0; j0 < S; j0 += 5) {
             float4 q1[5], q2[5];
 #pragma unroll
@@ -406,12 +429,13 @@ __device__ __forceinline__ float patch_dist(const Planes& P, const PatchLut& L, 
                 if (j0 + k < S) {
                     float ct, wt;
                     patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.tab(), ct, wt);
-                    patch_accum(cost_sum, weight_sum, ct, wt);
+                    sum.add(ct, wt);
+                    if (--left == 0 || j0 + k == S - 1) { sum.flush(); left = CS; }
                 }
             }
         }
     }
-    return cost_sum / weight_sum;
+    return sum.result();
 }
 
 // plane-fitting coefficients: bao_pmflow_kernel.cu:319-332 (pass 0 = no warp)

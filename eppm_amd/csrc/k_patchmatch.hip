@@ -13,7 +13,11 @@
 #include "eppm_internal.h"
 
 #ifndef EPPM_LPC9
+#ifdef EPPM_TOL
+#define EPPM_LPC9 32      // tolerance library: a lane = a chunk of 5 samples (coop_chunk): 20 of 32 lanes work, whatever the launch size
+#else
 #define EPPM_LPC9 16      // lanes per sweep chain at patch radius 9 (100 samples); doubled for launches that cannot fill the chip, see launch_pm_sweep
+#endif
 #endif
 #ifndef EPPM_SWEEP_GB
 #define EPPM_SWEEP_GB 7   // sample gathers a sweep lane keeps in flight (per image)
@@ -21,6 +25,17 @@
 #ifndef EPPM_LPC17
 #define EPPM_LPC17 64     // ... at patch radius 17 (324 samples)
 #endif
+#ifndef EPPM_LPC9_SPEC
+#ifdef EPPM_TOL
+#define EPPM_LPC9_SPEC 32     // tolerance library: see EPPM_LPC9
+#else
+#define EPPM_LPC9_SPEC 16     // lanes per chain in phase B at radius 9 (4 were tried -- a quarter of the waves, one round of workgroups --
+#endif
+#endif                        // and lost: 50-56 vs 32-41 us per 8-pair launch, the evaluations after accepted candidates take four times as long)
+#ifndef EPPM_LPC17_SPEC
+#define EPPM_LPC17_SPEC 64    // ... at radius 17
+#endif
+
 
 namespace eppm {
 
@@ -154,7 +169,9 @@ __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L
     const int pitch16 = P.pitch << 4;
     const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
     const rgbf c2 = texel_rgb(texel_at(P.pk2, texel_off(pitch16, P.w, P.h, x2, y2)));
-    float cost_sum = 0.0f, weight_sum = 0.0f;
+    PatchSum sum;
+    constexpr int CS = tol_chunk(RT);          // tolerance library: chunk of the canonical summation order (PatchSum)
+    static_assert(S % CS == 0, "whole chunks per row");
 #ifdef EPPM_TOL
     if constexpr (PK == 2) {
         static_assert(S % 4 == 2, "a row = whole dwordx4 gathers + one dwordx2");
@@ -180,10 +197,11 @@ __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L
             for (int jj = 0; jj < S; jj++) {
                 float ct, wt;
                 patch_terms(srow[2 * jj], unpack_texel(wq[jj], two), c1, c2, L.gsp[ii * S + jj], L.tab(), ct, wt);
-                patch_accum(cost_sum, weight_sum, ct, wt);
+                sum.add(ct, wt);
+                if ((jj + 1) % CS == 0) sum.flush();
             }
         }
-        return cost_sum / weight_sum;
+        return sum.result();
     }
 #endif
     const uint32_t* __restrict__ pc2 = PH.pc2;
@@ -208,12 +226,13 @@ __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L
                     float ct, wt;
                     if (PK == 1) q2[k] = make_texel(w2[k], w2[k] >> 24);
                     patch_terms(q1[k], q2[k], c1, c2, L.gsp[ii * S + j0 + k], L.tab(), ct, wt);
-                    patch_accum(cost_sum, weight_sum, ct, wt);
+                    sum.add(ct, wt);
+                    if ((j0 + k + 1) % CS == 0) sum.flush();
                 }
             }
         }
     }
-    return cost_sum / weight_sum;
+    return sum.result();
 }
 
 // the cost field with the source samples of the 16x16 block from an LDS tile, as in the search and in phase A of the sweeps (radius 9 / 17)
@@ -291,6 +310,49 @@ __device__ __forceinline__ float dpp_prev_lane(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
+// Samples per lane of a cooperative evaluation.  Exact library: the S*S samples dealt evenly to the LPC lanes.  Tolerance library: a lane
+// = a chunk of the canonical summation order (eppm_device.cuh: PatchSum) -- 5 samples at radius 9 (20 of 32 lanes work), 6 at radius 17
+// (54 of 64) --, whatever LPC is.
+template <int R, int LPC>
+__host__ __device__ constexpr int coop_chunk()
+{
+#ifdef EPPM_TOL
+    return tol_chunk(R);
+#else
+    return ((R + 1) * (R + 1) + LPC - 1) / LPC;
+#endif
+}
+// The sums of a cooperative evaluation from the lanes' terms tc[], tw[] (zero past the last sample); complete in lane NL - 1 of the group.
+// Exact library: the two running sums hop lane to lane while EVERY lane adds its whole chunk at every hop -- the additions happen in the
+// reference's order (only the sum that travels through lane ln at hop ln is the real one).  Tolerance library: every lane first sums
+// its own chunk from zero (fused multiply-adds), then the totals hop with one addition per hop: the canonical order of PatchSum, the
+// same bits as a lane that evaluates alone.  (A DPP tree instead of the hops was 8 % cheaper and wrong: its result differed in the
+// last bit from the serial kernels' and even between the lanes of one chain, and on images whose candidates TIE -- flat regions, saturated
+// blocks -- strict "<" then accepted in one kernel what another had stored as equal: 0.34 px on a fuzz case)
+template <int LPC, int CH, int NS, int NL>
+__device__ __forceinline__ void coop_chain_sum(const float (&tc)[CH], const float (&tw)[CH], float& ac, float& aw)
+{
+#ifdef EPPM_TOL
+    float pc = 0.0f, pw = 0.0f;
+#pragma unroll
+    for (int q = 0; q < CH; q++) patch_accum(pc, pw, tc[q], tw[q]);
+#pragma unroll
+    for (int ln = 0; ln < NL; ln++) {
+        if (ln > 0) { ac = dpp_prev_lane<LPC>(ac); aw = dpp_prev_lane<LPC>(aw); }
+        ac += pc; aw += pw;
+    }
+#else
+#pragma unroll
+    for (int ln = 0; ln < NL; ln++) {
+        if (ln > 0) { ac = dpp_prev_lane<LPC>(ac); aw = dpp_prev_lane<LPC>(aw); }
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+            if (ln * CH + q < NS) patch_accum(ac, aw, tc[q], tw[q]);
+        }
+    }
+#endif
+}
+
 // One patch evaluation spread over the LPC lanes of a DPP row (16) or of a whole wave (64), for kernels whose source samples lie in
 // the (kBlock + 2 RT)^2 LDS tile of a 16x16 block: the S*S samples are dealt to the lanes in contiguous chunks, each lane forms the
 // terms of its chunk, and the two running sums hop lane to lane while every lane adds its chunk -- the reference's order of additions,
@@ -299,7 +361,8 @@ template <int RT, int LPC, class LUT>
 __device__ __forceinline__ float coop_patch_dist(const Planes& P, const LUT& L, const float4* __restrict__ s_src, int TW, int tx, int ty,
                                                  int x2, int y2, int r)
 {
-    constexpr int S = RT + 1, NS = S * S, CH = (NS + LPC - 1) / LPC, NL = (NS + CH - 1) / CH;
+    constexpr int S = RT + 1, NS = S * S, CH = coop_chunk<RT, LPC>(), NL = (NS + CH - 1) / CH;
+    static_assert(NL <= LPC, "a lane per chunk");
     const int pitch16 = P.pitch << 4, wmax16 = (P.w - 1) << 4;
     const rgbf c1 = texel_rgb(s_src[(ty + RT) * TW + tx + RT]);
     const rgbf c2 = texel_rgb(texel_at(P.pk2, texel_off(pitch16, P.w, P.h, x2, y2)));
@@ -318,20 +381,8 @@ __device__ __forceinline__ float coop_patch_dist(const Planes& P, const LUT& L, 
         tc[k] = 0.0f; tw[k] = 0.0f;
         if (t0 + k < NS) patch_terms(s_src[so[k]], q2[k], c1, c2, L.gsp[t0 + k], L.tab(), tc[k], tw[k]);
     }
-    // The sums advance in the reference's sample order in BOTH libraries: the two running sums hop lane to lane while every lane adds
-    // its chunk (the tolerance library with fused multiply-adds, patch_accum).  A tolerance build with per-lane partial sums and a DPP
-    // tree was 8 % cheaper per evaluation and WRONG in a way only tie-heavy images show: the cost of a (pixel, candidate) pair must be the
-    // same bits whichever kernel evaluates it -- the search sums serially, a sweep cooperatively -- or equal-cost candidates of flat
-    // regions are accepted by one kernel and rejected by the other (mean EPE 0.34 px on a saturated-blocks fuzz case).
     float ac = 0.0f, aw = 0.0f;
-#pragma unroll
-    for (int ln = 0; ln < NL; ln++) {
-        if (ln > 0) { ac = dpp_prev_lane<LPC>(ac); aw = dpp_prev_lane<LPC>(aw); }
-#pragma unroll
-        for (int q = 0; q < CH; q++) {
-            if (ln * CH + q < NS) patch_accum(ac, aw, tc[q], tw[q]);
-        }
-    }
+    coop_chain_sum<LPC, CH, NS, NL>(tc, tw, ac, aw);
     const int src = ((threadIdx.x & 63) / LPC) * LPC + (NL - 1);      // lane holding the complete sums (wave-relative)
     return __shfl(ac, src, 64) / __shfl(aw, src, 64);
 }
@@ -383,7 +434,8 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
     // SPEC with a work list (pr.wl): the workgroup's CPB chains are CPB / 2 listed units (a unit = segments 2u, 2u + 1 of a line, so
     // that segments 0 and 1 -- the two visitors of pixel L -- always sit in one workgroup); a workgroup past the end of the list
     // returns at once.  Chains that are not listed keep their pixels: phase A has copied the whole field to the output plane.
-    constexpr int S = R + 1, NS = S * S, CH = (NS + LPC - 1) / LPC, CPB = 256 / LPC;
+    constexpr int S = R + 1, NS = S * S, CH = coop_chunk<R, LPC>(), CPB = 256 / LPC;
+    static_assert((NS + CH - 1) / CH <= LPC, "a lane per chunk");
     constexpr int SEGS = SweepTile<LPC>::SEGS, LINES = SweepTile<LPC>::LINES, TROWS = S + LINES - 1;
     static_assert(!(SPEC && TILE), "phase B evaluates rarely: it gathers its source samples");
     extern __shared__ float4 s_tile[];          // TILE: TROWS sample rows + LINES centre rows of TW texels
@@ -577,17 +629,10 @@ __global__ __launch_bounds__(256) EPPM_SWEEP_OCC void k_pm_sweep(PmBatch B, cons
                     }
                 }
             }
-            // sequential sums in sample order: lane 0's chunk first, then the partial sums move one lane right (both libraries: see coop_patch_dist)
+            // the sums in their defined order (coop_chain_sum): complete in the lane of the last chunk
             float ac = 0.0f, aw = 0.0f;
             constexpr int NL = (NS + CH - 1) / CH;       // lanes that own samples
-#pragma unroll
-            for (int ln = 0; ln < NL; ln++) {
-                if (ln > 0) { ac = dpp_prev_lane<LPC>(ac); aw = dpp_prev_lane<LPC>(aw); }
-#pragma unroll
-                for (int q = 0; q < CH; q++) {
-                    if (ln * CH + q < NS) patch_accum(ac, aw, tc[q], tw[q]);
-                }
-            }
+            coop_chain_sum<LPC, CH, NS, NL>(tc, tw, ac, aw);
             const int src = ((threadIdx.x & 63) / LPC) * LPC + (NL - 1);   // lane holding the complete sums (wave-relative)
             const float cs = __shfl(ac, src, 64), ws = __shfl(aw, src, 64);
             cv = cs / ws;
@@ -869,11 +914,12 @@ __global__ __launch_bounds__(256) void k_pm_spec_all(PmBatch B, const float* __r
     // registers cost the early iterations, which every block of that kernel also serves; this kernel only runs late.)  PatchMatch
     // 0.747 -> 0.741 ms per pair in 8-pair launches, default bench +0.4 % (two interleaved rounds each), 1920x1080 unchanged.
     if (RT == 9 && total <= EPPM_MERGED_COOP9_MAX) {
-        for (int slot = tid >> 4; slot < total; slot += 16) {
+        constexpr int CL = EPPM_LPC9_SPEC;            // lanes per evaluation: 16 (tolerance library: 32, a lane = a chunk)
+        for (int slot = tid / CL; slot < total; slot += 256 / CL) {
             const int pix = (int)s_list[slot] & 255, d = (int)s_list[slot] >> 8, e = s_cand[slot];
             const int px = bxx * kBlock + (pix & 15), py = byy * kBlock + (pix >> 4), ci = py * B.cpitch + px;
-            const float cv = coop_patch_dist<(RT == 9 ? 9 : 1), 16>(P, L, s_src, TW, pix & 15, pix >> 4, (int)(int16_t)(e & 0xffff), e >> 16, tid & 15);
-            if ((tid & 15) == 0) {
+            const float cv = coop_patch_dist<(RT == 9 ? 9 : 1), CL>(P, L, s_src, TW, pix & 15, pix >> 4, (int)(int16_t)(e & 0xffff), e >> 16, tid % CL);
+            if ((tid % CL) == 0) {
                 pr.spec[d * B.cache_plane + ci] = cv;
                 pr.scand[d * B.cache_plane + ci] = e;
                 if (cv < pr.cost[ci]) merged_list_unit(wl, B, d, px, py);
@@ -1035,12 +1081,6 @@ bool launch_pm_sweep(PmBatch& b, const float* lut, int R, int seg_len, int dir, 
     const bool is_row = (dir == 0 || dir == 2);
     const int len = is_row ? P.w : P.h, lines = is_row ? P.h : P.w;
     const int nseg = (len + seg_len - 1) / seg_len;
-#ifndef EPPM_LPC9_SPEC
-#define EPPM_LPC9_SPEC 16     // lanes per chain in phase B at radius 9 (4 were tried -- a quarter of the waves, one round of workgroups --
-#endif                        // and lost: 50-56 vs 32-41 us per 8-pair launch, the evaluations after accepted candidates take four times as long)
-#ifndef EPPM_LPC17_SPEC
-#define EPPM_LPC17_SPEC 64    // ... at radius 17
-#endif
     if (speculative && b.p[0].spec && (R == 9 || R == 17) && seg_len <= kSpecMaxSteps) {
         if (R == 9) { launch_sweep_spec<9>(b, lut, R, dir, seg_len, nseg, s); launch_sweep_b<9, EPPM_LPC9_SPEC>(b, lut, seg_len, dir, nseg, lines, s); }
         else { launch_sweep_spec<17>(b, lut, R, dir, seg_len, nseg, s); launch_sweep_b<17, EPPM_LPC17_SPEC>(b, lut, seg_len, dir, nseg, lines, s); }
@@ -1057,7 +1097,12 @@ bool launch_pm_sweep(PmBatch& b, const float* lut, int R, int seg_len, int dir, 
 #ifndef EPPM_SWEEP_PRE
 #define EPPM_SWEEP_PRE 1      // the classic form fetches its chains' pixels up front: 0 never, 1 launches that cannot fill the chip, 2 always
 #endif
-        if (chains * EPPM_LPC9 / 64 < EPPM_LPC_SWITCH_WAVES) launch_sweep_r<9, 2 * EPPM_LPC9, (EPPM_SWEEP_PRE >= 1)>(b, lut, seg_len, dir, nseg, lines, s);
+#ifdef EPPM_TOL
+        constexpr int LPC_SMALL = EPPM_LPC9;          // one dealing of the samples (coop_chunk): small launches only fetch up front
+#else
+        constexpr int LPC_SMALL = 2 * EPPM_LPC9;
+#endif
+        if (chains * 16 / 64 < EPPM_LPC_SWITCH_WAVES) launch_sweep_r<9, LPC_SMALL, (EPPM_SWEEP_PRE >= 1)>(b, lut, seg_len, dir, nseg, lines, s);
         else launch_sweep_r<9, EPPM_LPC9, (EPPM_SWEEP_PRE >= 2)>(b, lut, seg_len, dir, nseg, lines, s);
         return true;
     }

@@ -99,7 +99,8 @@ static struct { int sweep_order, post_inplace, exp_mode, seed_variant; } g_var =
  * the flow? -- the design study behind libeppm_hip_tol.so; never the parity oracle).
  *   mode  bit 1: 1 - exp(-d^2/s) = TD[kd], exp(-(a^2+b^2)/s) = TA[ka]*TA[kb] with k the integer L-inf distance of the u8 texels
  *         bit 2: cost_sum advances by fmaf(cost, weight, cost_sum)
- *         bit 4: the S*S terms are summed as S row sums (each in j order) added in i order, instead of one chain
+ *         bit 4: (PatchMatch scope) the canonical order of the tolerance kernels: chunks of half a row (a third at radius 17) summed
+ *                from zero, the chunk sums added one after the other (eppm_device.cuh: PatchSum); the refine keeps one chain
  *         bit 8: hardware-exp class: expf() wherever the table form does not apply (smoothing, weighted median)
  *         bit 16: (refine scope only) the weight as ONE hardware exp2 of a summed argument, exp2(log2(gs_j gs_i) - c (ka^2 + kb^2)),
  *                 c = log2(e) / (255^2 s) in float: the form the tolerance library's refine kernel uses (LDS bound otherwise)
@@ -513,13 +514,18 @@ float orc_patch_dist(const orc_uchar4* img1, const orc_uchar4* img2, const uint8
     if ((g_tol.mode & 1) && (g_tol.scope & 1)) {
         const orc_uchar4 k1 = tex_u8x4(img1, w, h, x1, y1), k2 = tex_u8x4(img2, w, h, x2, y2);
         float cost_sum = 0.0f, weight_sum = 0.0f;
+        /* mode bit 4: the canonical order of the tolerance library's PatchMatch costs (eppm_device.cuh: PatchSum): row-major samples in
+         * chunks of half a row (a third at radius 17), each chunk summed from zero, the chunk sums added one after the other */
+        const int S = R + 1, CS = (R == 17) ? 6 : (R + 2) / 2;
         for (int i = -R; i <= R; i += 2) {
             float cr = 0.0f, wr = 0.0f;
-            float* pc = (g_tol.mode & 4) ? &cr : &cost_sum;
-            float* pw = (g_tol.mode & 4) ? &wr : &weight_sum;
-            for (int j = -R; j <= R; j += 2)
+            int left = CS, jj = 0;
+            for (int j = -R; j <= R; j += 2, jj++) {
+                float* pc = (g_tol.mode & 4) ? &cr : &cost_sum;
+                float* pw = (g_tol.mode & 4) ? &wr : &weight_sum;
                 patch_sample_tol(img1, img2, c1, c2, w, h, k1, k2, x1 + j, y1 + i, x2 + j, y2 + i, gs[abs(j)], gs[abs(i)], cn, pc, pw);
-            if (g_tol.mode & 4) { cost_sum += cr; weight_sum += wr; }
+                if ((g_tol.mode & 4) && (--left == 0 || jj == S - 1)) { cost_sum += cr; weight_sum += wr; cr = wr = 0.0f; left = CS; }
+            }
         }
         return cost_sum / weight_sum;
     }
@@ -546,7 +552,6 @@ float orc_patch_dist_planefit(const orc_uchar4* img1, const orc_uchar4* img2, co
     const int tol = (g_tol.mode & 1) && (g_tol.scope & 2);
     g_tol_exp2_now = tol && (g_tol.mode & 16);
     const orc_uchar4 k1 = tex_u8x4(img1, w, h, x1, y1), k2 = tex_u8x4(img2, w, h, x2, y2);
-    float rows_c[64] = {0}, rows_w[64] = {0};
     float c4[4];
     for (int pass = 0; pass < 4; pass++) {
         const float* cf = kPlaneCoef[pass];
@@ -561,17 +566,13 @@ float orc_patch_dist_planefit(const orc_uchar4* img1, const orc_uchar4* img2, co
                     cx2 = cx1 + uu + (j)*cf[0] + (i)*cf[1];
                     cy2 = cy1 + vv + (j)*cf[2] + (i)*cf[3];
                 }
-                if (tol) {
-                    float* pc = (g_tol.mode & 4) ? &rows_c[(i + R) / 2] : &cost_sum;
-                    float* pw = (g_tol.mode & 4) ? &rows_w[(i + R) / 2] : &weight_sum;
+                if (tol)          /* the refine's sums advance in sample order, one chain per (pass, candidate) */
                     patch_sample_tol(img1, img2, c1, c2, w, h, k1, k2, (int)floorf(cx1), (int)floorf(cy1),
-                                     (int)floorf(cx2), (int)floorf(cy2), gs[abs(j)], gs[abs(i)], cn, pc, pw);
-                } else
+                                     (int)floorf(cx2), (int)floorf(cy2), gs[abs(j)], gs[abs(i)], cn, &cost_sum, &weight_sum);
+                else
                 patch_sample(img1, img2, c1, c2, w, h, center1, center2, (int)floorf(cx1), (int)floorf(cy1),
                              (int)floorf(cx2), (int)floorf(cy2), gs[abs(j)], gs[abs(i)], cn, &cost_sum, &weight_sum);
             }
-        if (tol && (g_tol.mode & 4))
-            for (int r = 0; r <= R; r++) { cost_sum += rows_c[r]; weight_sum += rows_w[r]; rows_c[r] = rows_w[r] = 0.0f; }
         c4[pass] = cost_sum / weight_sum;
     }
     /* __min(cost1,__min(cost2,__min(cost3,cost4))) :512 with __min(a,b) = (a<b)?a:b

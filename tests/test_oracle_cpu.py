@@ -1011,8 +1011,8 @@ def test_speculative_sweep_form_and_evaluation_cache_equal_the_lockstep_sweeps(c
 # ---------------------------------------------------------------- the tolerance library's arithmetic, on the CPU
 def test_tolerance_arithmetic_moves_no_match_on_the_bundled_pair(frames):
     """tools/tolerance_envelope.py's finding, which libeppm_hip_tol.so is built on, on the full bundled pair: the
-    integer-domain table form of the patch term -- with fused accumulation in the reference's sample order and the refine's weight as one
-    exp2 of a summed argument, i.e. what the tolerance kernels compute -- changes most bits of the PatchMatch cost plane and NOT ONE match; the final flow
+    integer-domain table form of the patch term -- with fused accumulation (PatchMatch in its chunked canonical order, the refine in sample order) and the refine's
+    weight as one exp2 of a summed argument, i.e. what the tolerance kernels compute -- changes most bits of the PatchMatch cost plane and NOT ONE match; the final flow
     stays three orders of magnitude inside north_star's 1e-3 px.  The same substitution in the smoothing alone moves ~88 % of the pixels
     (mean ~5e-4 px): the smoothed mean of equal integer flows sits on the next level's truncation boundary, which is why the tolerance
     library keeps the smoothing exact.  The oracle variants are test infrastructure; the parity oracle is the run with all of them off."""
@@ -1021,7 +1021,7 @@ def test_tolerance_arithmetic_moves_no_match_on_the_bundled_pair(frames):
     import tolerance_envelope as TE
     a, b = frames
     u0, v0, st0 = O.compute_flow(a, b, dump=True)
-    O.set_tol_variant(19, 3)                           # tables | fma | exp2 weights (sums in sample order), in PatchMatch and the refine
+    O.set_tol_variant(23, 3)                           # tables | fma | PatchMatch's chunked order | exp2 weights in the refine: what the kernels compute
     try:
         u1, v1, st1 = O.compute_flow(a, b, dump=True)
     finally:

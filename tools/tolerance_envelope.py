@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # (name, mode, scope)
 VARIANTS = [("tables_pm", 1, 1), ("tables_refine", 1, 2), ("tables_smoothing", 1, 4),
-            ("tables_fma_pm_refine", 3, 3), ("tables_fma_rowsums_pm_refine", 7, 3), ("kernel_form_tables_fma_exp2_refine", 19, 3), ("tables_fma_rowsums_all", 7, 7)]
+            ("tables_fma_pm_refine", 3, 3), ("kernel_form_tables_fma_chunks_exp2_refine", 23, 3), ("tables_fma_all", 3, 7)]
 
 
 def epe_stats(u, v, u0, v0):

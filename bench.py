@@ -797,7 +797,7 @@ def tolerance_mode(args):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "EPPM_HIP_VARIANT"):
         env.pop(k, None)
     out = {"library": "eppm_amd/lib/libeppm_hip_tol.so (make -C eppm_amd/csrc; -DEPPM_TOL: integer-domain tables / one hardware exp2 in the patch "
-                      "term, fused sums in the reference's order, column-parity target planes; everything else -- prepare, census, random field, left-right "
+                      "term, fused sums in one canonical chunked order (DESIGN.md section 9.2), column-parity target planes; everything else -- prepare, census, random field, left-right "
                       "check, outlier vote, weighted median, hole filling, flow smoothing -- is the exact library's code)",
            "parity": "NOT bit-identical; north_star's bar: mean EPE <= 1e-3 px against the oracle on frame10/frame11 (asserted by -m gpu tests)"}
     try:

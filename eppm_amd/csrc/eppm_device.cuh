@@ -166,8 +166,9 @@ __device__ __forceinline__ float one_minus_fast_exp(float x) { return 1 - fast_e
 // A channel is fl(k/255), so such a distance is |fl(a/255) - fl(b/255)| for two bytes a, b: one of only 598 distinct floats, and
 // any function of it -- 1 - exp(-d^2/s) of the patch term, exp(-d^2/s') of the smoothing and weighted-median weights -- has at most 598
 // values.  The table holds exactly what the formula returns for each of them (filled on the device BY that formula, k_delta_values,
-// once per device), so reading it is the same bits for 12 issue cycles instead of 34 (mul, exact division, exp polynomial, ldexp).
-// Two levels: kd = |a - b| = trunc(fma(d, 1020, 2)) / 4 names a group of neighbouring floats (the distances with the same byte
+// once per device), so reading it is the same bits for 6 issue cycles (v_mul, v_lshl_add) instead of 34 (mul, exact division, exp polynomial,
+// ldexp).
+// Two levels: kd = |a - b| = round(d * 255) names a group of neighbouring floats (the distances with the same byte
 // difference lie within 64 ulp of each other), t1[kd] = byte offset of the group in t2 minus 4 x the bits of its smallest member, so
 // the entry of d is at (bits(d) << 2) + t1[kd].  Built and checked exhaustively over the 65 536 byte pairs on the host
 // (api_common.cpp: delta_index; tests/test_abi_cpu.py::test_delta_index_covers_every_byte_pair).
@@ -181,9 +182,19 @@ struct DeltaTab {
 #ifndef EPPM_DELTA_BLF
 #define EPPM_DELTA_BLF 1          // the smoothing / weighted-median range weight by table (0: evaluate the formula)
 #endif
+#ifndef EPPM_DELTA_DENORM
+#define EPPM_DELTA_DENORM 1
+#endif
 __device__ __forceinline__ float delta_lookup(const DeltaTab& D, float d)
 {
+#if EPPM_DELTA_DENORM
+    // 4 * kd in ONE full-rate instruction: the product of d and the float whose bits are 1020 (1020 * 2^-149) is a denormal, and a
+    // denormal's bits are its value in units of 2^-149 -- round(d * 1020) = 4 * kd exactly, the distances of a group lying within
+    // 4e-6 relative of kd / 255 (kernels run with float_denorm_mode_32 = preserve, as the tolerance library's texels need too)
+    const uint32_t o1 = __float_as_uint(d * __uint_as_float(1020u));
+#else
     const uint32_t o1 = (uint32_t)__builtin_fmaf(d, 1020.0f, 2.0f) & ~3u;                   // 4 * kd: v_fma, v_cvt_u32, v_and
+#endif
     const int w = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(D.t1) + o1);
     const uint32_t o2 = (__float_as_uint(d) << 2) + (uint32_t)w;                             // v_lshl_add_u32
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(D.t2) + o2);

@@ -947,7 +947,7 @@ EPPM_UNROLL(EPPM_BLF_UNROLL)
             const float gx = s_lut[abs(dx - BR)];
             if (use_a) {
                 // (a skipped tap, r = 100, meets the entry of d = 1: exp(-2500) = 0 exactly, as the formula gives for d ~ 100)
-                const float delta_r = EPPM_DELTA_BLF ? fminf(max_abs_diff(ca, pix), 1.0f) : max_abs_diff(ca, pix);
+                const float delta_r = EPPM_DELTA_BLF ? __builtin_amdgcn_fmed3f(max_abs_diff(ca, pix), 0.0f, 1.0f) : max_abs_diff(ca, pix);
                 const float coef_r = EPPM_DELTA_BLF ? delta_lookup(s_D, delta_r) : fast_exp(div_wmf2(-(delta_r * delta_r)));
                 const float coef_s = gx * gya;
                 const float wgt = coef_r * coef_s;
@@ -956,7 +956,7 @@ EPPM_UNROLL(EPPM_BLF_UNROLL)
                 wa += wgt;
             }
             if (use_b) {
-                const float delta_r = EPPM_DELTA_BLF ? fminf(max_abs_diff(cb, pix), 1.0f) : max_abs_diff(cb, pix);
+                const float delta_r = EPPM_DELTA_BLF ? __builtin_amdgcn_fmed3f(max_abs_diff(cb, pix), 0.0f, 1.0f) : max_abs_diff(cb, pix);
                 const float coef_r = EPPM_DELTA_BLF ? delta_lookup(s_D, delta_r) : fast_exp(div_wmf2(-(delta_r * delta_r)));
                 const float coef_s = gx * gyb;
                 const float wgt = coef_r * coef_s;

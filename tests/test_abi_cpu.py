@@ -330,7 +330,8 @@ def test_device_code_uses_global_not_flat_memory_instructions(tmp_path):
 def test_delta_index_covers_every_byte_pair():
     """The two-level index behind the range terms that are read from a table (eppm_device.cuh: DeltaTab; api_common.cpp: delta_index),
     restated in numpy: the L-inf distance of two unorm8 texels is |fl(a/255) - fl(b/255)| for two bytes -- 598 distinct floats --, the
-    first level kd = trunc(fma(d, 1020, 2)) >> 2 equals |a - b| for every pair, the floats of one kd span at most 65 consecutive bit
+    first level kd = round(d * 255) (as trunc(fma(d, 1020, 2)) >> 2 and as the bits of the denormal product d * (1020 * 2^-149), the kernels'
+    form) equals |a - b| for every pair, the floats of one kd span at most 65 consecutive bit
     patterns, and the spans add up to what the kernels reserve (kDeltaSlots)."""
     g = (np.arange(256, dtype=np.float32) / np.float32(255)).astype(np.float32)
     a, b = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
@@ -339,6 +340,9 @@ def test_delta_index_covers_every_byte_pair():
     kd = np.abs(a - b)
     first = (d.astype(np.float64) * 1020.0 + 2.0).astype(np.float32).astype(np.int64) >> 2        # one rounding: the fma
     assert np.array_equal(first, kd)
+    # the form the kernels use: ONE float multiply whose result is denormal -- its bits are round(d * 1020) = 4 * kd (IEEE, denormals kept)
+    denorm = (d * np.array([1020], dtype=np.uint32).view(np.float32)[0]).astype(np.float32).view(np.uint32).astype(np.int64)
+    assert np.array_equal(denorm, 4 * kd)
     bits = d.view(np.uint32).astype(np.int64)
     spans = [int(bits[kd == k].max() - bits[kd == k].min() + 1) for k in range(256)]
     slots = int(re.search(r"constexpr int kDeltaSlots = (\d+);", open(os.path.join(ROOT, "eppm_amd", "csrc", "eppm_internal.h")).read()).group(1))

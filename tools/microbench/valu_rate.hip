@@ -90,6 +90,10 @@ KERNEL_PK(k_pk_add, "v_pk_add_f32 %0, %1, %0\n")
 KERNEL_PK(k_pk_mul, "v_pk_mul_f32 %0, %1, %0\n")
 KERNEL_PK(k_pk_fma, "v_pk_fma_f32 %0, %1, %2, %0\n")
 
+// round 6 (late): table offsets formed in the float pipeline -- a product whose RESULT is denormal is the integer round(d * 1020)
+KERNEL(k_mul_den,  "v_mul_f32 %0, 0x3fc, %1\n")
+KERNEL(k_fma_den,  "v_fmaak_f32 %0, %1, %3, 0x3fc\n")
+
 typedef void (*kern_t)(float*, float, float, int);
 
 int main()
@@ -114,6 +118,7 @@ int main()
         {"v_sad_u32", k_sad_u32}, {"v_sad_u8", k_sad_u8}, {"v_max3_u32", k_max3_u32}, {"v_max3_i32", k_max3_i32}, {"v_cvt_u32_f32", k_cvt_u32},
         {"v_mul_u32_u24_sdwa", k_mul24_sdwa}, {"v_lshlrev_b32_sdwa", k_lshl_sdwa}, {"v_sub_u32_sdwa", k_sub_sdwa}, {"v_pk_max_u16", k_pk_max_u16},
         {"v_pk_sub_i16", k_pk_sub_i16}, {"v_max_u32", k_max_u32}, {"v_and_or_b32", k_and_or},
+        {"v_mul_f32 -> denormal", k_mul_den}, {"v_fmaak_f32 ~denormal", k_fma_den},
         {"v_pk_add_f32 (2 adds)", k_pk_add}, {"v_pk_mul_f32 (2 muls)", k_pk_mul}, {"v_pk_fma_f32 (2 fmas)", k_pk_fma},
     };
     hipEvent_t e0, e1;

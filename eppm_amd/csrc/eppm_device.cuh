@@ -166,7 +166,7 @@ __device__ __forceinline__ float one_minus_fast_exp(float x) { return 1 - fast_e
 // A channel is fl(k/255), so such a distance is |fl(a/255) - fl(b/255)| for two bytes a, b: one of only 598 distinct floats, and
 // any function of it -- 1 - exp(-d^2/s) of the patch term, exp(-d^2/s') of the smoothing and weighted-median weights -- has at most 598
 // values.  The table holds exactly what the formula returns for each of them (filled on the device BY that formula, k_delta_values,
-// once per device), so reading it is the same bits for 6 issue cycles (v_mul, v_lshl_add) instead of 34 (mul, exact division, exp polynomial,
+// once per device), so reading it is the same bits for 6 issue cycles (v_fma, v_lshl_add) instead of 34 (mul, exact division, exp polynomial,
 // ldexp).
 // Two levels: kd = |a - b| = round(d * 255) names a group of neighbouring floats (the distances with the same byte
 // difference lie within 64 ulp of each other), t1[kd] = byte offset of the group in t2 minus 4 x the bits of its smallest member, so
@@ -182,27 +182,26 @@ struct DeltaTab {
 #ifndef EPPM_DELTA_BLF
 #define EPPM_DELTA_BLF 1          // the smoothing / weighted-median range weight by table (0: evaluate the formula)
 #endif
-#ifndef EPPM_DELTA_DENORM
-#define EPPM_DELTA_DENORM 1
-#endif
+// a DeltaTab lives in LDS; its look-up forms 32-bit LDS ADDRESSES (no base to add to an offset whose range the compiler cannot know)
+typedef const __attribute__((address_space(3))) float lds_cfloat;
+typedef const __attribute__((address_space(3))) int lds_cint;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
 __device__ __forceinline__ float delta_lookup(const DeltaTab& D, float d)
 {
-#if EPPM_DELTA_DENORM
-    // 4 * kd in ONE full-rate instruction: the product of d and the float whose bits are 1020 (1020 * 2^-149) is a denormal, and a
-    // denormal's bits are its value in units of 2^-149 -- round(d * 1020) = 4 * kd exactly, the distances of a group lying within
-    // 4e-6 relative of kd / 255 (kernels run with float_denorm_mode_32 = preserve, as the tolerance library's texels need too)
-    const uint32_t o1 = __float_as_uint(d * __uint_as_float(1020u));
-#else
-    const uint32_t o1 = (uint32_t)__builtin_fmaf(d, 1020.0f, 2.0f) & ~3u;                   // 4 * kd: v_fma, v_cvt_u32, v_and
-#endif
-    const int w = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(D.t1) + o1);
-    const uint32_t o2 = (__float_as_uint(d) << 2) + (uint32_t)w;                             // v_lshl_add_u32
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(D.t2) + o2);
+    // The address of t1[kd] in ONE full-rate instruction: a float below 2^-125 has the bits of its value in units of 2^-149, so an fma whose
+    // RESULT lies there is an integer -- fma(d, 1020 * 2^-149, &t1 * 2^-149) = &t1 + round(1020 d) = &t1 + 4 kd exactly, the distances of a
+    // group lying within 4e-6 relative of kd / 255 (kernels run with float_denorm_mode_32 = preserve, as the tolerance library's texels
+    // need too).  t1[kd] already contains &t2 (load_delta_tab), so (bits(d) << 2) + t1[kd] is the entry's address: v_fma, ds_read,
+    // v_lshl_add, ds_read = 6 issue cycles (the offset forms cost v_fma, v_cvt_u32, v_and + an address add, and v_lshlrev, v_add3: 18).
+    const uint32_t a1 = __float_as_uint(__builtin_fmaf(d, __uint_as_float(1020u), __uint_as_float(lds_addr(D.t1))));
+    const uint32_t a2 = (__float_as_uint(d) << 2) + (uint32_t)*reinterpret_cast<lds_cint*>(a1);
+    return *reinterpret_cast<lds_cfloat*>(a2);
 }
 // global layout behind a look-up table's own entries: t1[256] (int bits), then t2[kDeltaSlots]
 __device__ __forceinline__ void load_delta_tab(DeltaTab& D, const float* __restrict__ src, int tid, int nthreads)
 {
-    for (int t = tid; t < 256; t += nthreads) D.t1[t] = __float_as_int(src[t]);
+    const int t2_at = (int)lds_addr(D.t2);
+    for (int t = tid; t < 256; t += nthreads) D.t1[t] = __float_as_int(src[t]) + t2_at;          // modulo 2^32, as the look-up's sum
     for (int t = tid; t < kDeltaSlots; t += nthreads) D.t2[t] = src[256 + t];
 }
 __device__ __forceinline__ rgbf texel_rgb(const float4 t) { return rgbf{t.x, t.y, t.z}; }

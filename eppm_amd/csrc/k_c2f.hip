@@ -894,8 +894,13 @@ void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, f
 // PPL = pixels per lane: 2 (32x16 tile) for large launches, 1 (32x8 tile, twice the waves) otherwise, see launch_flow_blf.
 constexpr int BT_W = 32, BR = kBlfRadius, BTW = BT_W + 2 * BR;
 
+#ifdef EPPM_BLF_WAVES
+#define EPPM_BLF_OCC __attribute__((amdgpu_waves_per_eu(EPPM_BLF_WAVES, EPPM_BLF_WAVES)))
+#else
+#define EPPM_BLF_OCC
+#endif
 template <int PPL>
-__global__ __launch_bounds__(256) void k_flow_blf(float* __restrict__ out_, const float* __restrict__ in_,
+__global__ __launch_bounds__(256) EPPM_BLF_OCC void k_flow_blf(float* __restrict__ out_, const float* __restrict__ in_,
                                                   const uint32_t* __restrict__ img_, int ipitch, int w, int h, int fpitch,
                                                   const float* __restrict__ blf_lut, size_t pstride)
 {

@@ -340,7 +340,8 @@ def test_delta_index_covers_every_byte_pair():
     kd = np.abs(a - b)
     first = (d.astype(np.float64) * 1020.0 + 2.0).astype(np.float32).astype(np.int64) >> 2        # one rounding: the fma
     assert np.array_equal(first, kd)
-    # the form the kernels use: ONE float multiply whose result is denormal -- its bits are round(d * 1020) = 4 * kd (IEEE, denormals kept)
+    # the form the kernels use: ONE float operation whose result is denormal -- its bits are round(d * 1020) = 4 * kd (IEEE, denormals kept;
+    # the kernels add the table's LDS address in the same fma: an integer, the rounding is the product's)
     denorm = (d * np.array([1020], dtype=np.uint32).view(np.float32)[0]).astype(np.float32).view(np.uint32).astype(np.int64)
     assert np.array_equal(denorm, 4 * kd)
     bits = d.view(np.uint32).astype(np.int64)

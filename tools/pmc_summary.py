@@ -1,10 +1,10 @@
 """Per-kernel summary of a rocprofv3 --pmc counter_collection.csv: mean of each counter per dispatch, grouped by kernel name
 (+ grid size, so the level-1 and level-0 launches of one kernel stay apart), and the mean duration from the kernel trace.
 usage: pmc_summary.py DIR [name-filter]"""
-import csv, glob, sys, collections, re
+import csv, glob, os, sys, collections, re
 d = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-cc = glob.glob(d + "/*/*counter_collection.csv")[0]
+cc = max(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)       # the newest run's (gpurun merges into directories that may hold older files)
 rows = list(csv.DictReader(open(cc)))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
@@ -12,9 +12,9 @@ for r in rows:
     key = (name, r["Grid_Size"])
     agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = collections.defaultdict(list)
-kt = glob.glob(d + "/*/*kernel_trace.csv")
-if kt:
-    for r in csv.DictReader(open(kt[0])):
+kt = cc.replace("counter_collection.csv", "kernel_trace.csv")                          # the same process's trace
+if os.path.exists(kt):
+    for r in csv.DictReader(open(kt)):
         name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void eppm::", "")
         g = str(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))
         dur[(name, g)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)

@@ -17,7 +17,9 @@ for d in ("stats_default", "stats_single", "stats_batch8", "stats_tol_default", 
     # the bench process's file: the one with kernel rows (child processes that launch no kernel leave empty or no stats files)
     f = [x for x in glob.glob(f"{src}/{d}/*/*kernel_stats.csv") if "k_" in open(x).read()]
     if f:
-        shutil.copy(max(f, key=os.path.getsize), f"{dst}/{tag}_{d}_kernel_stats.csv")
+        # gpurun MERGES a call's outputs into gpurun_out/: a directory may still hold an earlier round's files (other process ids) -- the newest run counts
+        newest = max(os.path.getmtime(x) for x in f)
+        shutil.copy(max((x for x in f if newest - os.path.getmtime(x) < 300), key=os.path.getsize), f"{dst}/{tag}_{d}_kernel_stats.csv")
 summ = {}
 for d in sorted(os.listdir(src)):
     if d.startswith("pmc_") and glob.glob(f"{src}/{d}/*/*counter_collection.csv"):

@@ -915,7 +915,7 @@ __global__ __launch_bounds__(256) EPPM_BLF_OCC void k_flow_blf(float* __restrict
     const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
     const int tid = threadIdx.y * BT_W + threadIdx.x;
     if (tid <= BR) s_lut[tid] = blf_lut[tid];
-    load_delta_tab(s_D, blf_lut + BR + 1, tid, 256);
+    load_delta_tab<false>(s_D, blf_lut + BR + 1, tid, 256);
     for (int t = tid; t < BTW * BTH; t += 256) {
         const int cy = y0 + t / BTW - BR, cx = x0 + t % BTW - BR;
         float4 e = make_float4(100.0f, 0.0f, 0.0f, 0.0f);
@@ -953,7 +953,7 @@ EPPM_UNROLL(EPPM_BLF_UNROLL)
             if (use_a) {
                 // (a skipped tap, r = 100, meets the entry of d = 1: exp(-2500) = 0 exactly, as the formula gives for d ~ 100)
                 const float delta_r = EPPM_DELTA_BLF ? __builtin_amdgcn_fmed3f(max_abs_diff(ca, pix), 0.0f, 1.0f) : max_abs_diff(ca, pix);
-                const float coef_r = EPPM_DELTA_BLF ? delta_lookup(s_D, delta_r) : fast_exp(div_wmf2(-(delta_r * delta_r)));
+                const float coef_r = EPPM_DELTA_BLF ? delta_lookup_off(s_D, delta_r) : fast_exp(div_wmf2(-(delta_r * delta_r)));
                 const float coef_s = gx * gya;
                 const float wgt = coef_r * coef_s;
                 nxa += wgt * tp.w;
@@ -962,7 +962,7 @@ EPPM_UNROLL(EPPM_BLF_UNROLL)
             }
             if (use_b) {
                 const float delta_r = EPPM_DELTA_BLF ? __builtin_amdgcn_fmed3f(max_abs_diff(cb, pix), 0.0f, 1.0f) : max_abs_diff(cb, pix);
-                const float coef_r = EPPM_DELTA_BLF ? delta_lookup(s_D, delta_r) : fast_exp(div_wmf2(-(delta_r * delta_r)));
+                const float coef_r = EPPM_DELTA_BLF ? delta_lookup_off(s_D, delta_r) : fast_exp(div_wmf2(-(delta_r * delta_r)));
                 const float coef_s = gx * gyb;
                 const float wgt = coef_r * coef_s;
                 nxb += wgt * tp.w;

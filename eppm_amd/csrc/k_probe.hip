@@ -24,11 +24,15 @@ __global__ void k_probe(const float* __restrict__ x, float* __restrict__ y, int 
 // y[i] = delta_lookup(the DeltaTab at `tab`, x[i]): the table form of a range term against the formula it stands for
 __global__ __launch_bounds__(256) void k_probe_delta(const float* __restrict__ x, float* __restrict__ y, int n, const float* __restrict__ tab)
 {
-    __shared__ DeltaTab s_D;
+    __shared__ DeltaTab s_D, s_E;               // both forms of the look-up (LDS addresses / offsets): they must agree, or the answer is NaN
     load_delta_tab(s_D, tab, threadIdx.x, 256);
+    load_delta_tab<false>(s_E, tab, threadIdx.x, 256);
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] = delta_lookup(s_D, x[i]);
+    if (i < n) {
+        const float a = delta_lookup(s_D, x[i]), b = delta_lookup_off(s_E, x[i]);
+        y[i] = (__float_as_uint(a) == __float_as_uint(b)) ? a : __uint_as_float(0x7fc00000u);
+    }
 }
 void launch_probe_delta(const float* x, float* y, int n, const float* tab, hipStream_t s)
 {

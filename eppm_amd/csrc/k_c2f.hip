@@ -894,6 +894,19 @@ void launch_c2f_refine(const PlanesH& P, float* flow, const float* lut, int R, f
 // PPL = pixels per lane: 2 (32x16 tile) for large launches, 1 (32x8 tile, twice the waves) otherwise, see launch_flow_blf.
 constexpr int BT_W = 32, BR = kBlfRadius, BTW = BT_W + 2 * BR;
 
+#ifndef EPPM_BLF_MIX
+#define EPPM_BLF_MIX 3          // two pixels per lane: every M-th tap column's range weights by formula, the rest by table (LDS / VALU balance); 0: all by table
+#endif
+#ifndef EPPM_BLF_MIX1
+#define EPPM_BLF_MIX1 2         // one pixel per lane (the smaller launches)
+#endif
+// which taps of the smoothing evaluate their range weight instead of reading it (pixel: 0 upper / only, 1 lower)
+template <int PPL>
+__device__ __forceinline__ constexpr bool blf_by_formula(int dx, int pixel)
+{
+    constexpr int M = (PPL == 1) ? EPPM_BLF_MIX1 : EPPM_BLF_MIX;
+    return M == 1 ? (PPL == 2 ? pixel == 1 : (dx & 1)) : M >= 2 ? dx % M == 0 : false;
+}
 #ifdef EPPM_BLF_WAVES
 #define EPPM_BLF_OCC __attribute__((amdgpu_waves_per_eu(EPPM_BLF_WAVES, EPPM_BLF_WAVES)))
 #else
@@ -952,8 +965,10 @@ EPPM_UNROLL(EPPM_BLF_UNROLL)
             const float gx = s_lut[abs(dx - BR)];
             if (use_a) {
                 // (a skipped tap, r = 100, meets the entry of d = 1: exp(-2500) = 0 exactly, as the formula gives for d ~ 100)
-                const float delta_r = EPPM_DELTA_BLF ? __builtin_amdgcn_fmed3f(max_abs_diff(ca, pix), 0.0f, 1.0f) : max_abs_diff(ca, pix);
-                const float coef_r = EPPM_DELTA_BLF ? delta_lookup_off(s_D, delta_r) : fast_exp(div_wmf2(-(delta_r * delta_r)));
+                // one pixel per lane (PPL = 1): every other tap column by formula
+                const bool tab_a = EPPM_DELTA_BLF && !blf_by_formula<PPL>(dx, 0);
+                const float delta_r = tab_a ? __builtin_amdgcn_fmed3f(max_abs_diff(ca, pix), 0.0f, 1.0f) : max_abs_diff(ca, pix);
+                const float coef_r = tab_a ? delta_lookup_off(s_D, delta_r) : fast_exp(div_wmf2(-(delta_r * delta_r)));
                 const float coef_s = gx * gya;
                 const float wgt = coef_r * coef_s;
                 nxa += wgt * tp.w;
@@ -961,8 +976,12 @@ EPPM_UNROLL(EPPM_BLF_UNROLL)
                 wa += wgt;
             }
             if (use_b) {
-                const float delta_r = EPPM_DELTA_BLF ? __builtin_amdgcn_fmed3f(max_abs_diff(cb, pix), 0.0f, 1.0f) : max_abs_diff(cb, pix);
-                const float coef_r = EPPM_DELTA_BLF ? delta_lookup_off(s_D, delta_r) : fast_exp(div_wmf2(-(delta_r * delta_r)));
+                // EPPM_BLF_MIX: the lower pixel EVALUATES the weight (the same bits: the table was filled by this formula; a skipped tap's
+                // distance ~100 gives exp(-2.5e7) = 0 exactly) -- the table reads of both pixels made the LDS array the kernel's bound
+                // (28 array cycles per tap against 14.5 issue cycles per CU); one of two by formula: 18 against 21.5
+                const bool tab_b = EPPM_DELTA_BLF && !blf_by_formula<PPL>(dx, 1);
+                const float delta_r = tab_b ? __builtin_amdgcn_fmed3f(max_abs_diff(cb, pix), 0.0f, 1.0f) : max_abs_diff(cb, pix);
+                const float coef_r = tab_b ? delta_lookup_off(s_D, delta_r) : fast_exp(div_wmf2(-(delta_r * delta_r)));
                 const float coef_s = gx * gyb;
                 const float wgt = coef_r * coef_s;
                 nxb += wgt * tp.w;

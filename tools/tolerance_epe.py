@@ -5,7 +5,7 @@ pair forwards (north_star's tolerance case: <= 1e-3 px mean EPE) and backwards, 
 (1920x1080), configs[4] (3840x2160, radius 17; only with --all) and the eight fixed-seed fuzz cases of tests/test_configs_gpu.py.
 Prints one JSON line.
 
-usage: tolerance_epe.py [--all]        (internal: --dump FILE computes the flows with the library EPPM_HIP_VARIANT selects)"""
+usage: tolerance_epe.py [--all] [--no-fuzz] [--fuzz-seeds FIRST:N]        (internal: --dump FILE computes the flows with the library EPPM_HIP_VARIANT selects)"""
 import json
 import os
 import subprocess
@@ -32,7 +32,11 @@ def cases(all_sizes):
         # the fixed-seed fuzz cases of the parity suite, all eight kinds per seed: synthetic motion, unrelated noise, flat regions with
         # saturated blocks (costs that tie exactly, weights that underflow), low contrast; odd sizes, radii 4 / 5 / 9 / 17, 1-4 iterations,
         # 1-8 guesses, every propagation mode and pyramid depth
-        for seed in T.FUZZ_SEEDS:
+        seeds = T.FUZZ_SEEDS
+        if "--fuzz-seeds" in sys.argv:          # FIRST:N -- a wider sweep than the suite's eight seeds (outside the suite)
+            first, n = (int(x) for x in sys.argv[sys.argv.index("--fuzz-seeds") + 1].split(":"))
+            seeds = range(first, first + n)
+        for seed in seeds:
             for t in range(8):
                 fa, fb, params = T._fuzz_case(seed, t)
                 out.append((f"fuzz_seed{seed}_case{t}", fa, fb, params))
@@ -64,7 +68,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         f = os.path.join(td, "tol.npz")
         env = dict(os.environ, EPPM_HIP_VARIANT="tol")
-        subprocess.run([sys.executable, os.path.abspath(__file__), "--dump", f] + [x for x in ("--all", "--no-fuzz") if x in sys.argv], env=env, check=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--dump", f] + [x for x in ("--all", "--no-fuzz") if x in sys.argv] + (sys.argv[sys.argv.index("--fuzz-seeds"):][:2] if "--fuzz-seeds" in sys.argv else []), env=env, check=True)
         ap = np.load(f)
         approx = {k: ap[k] for k in ap.files}
     os.environ.pop("EPPM_HIP_VARIANT", None)

@@ -309,6 +309,15 @@ __device__ __forceinline__ float tol_exp_arg(uint32_t off4k, float lsrc)
     const float kf = __uint_as_float(off4k) * 0x1p100f;
     return __builtin_fmaf(kf * kf, -kTolExpC * 0x1p98f, lsrc);
 }
+// The same argument with the distance formed directly as the normal float 4k * 2^-49: the centre texel is kept scaled by 2^100
+// (tol_scale_centre, once per candidate) and each channel difference is ONE fma, sample * 2^100 - centre (exact) -- the values of
+// tol_exp_arg(linf_off(c, p), lsrc) bit for bit, one multiplication fewer per term
+__device__ __forceinline__ rgbf tol_scale_centre(const rgbf c) { return rgbf{c.x * 0x1p100f, c.y * 0x1p100f, c.z * 0x1p100f}; }
+__device__ __forceinline__ float tol_exp_arg_scaled(const rgbf cs, const rgbf p, float lsrc)
+{
+    const float kf = fmaxf(fmaxf(fabsf(__builtin_fmaf(p.x, 0x1p100f, -cs.x)), fabsf(__builtin_fmaf(p.y, 0x1p100f, -cs.y))), fabsf(__builtin_fmaf(p.z, 0x1p100f, -cs.z)));
+    return __builtin_fmaf(kf * kf, -kTolExpC * 0x1p98f, lsrc);
+}
 // a word {R, G, B, census} of the 4-byte planes -> the texel make_texel builds from it: three SDWA shifts (byte k << 2) and a byte permute
 // (census into all four bytes), 16 issue cycles; `two` = a register holding 2 (an SDWA operand cannot be an inline constant)
 __device__ __forceinline__ float4 unpack_texel(uint32_t w, uint32_t two)

@@ -200,6 +200,7 @@ __device__ __forceinline__ void c2f_pass(const Planes& P, const PatchLutT<R + 1>
     const C2fTables<R>& T = c2f_tables<R>();
 #ifdef EPPM_TOL
     const float* __restrict__ lg2 = L.gsp;          // log2(gs_j gs_i), load_patch_lut<true>
+    const rgbf c1s = tol_scale_centre(c1), c2s[3] = {tol_scale_centre(c2[0]), tol_scale_centre(c2[1]), tol_scale_centre(c2[2])};
 #endif
     float cs[3] = {0.0f, 0.0f, 0.0f}, ws[3] = {0.0f, 0.0f, 0.0f};
     const unsigned pitch16 = (unsigned)P.pitch << 4;
@@ -219,7 +220,7 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
             const rgbf p1 = texel_rgb(q1);
             const uint32_t k1 = __float_as_uint(q1.w);
 #ifdef EPPM_TOL
-            const float lsrc = tol_exp_arg(linf_off(c1, p1), lg2[ii * S + jj]);               // log2 of the source half of the weight: once per sample
+            const float lsrc = tol_exp_arg_scaled(c1s, p1, lg2[ii * S + jj]);                 // log2 of the source half of the weight: once per sample
 #else
             float a2 = max_abs_diff(c1, p1);
             a2 *= a2;
@@ -249,7 +250,7 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
                 const rgbf p2 = texel_rgb(q2[n]);
 #ifdef EPPM_TOL
                 const float cost = tol_cost(L.tab(), p1, p2, k1, __float_as_uint(q2[n].w));
-                patch_accum(cs[n], ws[n], cost, __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2[n], p2), lsrc)));
+                patch_accum(cs[n], ws[n], cost, __builtin_amdgcn_exp2f(tol_exp_arg_scaled(c2s[n], p2, lsrc)));
 #else
                 float cost = max_abs_diff(p1, p2);
                 cost = EPPM_DELTA_PATCH ? delta_lookup(L.D, cost) : one_minus_fast_exp(div_ad2(-(cost * cost)));      // the same bits either way (eppm_device.cuh: DeltaTab)
@@ -423,6 +424,7 @@ __device__ __forceinline__ void c2f_pass2_win(const PatchLutT<R + 1>& L, const f
     const C2fTables<R>& T = c2f_tables<R>();
 #ifdef EPPM_TOL
     const float* __restrict__ lg2 = L.gsp;          // log2(gs_j gs_i), load_patch_lut<true>
+    const rgbf c1s = tol_scale_centre(c1), c2s[3] = {tol_scale_centre(c2[0]), tol_scale_centre(c2[1]), tol_scale_centre(c2[2])};
 #endif
     float csA[3] = {0.0f, 0.0f, 0.0f}, wsA[3] = {0.0f, 0.0f, 0.0f}, csB[3] = {0.0f, 0.0f, 0.0f}, wsB[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll 1
@@ -435,7 +437,7 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
             const rgbf p1 = texel_rgb(q1);
             const uint32_t k1 = __float_as_uint(q1.w);
 #ifdef EPPM_TOL
-            const float lsrc = tol_exp_arg(linf_off(c1, p1), lg2[ii * S + jj]);               // log2 of the source half of the weight: once per 6 terms
+            const float lsrc = tol_exp_arg_scaled(c1s, p1, lg2[ii * S + jj]);                 // log2 of the source half of the weight: once per 6 terms
 #else
             float a2 = max_abs_diff(c1, p1);
             a2 *= a2;
@@ -454,12 +456,12 @@ EPPM_UNROLL(EPPM_C2F_UNROLL)
                 {
                     const rgbf p2 = texel_rgb(qa[n]);
                     const float cost = tol_cost(L.tab(), p1, p2, k1, __float_as_uint(qa[n].w));
-                    patch_accum(csA[n], wsA[n], cost, __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2[n], p2), lsrc)));
+                    patch_accum(csA[n], wsA[n], cost, __builtin_amdgcn_exp2f(tol_exp_arg_scaled(c2s[n], p2, lsrc)));
                 }
                 {
                     const rgbf p2 = texel_rgb(qb[n]);
                     const float cost = tol_cost(L.tab(), p1, p2, k1, __float_as_uint(qb[n].w));
-                    patch_accum(csB[n], wsB[n], cost, __builtin_amdgcn_exp2f(tol_exp_arg(linf_off(c2[n], p2), lsrc)));
+                    patch_accum(csB[n], wsB[n], cost, __builtin_amdgcn_exp2f(tol_exp_arg_scaled(c2s[n], p2, lsrc)));
                 }
 #else
                 {

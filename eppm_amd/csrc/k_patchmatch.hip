@@ -160,6 +160,8 @@ template <int M> __device__ __forceinline__ float patch_dist_any(const Planes&, 
 // (The source half of a sample's weight is the same for the six guesses of a pixel; forming it once per workgroup in LDS -- 26 KB,
 // [sample][pixel] -- and a barrier LOSES here as it did in the exact library: search 215 -> 234 us per 8-pair launch, bench 304 -> 298,
 // profiles/r06x_c_search_hoist.txt.)
+#define EPPM_PM_PRAGMA_(x) _Pragma(#x)
+#define EPPM_PM_UNROLL(n) EPPM_PM_PRAGMA_(unroll n)
 template <int RT, int PK = 0, class LUT>
 __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L, int R, const float4* __restrict__ s_src, int TW,
                                                    int tx, int ty, int x1, int y1, int x2, int y2, const PlanesH& PH)
@@ -193,7 +195,14 @@ __device__ __forceinline__ float search_patch_dist(const Planes& P, const LUT& L
                 wq[4 * g] = v.x; wq[4 * g + 1] = v.y; wq[4 * g + 2] = v.z; wq[4 * g + 3] = v.w;
             }
             { const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, ro + 4 * (S - 2), 0, 0); wq[S - 2] = v.x; wq[S - 1] = v.y; }
-#pragma unroll
+            // terms of a row the compiler may interleave: a divisor of S that keeps the kernel at 65 VGPRs = 7 waves per SIMD (radius 9: 5 of
+            // 10 -- all 10: 77 VGPRs = 6 waves, search 226 -> 213 us; radius 17: 9 of 18 -- all 18: 98 VGPRs)
+#ifdef EPPM_SEARCH_TERM_UNROLL
+            constexpr int TU = EPPM_SEARCH_TERM_UNROLL;
+#else
+            constexpr int TU = (S % 5 == 0) ? 5 : (S % 9 == 0) ? 9 : S;
+#endif
+EPPM_PM_UNROLL((TU))
             for (int jj = 0; jj < S; jj++) {
                 float ct, wt;
                 patch_terms(srow[2 * jj], unpack_texel(wq[jj], two), c1, c2, L.gsp[ii * S + jj], L.tab(), ct, wt);
